@@ -1,0 +1,16 @@
+# liblasr.so: hand-written HIP for gfx950 (MI355X).  `make` builds the library in-tree.
+HIPCC ?= hipcc
+ARCH ?= gfx950
+SRC := $(wildcard lightning_asr_amd/csrc/*.hip)
+OBJ := $(patsubst lightning_asr_amd/csrc/%.hip,build/%.o,$(SRC))
+CXXFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Wall -Wno-unused-function
+
+lightning_asr_amd/liblasr.so: $(OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+build/%.o: lightning_asr_amd/csrc/%.hip lightning_asr_amd/csrc/common.h include/lasr.h
+	@mkdir -p build
+	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+
+clean:
+	rm -rf build lightning_asr_amd/liblasr.so

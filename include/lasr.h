@@ -1,0 +1,235 @@
+/* lasr.h — C ABI of liblasr.so: the MI355X (gfx950) QuartzNet-CTC training hot path.
+ *
+ * The reference (kouyt5/lightning-asr) is pure Python and has NO FFI layer: its hot path runs
+ * through torch / torchaudio operator calls.  Each entry point below therefore cites the
+ * reference Python call site (path:line under the reference tree) whose arithmetic it replaces;
+ * INTEGRATION.md shows the ctypes binding a maintainer adds at that call site.
+ *
+ * Conventions
+ *   - plain C, POD arguments only: raw device pointers, int64 sizes, enums, hipStream_t as void*.
+ *   - the CALLER owns every buffer (inputs, outputs, workspaces); the library allocates nothing
+ *     on the device and never synchronises it.  All work is enqueued on `stream`.
+ *   - return value: 0 = ok, <0 = LASR_E_* (bad argument/shape), >0 = hipError_t passthrough.
+ *     lasr_last_error() returns a thread-local message for the last non-zero return.
+ *   - activation layout is channels-last: a (B, C, T) reference tensor is stored [B][T][C]
+ *     ("rows" n = b*T + t).  dtype of activations: LASR_F32 (parity mode) or LASR_BF16.
+ *     Statistics, parameters, log-probs, CTC and the optimiser are always f32.
+ */
+#ifndef LASR_H
+#define LASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LASR_VERSION 100
+
+enum { LASR_F32 = 0, LASR_BF16 = 1 };
+enum { LASR_ACT_NONE = 0, LASR_ACT_RELU = 1, LASR_ACT_SWISH = 2 };
+enum { LASR_VARIANT_PLAIN = 0, LASR_VARIANT_CONTEXT = 1, LASR_VARIANT_CONTEXT_SE = 2 };
+enum {
+  LASR_E_ARG = -1,      /* null pointer / negative size / unsupported enum */
+  LASR_E_SHAPE = -2,    /* shape outside what the kernels are built for */
+  LASR_E_WORKSPACE = -3 /* workspace too small */
+};
+
+int lasr_version(void);
+const char* lasr_last_error(void);
+
+/* ---------------------------------------------------------------- features ----------------
+ * data_module.py:150-174 AudioParser.parse_audio (torchaudio MelSpectrogram(16000, n_fft=512,
+ * pad=32, win_length=320, hop_length=160, n_mels=64) + AmplitudeToDB('power'), :68-71):
+ * dither (optional, noise passed in) -> pre-emphasis 0.97 -> |STFT|^2 -> HTK mel(64) ->
+ * 10 log10(max(.,1e-10)) -> [SpecAugment rows/cols := 0, :97-122] -> (x-mean)/std (unbiased
+ * over the utterance's own 64*T_b values, :171-172) -> zero padding past T_b (collate :222-248).
+ */
+int64_t lasr_mel_num_frames(int64_t n_samples); /* 1 + (n_samples + 64) / 160 */
+size_t lasr_mel_workspace_bytes(int64_t B, int64_t T);
+/* wave (B, L) f32, sample_lens (B) int32 valid samples per row (NULL = all L),
+ * dither (B, L) f32 N(0,1) noise or NULL, aug (B,4) int32 {rect_x,w_x,rect_y,w_y} or NULL.
+ * out_bft: (B, 64, T) f32 reference layout, may be NULL.
+ * out_btf: (B, T, 64) channels-last in `dtype`, may be NULL.
+ * frames_out (B) int32 = frames per utterance; pct_out (B) f32 = frames/T (collate :243).
+ * normalize: 0 = stop at dB (no mean/std), 1 = full chain.                                   */
+int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dither, const int32_t* aug,
+                 int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,
+                 int32_t* frames_out, float* pct_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* (B, C, T) f32 reference layout -> [B][T][C] channels-last `dtype`   (models/QuartNet.py:154 squeeze) */
+int lasr_bct_to_btc(const float* in, void* out, int dtype, int64_t B, int64_t C, int64_t T, void* stream);
+int lasr_btc_to_bct(const void* in, int dtype, float* out, int64_t B, int64_t C, int64_t T, void* stream);
+
+/* lens[b] = int32(trunc(f32(T) * pct[b]))   (models/QuartNet.py:311, train.py:76) */
+int lasr_mask_lengths(const float* pct, int64_t B, int64_t T, int32_t* lens, void* stream);
+
+/* ---------------------------------------------------------------- conv block pieces -------
+ * models/QuartNet.py:29-39 SeprationConv.forward and :71-78 QuartNetBlock.forward.            */
+
+/* depthwise conv1d, groups=C, zero padding k/2, no bias (models/QuartNet.py:19-21,30).
+ * x [B][Tin][C] -> y [B][Tout][C], Tout = (Tin + 2*(k/2) - k)/stride + 1.  w (C, k) f32.
+ * flip=1 correlates with the time-reversed taps (the data-gradient of a stride-1 conv).
+ * addend (same shape as y, may be NULL) is added to the result.                               */
+int lasr_dwconv_fwd(const void* x, const float* w, const void* addend, void* y, int dtype, int64_t B,
+                    int64_t Tin, int64_t C, int k, int stride, int flip, void* stream);
+/* dw (C, k) f32 = sum_{b,t} dy[b,t,c] * x[b, t*stride + j - k/2, c].  workspace: f32 partials. */
+size_t lasr_dwconv_wgrad_workspace_bytes(int64_t B, int64_t Tout, int64_t C, int k);
+int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int dtype, int64_t B, int64_t Tin,
+                      int64_t C, int k, int stride, void* workspace, size_t workspace_bytes, void* stream);
+
+/* General GEMM on row-major device matrices, f32 accumulate on MFMA:
+ *   C[M][N] = sum_k opA(A)[m][k] * opB(B)[n][k]  (+ bias[n]) (+ addend[m][n])
+ * transA=0: A is [M][K] (K contiguous); transA=1: A is [K][M].  transB=0: B is [N][K]; 1: [K][N].
+ * dtype_ab / dtype_c: LASR_F32 or LASR_BF16 (A and B share a dtype).
+ * row_lens/rows_per_seq: if row_lens != NULL, output row m = b*rows_per_seq + t is written as
+ *   zero when t >= row_lens[b]  (MaskCNN, models/QuartNet.py:309-321, applied BEFORE BN).
+ * stats (2*N f32, may be NULL): stats[n] = sum_m C[m][n], stats[N+n] = sum_m C[m][n]^2 over the
+ *   stored (masked, dtype-rounded) values, summed in a fixed order through `workspace`
+ *   (feeds training-mode BatchNorm1d, :35).  Replaces pointwise_conv / reside.0 / last_cnn2.0 /
+ *   decoder (models/QuartNet.py:31,63,146,275) and their autograd backward GEMMs.
+ * split_k > 1 sums partial products through `workspace` (split_k*M*N f32), deterministic;
+ *   it excludes row masking and statistics.                                                     */
+size_t lasr_gemm_workspace_bytes(int64_t M, int64_t N, int split_k, int want_stats);
+int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N,
+              int64_t K, int transA, int transB, const float* bias, const void* addend,
+              const int32_t* row_lens, int64_t rows_per_seq, float* stats, int split_k, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* Training-mode BatchNorm1d(eps) statistics -> affine coefficients (models/QuartNet.py:24,35):
+ * mean = s/n, var = q/n - mean^2 (biased); coef[c] = gamma*rstd, coef[C+c] = beta - mean*gamma*rstd;
+ * saved[c] = mean, saved[C+c] = rstd; running_mean/var updated with momentum (unbiased var) when
+ * non-NULL.  training=0: coefficients from the running statistics, stats ignored.              */
+int lasr_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float* coef, float* saved, int64_t C, int64_t n_rows, float eps,
+                     float momentum, int training, void* stream);
+
+/* out = act( (y*coef_a + coef_b) * se_scale[b][c] + (y2*coef2_a + coef2_b) )
+ * y2/coef2 (residual branch) and se_scale ([B][C] f32) may be NULL.
+ * (BN-apply + SE scale + residual add + ReLU: models/QuartNet.py:35-37,74-77; ContextSE :55) */
+int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2, const float* coef2,
+                    const float* se_scale, void* out, int dtype, int64_t B, int64_t T, int64_t C, int act,
+                    void* stream);
+
+/* Backward of the above + BatchNorm backward, two passes over the activations:
+ * pass 1 (stats): d = dout * act'(.) ; sums[0..C) = sum d*se, [C..2C) = sum d*se*yhat for branch 1
+ *                 and the same for branch 2 in sums2 (se=1 there); yhat = (y-mean)*rstd.
+ * pass 2 (apply): dy = gamma*rstd * (d*se - s1/n - yhat*s2/n), rows t >= row_lens[b] zeroed for
+ *                 branch 1 only (the residual branch is never masked, models/QuartNet.py:75).
+ * The pre-activation is rebuilt from y/y2 and the coefficients, so the forward output is not read.
+ * dgamma = s2, dbeta = s1 are written by pass 2 (f32, may be NULL).
+ * se_grad ([B][C] f32, may be NULL): extra per-(b,c) gradient added to d*se (SE pooled path).  */
+size_t lasr_bn_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
+int lasr_bn_act_bwd_stats(const void* dout, const void* y, const float* coef,
+                          const float* saved, const void* y2, const float* coef2, const float* saved2,
+                          const float* se_scale, const float* se_grad, float* sums, float* sums2, int dtype,
+                          int64_t B, int64_t T, int64_t C, int act, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int lasr_bn_act_bwd_apply(const void* dout, const void* y, const float* coef,
+                          const float* saved, const float* gamma, const void* y2, const float* coef2,
+                          const float* saved2, const float* gamma2, const float* se_scale,
+                          const float* se_grad, const float* sums, const float* sums2,
+                          const int32_t* row_lens, void* dy, void* dy2, float* dgamma, float* dbeta,
+                          float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T, int64_t C, int act,
+                          void* stream);
+
+/* ---------------------------------------------------------------- head + loss --------------
+ * models/QuartNet.py:287-290 log_softmax over classes; train.py:76-78,196 CTCLoss(blank=C-1,
+ * reduction='none', zero_infinity=False) and the batch mean; utils/asr_metrics.py:138-171.     */
+
+/* logits [N][C] f32 -> logp [N][C] f32 (may alias logits), argmax (N) int32 (may be NULL).
+ * Ties resolve to the lowest class id, as torch.argmax does on CPU.                            */
+int lasr_log_softmax(const float* logits, float* logp, int32_t* argmax, int64_t N, int64_t C, void* stream);
+/* grad_logits = grad_logp - exp(logp) * sum_c grad_logp   (autograd of F.log_softmax) */
+int lasr_log_softmax_bwd(const float* logp, const float* grad_logp, float* grad_logits, int64_t N, int64_t C,
+                         void* stream);
+
+size_t lasr_ctc_workspace_bytes(int64_t B, int64_t T, int64_t S_max);
+/* logp (B, T, C) f32 log-probs; targets (B, S_max) int64 zero padded; in_lens/tgt_lens (B) int32.
+ * nll (B) f32 per-sample negative log-likelihood (+inf when infeasible).
+ * If grad != NULL: grad (B,T,C) f32 = gscale[b] * (exp(logp) - occupancy): exactly what torch's
+ *   CTCLoss backward returns for grad_output = gscale.  Its class-sum is 0, so log_softmax backward
+ *   maps it to itself: it is also d/d(logits).  Rows t >= in_lens[b] are zero; rows of an infeasible
+ *   sample are NaN (zero_infinity=False).  gscale (B) f32 or NULL (= 1/B: batch mean, train.py:77).
+ *   S_max <= 511 (lattice of 2S+1 states held 4/8/16 per lane of one wave).                       */
+int lasr_ctc_loss(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens,
+                  int64_t B, int64_t T, int64_t C, int64_t S_max, int blank, float* nll, float* grad,
+                  const float* gscale, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Greedy CTC collapse of argmax ids (B, T) int32 truncated to lens (B) (NULL = T):
+ * tokens (B, T) int32, n_tokens (B) int32.   utils/asr_metrics.py:159-166                      */
+int lasr_greedy_decode(const int32_t* ids, const int32_t* lens, int64_t B, int64_t T, int blank,
+                       int32_t* tokens, int32_t* n_tokens, void* stream);
+
+/* ---------------------------------------------------------------- optimiser ----------------
+ * scheduler/novograd.py:75-145 with betas=(0.8,0.5), eps=1e-8, no amsgrad/grad_averaging/luc
+ * (train.py:46), applied to all tensors in one pass over flat f32 buffers.
+ * offsets (n_tensors+1) int64 element offsets into params/grads/exp_avg; exp_avg_sq (n_tensors) f32
+ * (0 = "not initialised", scheduler/novograd.py:115).  lr is read from the device (1 f32) so a
+ * captured graph can replay it.  grad_scale multiplies grads first (1/world after all-reduce).   */
+size_t lasr_novograd_workspace_bytes(int64_t n_tensors, int64_t n_elems);
+int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       const int64_t* offsets, int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2,
+                       float eps, float weight_decay, float grad_scale, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* small helpers used by the plan and by the host */
+int lasr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C);
+int lasr_colsum_f32(const float* x, float* out, int64_t rows, int64_t C, void* workspace, size_t workspace_bytes,
+                    void* stream);                                   /* out[c] = sum_r x[r][c] (decoder bias grad) */
+int lasr_scale_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream); /* torch.mean, train.py:77 */
+
+/* ---------------------------------------------------------------- whole model ---------------
+ * MyModel2 (models/QuartNet.py:264-291; QuartNetContext.py:202; QuartNetContextSE.py:220) driven
+ * as one native plan: the library sequences every kernel of forward, loss and backward on
+ * `stream` from a single call, over caller-owned flat buffers.                                  */
+typedef struct lasr_model lasr_model_t;
+
+typedef struct {
+  int32_t variant;   /* LASR_VARIANT_* */
+  int32_t n_class;   /* len(labels)+1; blank = n_class-1 */
+  int32_t in_c;      /* 64 */
+  int32_t mask;      /* model.mask (conf/conf.yaml:36) */
+  int32_t act;       /* LASR_ACT_RELU (reference) or LASR_ACT_SWISH */
+  int32_t dtype;     /* activation dtype */
+} lasr_model_config;
+
+int lasr_model_create(const lasr_model_config* cfg, lasr_model_t** out);
+void lasr_model_destroy(lasr_model_t* m);
+/* Tensors in reference state_dict order.  kind: 0 = parameter (lives in the flat param buffer at
+ * `offset` elements), 1 = f32 buffer (running_mean/var, flat buffer array), 2 = num_batches_tracked
+ * (int64, kept by the host).  Returns the number of tensors; fills row i when i >= 0.            */
+int64_t lasr_model_tensor_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap,
+                               int64_t shape[4], int32_t* ndim, int32_t* kind, int64_t* offset);
+int64_t lasr_model_param_elems(const lasr_model_t* m);
+int64_t lasr_model_buffer_elems(const lasr_model_t* m);
+int64_t lasr_model_out_frames(const lasr_model_t* m, int64_t T_in);
+size_t lasr_model_workspace_bytes(lasr_model_t* m, int64_t B, int64_t T_in, int64_t S_max);
+/* Named intermediate ("tap": unit name, "<unit>.y", "<unit>.u", "logits", "grad_logits", "lens")
+ * inside the workspace after a forward: returns its byte offset, or -1.                          */
+int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, int64_t T_in, int64_t S_max, int64_t shape[3]);
+
+/* feats: [B][T_in][in_c] channels-last in cfg.dtype (from lasr_mel_fwd / lasr_bct_to_btc).
+ * logp_out (B, T', n_class) f32; argmax_out (B, T') int32 or NULL.  training=1 uses batch
+ * statistics, updates `buffers`, and keeps what backward needs in the workspace.                */
+int lasr_model_forward(lasr_model_t* m, const float* params, float* buffers, const void* feats,
+                       const float* pct, int64_t B, int64_t T_in, int training, float* logp_out,
+                       int32_t* argmax_out, void* workspace, size_t workspace_bytes, void* stream);
+/* After a training forward in the same workspace: logp (B,T',C) as returned by it, grad_logp = dL/d logp
+ * -> grads (flat f32, same layout as params; every element overwritten).                          */
+int lasr_model_backward(lasr_model_t* m, const float* params, const void* feats, const float* logp,
+                        const float* grad_logp, int64_t B, int64_t T_in, float* grads, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* forward + mean CTC (train.py:75-78) + backward in one call.  loss_out (1) f32, nll_out (B) f32. */
+int lasr_model_loss_backward(lasr_model_t* m, const float* params, float* buffers, const void* feats,
+                             const float* pct, const int64_t* targets, const int32_t* tgt_lens, int64_t B,
+                             int64_t T_in, int64_t S_max, float* logp_out, float* loss_out, float* nll_out,
+                             int32_t* argmax_out, float* grads, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LASR_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of liblasr.so (include/lasr.h).  There is no CPU fallback: if the HIP library is
+missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblasr.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+VARIANT = {"plain": 0, "context": 1, "context_se": 2}
+
+_p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("n_class", C.c_int32), ("in_c", C.c_int32),
+                ("mask", C.c_int32), ("act", C.c_int32), ("dtype", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/lasr.h declares
+SIGNATURES = {
+    "lasr_version": (_i32, []),
+    "lasr_last_error": (C.c_char_p, []),
+    "lasr_mel_num_frames": (_i64, [_i64]),
+    "lasr_mel_workspace_bytes": (_sz, [_i64, _i64]),
+    "lasr_mel_fwd": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _p, _sz, _p]),
+    "lasr_bct_to_btc": (_i32, [_p, _p, _i32, _i64, _i64, _i64, _p]),
+    "lasr_btc_to_bct": (_i32, [_p, _i32, _p, _i64, _i64, _i64, _p]),
+    "lasr_mask_lengths": (_i32, [_p, _i64, _i64, _p, _p]),
+    "lasr_dwconv_fwd": (_i32, [_p, _p, _p, _p, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _p]),
+    "lasr_dwconv_wgrad_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
+    "lasr_dwconv_wgrad": (_i32, [_p, _p, _p, _i32, _i64, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "lasr_gemm_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "lasr_gemm": (_i32, [_p, _p, _p, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _sz, _p]),
+    "lasr_bn_finalize": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _f32, _i32, _p]),
+    "lasr_bn_act_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i64, _i32, _p]),
+    "lasr_bn_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lasr_bn_act_bwd_stats": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),
+    "lasr_bn_act_bwd_apply": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p]),
+    "lasr_log_softmax": (_i32, [_p, _p, _p, _i64, _i64, _p]),
+    "lasr_log_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i64, _p]),
+    "lasr_ctc_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lasr_ctc_loss": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    "lasr_greedy_decode": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p]),
+    "lasr_novograd_workspace_bytes": (_sz, [_i64, _i64]),
+    "lasr_novograd_step": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p, _sz, _p]),
+    "lasr_cast_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
+    "lasr_colsum_workspace_bytes": (_sz, [_i64, _i64]),
+    "lasr_colsum_f32": (_i32, [_p, _p, _i64, _i64, _p, _sz, _p]),
+    "lasr_scale_sum_f32": (_i32, [_p, _i64, _f32, _p, _p]),
+    "lasr_model_create": (_i32, [C.POINTER(ModelConfig), C.POINTER(_p)]),
+    "lasr_model_destroy": (None, [_p]),
+    "lasr_model_tensor_info": (_i64, [_p, _i64, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(_i64)]),
+    "lasr_model_param_elems": (_i64, [_p]),
+    "lasr_model_buffer_elems": (_i64, [_p]),
+    "lasr_model_out_frames": (_i64, [_p, _i64]),
+    "lasr_model_workspace_bytes": (_sz, [_p, _i64, _i64, _i64]),
+    "lasr_model_tap": (_i64, [_p, C.c_char_p, _i64, _i64, _i64, C.POINTER(_i64)]),
+    "lasr_model_forward": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "lasr_model_backward": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
+    "lasr_model_loss_backward": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+}
+
+_lib = None
+
+
+class LasrError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load liblasr.so (built in-tree by ``make`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LasrError("liblasr.so not found at %s: build it with `make` (hipcc --offload-arch=gfx950); "
+                        "there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().lasr_last_error()
+        raise LasrError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point and raise on a non-zero status."""
+    check(getattr(load(), name)(*args), name)

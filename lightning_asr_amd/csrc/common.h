@@ -1,0 +1,111 @@
+// Shared helpers for liblasr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/lasr.h"
+
+namespace lasr {
+
+// ---- error state (thread local, message only; codes travel as return values) -----------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define LASR_CHECK_ARG(cond, ...)                         \
+  do {                                                    \
+    if (!(cond)) return ::lasr::fail(LASR_E_ARG, __VA_ARGS__); \
+  } while (0)
+#define LASR_CHECK_SHAPE(cond, ...)                         \
+  do {                                                      \
+    if (!(cond)) return ::lasr::fail(LASR_E_SHAPE, __VA_ARGS__); \
+  } while (0)
+#define LASR_LAUNCH_CHECK(name)                                   \
+  do {                                                            \
+    hipError_t e__ = hipGetLastError();                           \
+    if (e__ != hipSuccess) return ::lasr::hip_fail(e__, name);    \
+  } while (0)
+#define LASR_TRY(expr)          \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline size_t dtype_size(int dtype) { return dtype == LASR_BF16 ? 2 : 4; }
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------
+typedef uint16_t bf16_t;  // raw storage
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+  __hip_bfloat16 h = __float2bfloat16(f);
+  return *reinterpret_cast<bf16_t*>(&h);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int kDtype = LASR_F32;
+  static constexpr int kVec = 4;  // elements per 16-byte access
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ void ld4(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  __device__ static __forceinline__ void st4(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int kDtype = LASR_BF16;
+  static constexpr int kVec = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  __device__ static __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
+    uint2 v = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void st4(bf16_t* p, const float (&o)[4]) {
+    uint2 v;
+    v.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+};
+
+// ---- wave / block reductions (wave = 64 lanes) -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  if (act == LASR_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == LASR_ACT_SWISH) return x / (1.f + __expf(-x));
+  return x;
+}
+
+}  // namespace lasr

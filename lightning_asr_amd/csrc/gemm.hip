@@ -1,0 +1,305 @@
+// MFMA GEMM for the 1x1 ("pointwise") convolutions and every GEMM-shaped gradient:
+//   C[M][N] = sum_k opA(A)[m][k] * opB(B)[n][k]  (+bias[n]) (+addend[m][n]), rows masked, BN sums.
+// Replaces pointwise_conv / reside.0 / last_cnn2.0 / decoder (models/QuartNet.py:31,63,146,275)
+// and their autograd backward GEMMs (dgrad: transB=1, wgrad: transA=1,transB=1 with split-K).
+//
+// This file holds the exact-f32 path: v_mfma_f32_32x32x2_f32 (bitwise a k-ordered fmaf chain,
+// 64 FLOP/clk/SIMD).  128x128x16 block tile, 4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32.
+// Both operands are staged K-major in LDS ([k][m], [k][n]) so a fragment read is 32 consecutive
+// floats per half-wave (conflict-free ds_read_b32) whatever the global layout was.
+#include "common.h"
+
+namespace lasr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BM = 128, BN = 128, BK = 16;
+static constexpr int LDS_LD = BM + 4;  // row stride of the K-major tiles
+
+// Load one BK x 128 operand tile (rows = k, cols = m) of op(X) into registers (8 floats / thread).
+// TRANS=false: X is [R][K] (k contiguous): thread -> row = tid/4 + 64*p, k = 4*(tid%4)..+3
+// TRANS=true : X is [K][R] (r contiguous): thread -> k = tid/32 + 8*p, r = 4*(tid%32)..+3
+template <typename T, bool TRANS>
+__device__ __forceinline__ void load_tile(const T* __restrict__ X, int64_t ld, int64_t R, int64_t K, int64_t r0, int64_t k0,
+                                          int64_t kend, bool vec_ok, float (&reg)[2][4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    reg[p][0] = reg[p][1] = reg[p][2] = reg[p][3] = 0.f;
+    if (!TRANS) {
+      const int64_t r = r0 + (tid >> 2) + 64 * p;
+      const int64_t k = k0 + ((tid & 3) << 2);
+      if (r < R) {
+        const T* src = X + r * ld + k;
+        if (vec_ok && k + 3 < kend) {
+          Elem<T>::ld4(src, reg[p]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) reg[p][e] = Elem<T>::ld(src + e);
+        }
+      }
+    } else {
+      const int64_t k = k0 + (tid >> 5) + 8 * p;
+      const int64_t r = r0 + ((tid & 31) << 2);
+      if (k < kend) {
+        const T* src = X + k * ld + r;
+        if (vec_ok && r + 3 < R) {
+          Elem<T>::ld4(src, reg[p]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (r + e < R) reg[p][e] = Elem<T>::ld(src + e);
+        }
+      }
+    }
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float (&reg)[2][4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (!TRANS) {
+      const int r = (tid >> 2) + 64 * p;
+      const int k = (tid & 3) << 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[(k + e) * LDS_LD + r] = reg[p][e];
+    } else {
+      const int k = (tid >> 5) + 8 * p;
+      const int r = (tid & 31) << 2;
+      *reinterpret_cast<float4*>(s + k * LDS_LD + r) = make_float4(reg[p][0], reg[p][1], reg[p][2], reg[p][3]);
+    }
+  }
+}
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  int64_t M, N, K, lda, ldb, ldc;
+  const float* bias; const void* addend;
+  const int32_t* row_lens; int64_t rows_per_seq;
+  float* stat_partials;  // [gridM][2][N] or null
+  float* split_ws;       // [split][M][N] or null
+  int64_t k_per_split;
+  int vecA, vecB;
+};
+
+// grid: (ceil(N/BN), ceil(M/BM), split_k)
+template <typename TAB, typename TC, bool TRANS_A, bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float sA[BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float sB[BK * LDS_LD];
+  __shared__ float s_stat[2][2][BN];  // [wm][sum|sq][col]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+  const TAB* A = reinterpret_cast<const TAB*>(g.A);
+  const TAB* B = reinterpret_cast<const TAB*>(g.B);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float ra[2][4], rb[2][4];
+  load_tile<TAB, TRANS_A>(A, g.lda, g.M, g.K, m0, kbeg, kend, g.vecA, ra);
+  load_tile<TAB, TRANS_B>(B, g.ldb, g.N, g.K, n0, kbeg, kend, g.vecB, rb);
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();
+    store_tile<TRANS_A>(sA, ra);
+    store_tile<TRANS_B>(sB, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      load_tile<TAB, TRANS_A>(A, g.lda, g.M, g.K, m0, k0 + BK, kend, g.vecA, ra);
+      load_tile<TAB, TRANS_B>(B, g.ldb, g.N, g.K, n0, k0 + BK, kend, g.vecB, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float* pa = sA + (kk + half) * LDS_LD + wm * 64 + l31;
+      const float* pb = sB + (kk + half) * LDS_LD + wn * 64 + l31;
+      const float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue.  acc[mi][ni][r]: row = wm*64 + mi*32 + (r&3) + 8*(r>>2) + 4*half, col = wn*64 + ni*32 + l31
+  if (g.split_ws) {
+    float* W = g.split_ws + (int64_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int64_t n = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < g.M && n < g.N) W[m * g.N + n] = acc[mi][ni][r];
+        }
+      }
+    return;
+  }
+  TC* C = reinterpret_cast<TC*>(g.C);
+  const TC* addend = reinterpret_cast<const TC*>(g.addend);
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t n = n0 + wn * 64 + ni * 32 + l31;
+    const bool n_ok = n < g.N;
+    const float bv = (g.bias && n_ok) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M && n_ok) {
+          float v = acc[mi][ni][r] + bv;
+          if (addend) v += Elem<TC>::ld(addend + m * g.ldc + n);
+          if (g.row_lens) {
+            const int64_t b = m / g.rows_per_seq;
+            if (m - b * g.rows_per_seq >= g.row_lens[b]) v = 0.f;
+          }
+          Elem<TC>::st(C + m * g.ldc + n, v);
+          if (g.stat_partials) {
+            // statistics of the value as stored (bf16-rounded when TC is bf16)
+            const float sv = Elem<TC>::kDtype == LASR_BF16 ? bf16_to_f32(f32_to_bf16(v)) : v;
+            csum[ni] += sv;
+            csq[ni] = fmaf(sv, sv, csq[ni]);
+          }
+        }
+      }
+    }
+  }
+  if (g.stat_partials) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      csum[ni] += __shfl_xor(csum[ni], 32, 64);
+      csq[ni] += __shfl_xor(csq[ni], 32, 64);
+      if (half == 0) {
+        s_stat[wm][0][wn * 64 + ni * 32 + l31] = csum[ni];
+        s_stat[wm][1][wn * 64 + ni * 32 + l31] = csq[ni];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int64_t n = n0 + tid;
+      if (n < g.N) {
+        float* P = g.stat_partials + (int64_t)blockIdx.y * 2 * g.N;
+        P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
+        P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+      }
+    }
+  }
+}
+
+// stats[i] = sum_blk partials[blk][i], i < 2N
+__global__ __launch_bounds__(256) void gemm_stats_reduce_kernel(const float* __restrict__ partials, int nblk, int64_t n2,
+                                                                float* __restrict__ stats) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partials[(int64_t)b * n2 + i];
+  stats[i] = (float)s;
+}
+
+// C = sum_s ws[s] (+bias)(+addend)
+template <typename TC>
+__global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                                int64_t ldc, const float* __restrict__ bias,
+                                                                const TC* __restrict__ addend, TC* __restrict__ C) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int64_t m = i / N, n = i - m * N;
+  float s = 0.f;
+  for (int p = 0; p < split; ++p) s += ws[(int64_t)p * M * N + i];
+  if (bias) s += bias[n];
+  if (addend) s += Elem<TC>::ld(addend + m * ldc + n);
+  Elem<TC>::st(C + m * ldc + n, s);
+}
+
+template <typename TAB, typename TC>
+static int launch_f32(const GemmArgs& g, int transA, int transB, dim3 grid, hipStream_t st) {
+#define LASR_GEMM_CASE(TA_, TB_)                                                                              \
+  hipLaunchKernelGGL((gemm_f32_kernel<TAB, TC, TA_, TB_>), grid, dim3(256), 0, st, g)
+  if (!transA && !transB) LASR_GEMM_CASE(false, false);
+  else if (!transA && transB) LASR_GEMM_CASE(false, true);
+  else if (transA && !transB) LASR_GEMM_CASE(true, false);
+  else LASR_GEMM_CASE(true, true);
+#undef LASR_GEMM_CASE
+  LASR_LAUNCH_CHECK("gemm_f32_kernel");
+  return 0;
+}
+
+}  // namespace lasr
+
+using namespace lasr;
+
+extern "C" size_t lasr_gemm_workspace_bytes(int64_t M, int64_t N, int split_k, int want_stats) {
+  size_t b = 0;
+  if (split_k > 1) b += align_up((size_t)split_k * M * N * sizeof(float), 256);
+  if (want_stats) b += align_up((size_t)cdiv(M, BM) * 2 * N * sizeof(float), 256);
+  return b;
+}
+
+extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,
+                         int transA, int transB, const float* bias, const void* addend, const int32_t* row_lens,
+                         int64_t rows_per_seq, float* stats, int split_k, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  LASR_CHECK_ARG(A && B && C, "lasr_gemm: null pointer");
+  LASR_CHECK_ARG((dtype_ab == LASR_F32 || dtype_ab == LASR_BF16) && (dtype_c == LASR_F32 || dtype_c == LASR_BF16), "lasr_gemm: bad dtype");
+  LASR_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && split_k >= 1 && split_k <= 1024, "lasr_gemm: M=%lld N=%lld K=%lld split=%d",
+                   (long long)M, (long long)N, (long long)K, split_k);
+  LASR_CHECK_ARG(!(row_lens && rows_per_seq <= 0), "lasr_gemm: rows_per_seq");
+  LASR_CHECK_ARG(!(split_k > 1 && (row_lens || stats)), "lasr_gemm: split_k excludes masking/statistics");
+  const size_t need = lasr_gemm_workspace_bytes(M, N, split_k, stats != nullptr);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return fail(LASR_E_WORKSPACE, "lasr_gemm: workspace %zu < %zu", workspace_bytes, need);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+  g.lda = transA ? M : K; g.ldb = transB ? N : K; g.ldc = N;
+  g.bias = bias; g.addend = addend; g.row_lens = row_lens; g.rows_per_seq = rows_per_seq;
+  g.stat_partials = nullptr; g.split_ws = nullptr;
+  const size_t esz = dtype_size(dtype_ab);
+  // 4-element vector loads need the row pitch and base to keep every 4-group aligned
+  g.vecA = (g.lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % (4 * esz) == 0);
+  g.vecB = (g.ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(B) % (4 * esz) == 0);
+  char* wsp = reinterpret_cast<char*>(workspace);
+  if (split_k > 1) {
+    g.split_ws = reinterpret_cast<float*>(wsp);
+    wsp += align_up((size_t)split_k * M * N * sizeof(float), 256);
+    const int64_t per = cdiv(cdiv(K, split_k), BK) * BK;
+    g.k_per_split = per;
+    split_k = (int)cdiv(K, per);
+  } else {
+    g.k_per_split = K;
+  }
+  const int grid_m = (int)cdiv(M, BM);
+  if (stats) g.stat_partials = reinterpret_cast<float*>(wsp);
+  dim3 grid((unsigned)cdiv(N, BN), (unsigned)grid_m, (unsigned)split_k);
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (dtype_ab == LASR_F32) rc = dtype_c == LASR_F32 ? launch_f32<float, float>(g, transA, transB, grid, st) : launch_f32<float, bf16_t>(g, transA, transB, grid, st);
+  else rc = dtype_c == LASR_F32 ? launch_f32<bf16_t, float>(g, transA, transB, grid, st) : launch_f32<bf16_t, bf16_t>(g, transA, transB, grid, st);
+  if (rc) return rc;
+  if (g.split_ws) {
+    const int64_t mn = M * N;
+    if (dtype_c == LASR_F32)
+      hipLaunchKernelGGL(gemm_split_reduce_kernel<float>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g.split_ws, split_k, M, N, g.ldc, bias, (const float*)addend, (float*)C);
+    else
+      hipLaunchKernelGGL(gemm_split_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g.split_ws, split_k, M, N, g.ldc, bias, (const bf16_t*)addend, (bf16_t*)C);
+    LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
+  }
+  if (stats) {
+    hipLaunchKernelGGL(gemm_stats_reduce_kernel, dim3((unsigned)cdiv(2 * N, 256)), dim3(256), 0, st, g.stat_partials, grid_m, 2 * N, stats);
+    LASR_LAUNCH_CHECK("gemm_stats_reduce_kernel");
+  }
+  return 0;
+}

@@ -1,0 +1,309 @@
+// Fused log-mel front-end for gfx950:  wave -> (dither) -> pre-emphasis -> Hann(320)/512-pt STFT
+// -> |.|^2 -> HTK mel(64) -> 10 log10 -> SpecAugment zeros -> per-utterance (x-mean)/std.
+// Replaces data_module.py:150-174 (torchaudio MelSpectrogram/AmplitudeToDB, :68-71).
+//
+// One 64-lane wave owns one frame: the 512-point FFT is three radix-8 Stockham passes, each lane
+// holding 8 complex points in registers and exchanging through LDS between passes.  A 256-thread
+// workgroup handles a tile of FRAMES_PER_BLOCK consecutive frames of one utterance, so the
+// (B,64,T) reference-layout store is done from an LDS transpose in 64-byte runs and the
+// channels-last store is a full 256-byte row per wave.
+#include "common.h"
+#include <math.h>
+#include <mutex>
+
+namespace lasr {
+
+static constexpr int kNfft = 512, kWin = 320, kHop = 160, kPad = 32, kMel = 64, kFreq = 257;
+static constexpr int kWinOff = (kNfft - kWin) / 2;  // 96
+static constexpr int kFramesPerBlock = 16;
+static constexpr int kWaves = 4;
+
+struct MelTables {
+  double window[kWin];
+  double tw_re[kNfft];
+  double tw_im[kNfft];
+  float fb[kFreq * kMel];  // [k][m]
+  int lo[kMel];            // first bin with non-zero weight
+  int hi[kMel];            // last bin with non-zero weight
+};
+__device__ MelTables g_mel;
+
+static int init_tables() {
+  static std::once_flag once;
+  static int rc = 0;
+  std::call_once(once, [] {
+    MelTables* t = new MelTables();
+    // the reference window is the f32 periodic Hann torch.hann_window returns
+    for (int n = 0; n < kWin; ++n) t->window[n] = (double)(float)(0.5 - 0.5 * cos(2.0 * M_PI * n / kWin));
+    for (int n = 0; n < kNfft; ++n) {
+      t->tw_re[n] = cos(-2.0 * M_PI * n / kNfft);
+      t->tw_im[n] = sin(-2.0 * M_PI * n / kNfft);
+    }
+    // HTK mel filterbank, torchaudio 0.8.1 create_fb_matrix(257, 0, 8000, 64, 16000, norm=None), f32 steps
+    float f_pts[kMel + 2];
+    const float m_min = 0.f, m_max = 2595.0f * log10f(1.0f + 8000.0f / 700.0f);
+    for (int i = 0; i < kMel + 2; ++i) {
+      float m = m_min + (m_max - m_min) * (float)i / (float)(kMel + 1);
+      f_pts[i] = 700.0f * (powf(10.0f, m / 2595.0f) - 1.0f);
+    }
+    for (int m = 0; m < kMel; ++m) { t->lo[m] = kFreq; t->hi[m] = -1; }
+    for (int k = 0; k < kFreq; ++k) {
+      const float f = 8000.0f * (float)k / (float)(kFreq - 1);
+      for (int m = 0; m < kMel; ++m) {
+        const float down = (f - f_pts[m]) / (f_pts[m + 1] - f_pts[m]);
+        const float up = (f_pts[m + 2] - f) / (f_pts[m + 2] - f_pts[m + 1]);
+        const float w = fmaxf(0.f, fminf(down, up));
+        t->fb[k * kMel + m] = w;
+        if (w > 0.f) {
+          if (k < t->lo[m]) t->lo[m] = k;
+          if (k > t->hi[m]) t->hi[m] = k;
+        }
+      }
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_mel), t, sizeof(MelTables));
+    delete t;
+    if (e != hipSuccess) rc = hip_fail(e, "mel table upload");
+  });
+  return rc;
+}
+
+// The transform runs in f64: the kernel is bound by its 20 MB of HBM traffic, not by 1.5 GFLOP of
+// butterflies, and f64 removes FFT round-off from the weak bins of high-dynamic-range frames.
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ void bfly(cplx& a, cplx& b) {
+  cplx t = a;
+  a = {t.re + b.re, t.im + b.im};
+  b = {t.re - b.re, t.im - b.im};
+}
+__device__ __forceinline__ cplx mul_negi(cplx a) { return {a.im, -a.re}; }  // a * (-i)
+
+// 8-point DFT in registers (decimation in frequency).  Natural-order result k lives in v[kPerm[k]].
+__device__ __forceinline__ void fft8(cplx (&v)[8]) {
+  const double h = 0.70710678118654752440;
+  bfly(v[0], v[4]); bfly(v[1], v[5]); bfly(v[2], v[6]); bfly(v[3], v[7]);
+  v[5] = cmul(v[5], cplx{h, -h});
+  v[6] = mul_negi(v[6]);
+  v[7] = cmul(v[7], cplx{-h, -h});
+  bfly(v[0], v[2]); bfly(v[1], v[3]); v[3] = mul_negi(v[3]);
+  bfly(v[0], v[1]); bfly(v[2], v[3]);
+  bfly(v[4], v[6]); bfly(v[5], v[7]); v[7] = mul_negi(v[7]);
+  bfly(v[4], v[5]); bfly(v[6], v[7]);
+}
+__device__ static const int kPerm[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+
+// sample of the zero-padded (32|L|32), pre-emphasised, dithered signal at padded index i in [0, L+64)
+__device__ __forceinline__ float padded_sample(const float* __restrict__ y, const float* __restrict__ nz,
+                                               int64_t L, int64_t i) {
+  const int64_t j = i - kPad;
+  if (j < 0 || j >= L) return 0.f;
+  // f32 steps, as the reference computes them (data_module.py:155,157)
+  float cur = y[j];
+  if (nz) cur += 1e-5f * nz[j];
+  if (j == 0) return cur;
+  float prev = y[j - 1];
+  if (nz) prev += 1e-5f * nz[j - 1];
+  return cur - 0.97f * prev;
+}
+
+// grid: (ceil(T/16), B), block 256.  dB values -> db_out [B][T][64] f32 (workspace); per-block
+// (sum, sumsq) in double -> partials[b][blk][2].
+__global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ wave, const int32_t* __restrict__ sample_lens,
+                                                     const float* __restrict__ dither, const int32_t* __restrict__ aug,
+                                                     int64_t L, int64_t T, float* __restrict__ db_out,
+                                                     double* __restrict__ partials, int32_t* __restrict__ frames_out,
+                                                     float* __restrict__ pct_out) {
+  __shared__ double s_re[kWaves][kNfft];
+  __shared__ double s_im[kWaves][kNfft];
+  __shared__ double s_twr[kNfft];
+  __shared__ double s_twi[kNfft];
+  __shared__ double s_red[kWaves][2];
+
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t Lb = sample_lens ? (int64_t)sample_lens[b] : L;
+  const int64_t Lp = Lb + 2 * kPad;
+  const int64_t Tb = 1 + Lp / kHop;
+  const float* y = wave + (int64_t)b * L;
+  const float* nz = dither ? dither + (int64_t)b * L : nullptr;
+  for (int i = threadIdx.x; i < kNfft; i += 256) { s_twr[i] = g_mel.tw_re[i]; s_twi[i] = g_mel.tw_im[i]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    frames_out[b] = (int32_t)Tb;
+    pct_out[b] = (float)Tb / (float)T;
+  }
+  int rx = 0, wx = 0, ry = 0, wy = 0;
+  if (aug) { rx = aug[b * 4 + 0]; wx = aug[b * 4 + 1]; ry = aug[b * 4 + 2]; wy = aug[b * 4 + 3]; }
+  __syncthreads();
+
+  double acc_s = 0.0, acc_q = 0.0;
+  double* sre = s_re[wid];
+  double* sim = s_im[wid];
+  for (int it = 0; it < kFramesPerBlock / kWaves; ++it) {
+    const int64_t f = (int64_t)blockIdx.x * kFramesPerBlock + it * kWaves + wid;
+    const bool live = f < Tb && f < T;  // wave-uniform
+    cplx v[8];
+    // ---- pass 0 (Ns = 1): lane j loads x[j + 64 r]; only n in [96, 416) is inside the window
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = lane + 64 * r;
+      double x = 0.0;
+      if (live && n >= kWinOff && n < kWinOff + kWin) {
+        int64_t i = f * kHop - kNfft / 2 + n;  // index into the padded signal, reflect at both ends
+        if (i < 0) i = -i;
+        if (i >= Lp) i = 2 * (Lp - 1) - i;
+        x = (double)padded_sample(y, nz, Lb, i) * g_mel.window[n - kWinOff];
+      }
+      v[r] = {x, 0.0};
+    }
+    fft8(v);
+    __syncthreads();  // previous iteration's readers are done with sre/sim
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sre[lane * 8 + r] = v[kPerm[r]].re; sim[lane * 8 + r] = v[kPerm[r]].im; }
+    __syncthreads();
+    // ---- pass 1 (Ns = 8)
+    {
+      const int k = lane & 7;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        cplx x = {sre[lane + 64 * r], sim[lane + 64 * r]};
+        const int tw = r * k * 8;
+        v[r] = cmul(x, cplx{s_twr[tw], s_twi[tw]});
+      }
+      fft8(v);
+      __syncthreads();
+      const int base = (lane >> 3) * 64 + k;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { sre[base + r * 8] = v[kPerm[r]].re; sim[base + r * 8] = v[kPerm[r]].im; }
+      __syncthreads();
+    }
+    // ---- pass 2 (Ns = 64)
+    {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        cplx x = {sre[lane + 64 * r], sim[lane + 64 * r]};
+        const int tw = r * lane;
+        v[r] = cmul(x, cplx{s_twr[tw], s_twi[tw]});
+      }
+      fft8(v);
+      __syncthreads();
+      // X[lane + 64 r] = v[perm r]; keep the power of bins 0..256 in sre
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const cplx z = v[kPerm[r]];
+        sre[lane + 64 * r] = z.re * z.re + z.im * z.im;
+      }
+      if (lane == 0) {
+        const cplx z = v[kPerm[4]];
+        sre[256] = z.re * z.re + z.im * z.im;
+      }
+      __syncthreads();
+    }
+    // ---- mel + dB: lane = mel channel
+    float db = 0.f;
+    if (live) {
+      double m = 0.0;
+      const int lo = g_mel.lo[lane], hi = g_mel.hi[lane];
+      for (int k = lo; k <= hi; ++k) m = fma(sre[k], (double)g_mel.fb[k * kMel + lane], m);
+      db = (float)(10.0 * log10(fmax(m, 1e-10)));
+      if (aug && ((lane >= rx && lane < rx + wx) || (f >= ry && f < ry + wy))) db = 0.f;
+      acc_s += (double)db;
+      acc_q += (double)db * (double)db;
+    }
+    if (f < T) db_out[((int64_t)b * T + f) * kMel + lane] = db;
+  }
+  acc_s = wave_sum_d(acc_s);
+  acc_q = wave_sum_d(acc_q);
+  if (lane == 0) { s_red[wid][0] = acc_s; s_red[wid][1] = acc_q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0, q = 0;
+    for (int w = 0; w < kWaves; ++w) { s += s_red[w][0]; q += s_red[w][1]; }
+    partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 0] = s;
+    partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 1] = q;
+  }
+}
+
+// grid: (ceil(T/16), B), block 256: normalise a [16 frames][64] tile, write both layouts.
+template <typename T>
+__global__ __launch_bounds__(256) void mel_norm_kernel(const float* __restrict__ db, const double* __restrict__ partials,
+                                                       const int32_t* __restrict__ frames, int64_t Tt, int nblk,
+                                                       int normalize, float* __restrict__ out_bft, T* __restrict__ out_btf) {
+  __shared__ float tile[kFramesPerBlock][kMel + 1];
+  __shared__ float s_mu, s_rstd;
+  const int b = blockIdx.y;
+  const int64_t Tb = frames[b];
+  if (threadIdx.x < 64) {
+    double s = 0, q = 0;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+      s += partials[((int64_t)b * nblk + i) * 2 + 0];
+      q += partials[((int64_t)b * nblk + i) * 2 + 1];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (threadIdx.x == 0) {
+      const double n = (double)Tb * kMel;
+      const double mu = s / n;
+      double var = (q - n * mu * mu) / (n - 1.0);  // unbiased, torch.std_mean default
+      if (var < 0) var = 0;
+      s_mu = normalize ? (float)mu : 0.f;
+      s_rstd = normalize ? (float)(1.0 / sqrt(var)) : 1.f;
+    }
+  }
+  __syncthreads();
+  const float mu = s_mu, rstd = s_rstd;
+  const int64_t f0 = (int64_t)blockIdx.x * kFramesPerBlock;
+  for (int i = threadIdx.x; i < kFramesPerBlock * kMel; i += 256) {
+    const int fr = i >> 6, m = i & 63;
+    const int64_t f = f0 + fr;
+    float v = 0.f;
+    if (f < Tt && f < Tb) v = (db[((int64_t)b * Tt + f) * kMel + m] - mu) * rstd;
+    tile[fr][m] = v;
+    if (out_btf && f < Tt) Elem<T>::st(out_btf + ((int64_t)b * Tt + f) * kMel + m, v);
+  }
+  if (out_bft) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kFramesPerBlock * kMel; i += 256) {
+      const int m = i >> 4, fr = i & 15;
+      const int64_t f = f0 + fr;
+      if (f < Tt) out_bft[((int64_t)b * kMel + m) * Tt + f] = tile[fr][m];
+    }
+  }
+}
+
+}  // namespace lasr
+
+using namespace lasr;
+
+extern "C" int64_t lasr_mel_num_frames(int64_t n_samples) { return 1 + (n_samples + 2 * kPad) / kHop; }
+
+extern "C" size_t lasr_mel_workspace_bytes(int64_t B, int64_t T) {
+  const size_t nblk = (size_t)cdiv(T, kFramesPerBlock);
+  return align_up((size_t)B * T * kMel * sizeof(float), 256) + align_up((size_t)B * nblk * 2 * sizeof(double), 256);
+}
+
+extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dither, const int32_t* aug,
+                            int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,
+                            int32_t* frames_out, float* pct_out, void* workspace, size_t workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(wave && frames_out && pct_out && workspace, "lasr_mel_fwd: null pointer");
+  LASR_CHECK_ARG(out_bft || out_btf, "lasr_mel_fwd: no output requested");
+  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_mel_fwd: bad dtype %d", dtype);
+  LASR_CHECK_SHAPE(B > 0 && B < 65536 && L >= 2 && L < (1ll << 30), "lasr_mel_fwd: B=%lld L=%lld", (long long)B, (long long)L);
+  const int64_t T = lasr_mel_num_frames(L);
+  if (workspace_bytes < lasr_mel_workspace_bytes(B, T)) return fail(LASR_E_WORKSPACE, "lasr_mel_fwd: workspace too small");
+  LASR_TRY(init_tables());
+  float* db = reinterpret_cast<float*>(workspace);
+  double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * T * kMel * sizeof(float), 256));
+  const int nblk = (int)cdiv(T, kFramesPerBlock);
+  dim3 grid(nblk, (unsigned)B);
+  hipLaunchKernelGGL(mel_db_kernel, grid, dim3(256), 0, as_stream(stream), wave, sample_lens, dither, aug, L, T, db,
+                     partials, frames_out, pct_out);
+  LASR_LAUNCH_CHECK("mel_db_kernel");
+  if (dtype == LASR_F32)
+    hipLaunchKernelGGL(mel_norm_kernel<float>, grid, dim3(256), 0, as_stream(stream), db, partials, frames_out, T, nblk,
+                       normalize, out_bft, reinterpret_cast<float*>(out_btf));
+  else
+    hipLaunchKernelGGL(mel_norm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), db, partials, frames_out, T, nblk,
+                       normalize, out_bft, reinterpret_cast<bf16_t*>(out_btf));
+  LASR_LAUNCH_CHECK("mel_norm_kernel");
+  return 0;
+}

@@ -1,0 +1,404 @@
+// Native execution plan for MyModel2 (models/QuartNet.py:264-291 and the Context / ContextSE
+// variants): the library sequences every kernel of forward, CTC loss and backward on one stream
+// over caller-owned flat buffers.  No tracing, no autograd: the plan is static per (B, T_in), so
+// the whole step can be captured into a hipGraph by the host.
+#include "common.h"
+#include <string>
+#include <vector>
+#include <math.h>
+
+extern "C" size_t lasr_bn_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
+extern "C" size_t lasr_gemm_workspace_bytes(int64_t M, int64_t N, int split_k, int want_stats);
+extern "C" size_t lasr_dwconv_wgrad_workspace_bytes(int64_t B, int64_t Tout, int64_t C, int k);
+extern "C" int lasr_log_softmax_bwd(const float*, const float*, float*, int64_t, int64_t, void*);
+extern "C" int lasr_cast_f32_to_bf16(const float*, void*, int64_t, void*);
+extern "C" int lasr_colsum_f32(const float* x, float* out, int64_t rows, int64_t C, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C);
+extern "C" int lasr_scale_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream);
+
+namespace lasr {
+
+static constexpr float kBnEps = 1e-3f;   // nn.BatchNorm1d(out_ch, eps=1e-3)  models/QuartNet.py:24
+static constexpr float kBnMom = 0.1f;
+
+struct TensorInfo {
+  std::string name;
+  int64_t shape[4] = {0, 0, 0, 0};
+  int ndim = 0;
+  int kind = 0;  // 0 param, 1 f32 buffer, 2 int64 counter
+  int64_t offset = 0;
+  int64_t numel = 1;
+};
+
+struct BnRef { int64_t gamma = -1, beta = -1, rmean = -1, rvar = -1; };
+
+// One "unit": [depthwise conv] -> 1x1 GEMM (+mask) -> BN  [+ residual 1x1 GEMM -> BN] -> activation
+struct Unit {
+  std::string tap;
+  int ci = 0, co = 0, k = 0, stride = 1;
+  bool has_dw = false, has_res = false, masked = false, act = true;
+  int64_t w_dw = -1, w_pw = -1, w_res = -1;
+  BnRef bn, bn_res;
+  // workspace offsets (bytes) filled by plan()
+  size_t o_u = 0, o_y = 0, o_y2 = 0, o_out = 0, o_coef = 0, o_saved = 0, o_coef2 = 0, o_saved2 = 0, o_stats = 0, o_stats2 = 0;
+};
+
+struct Plan {
+  int64_t B = 0, T_in = 0, T = 0, S_max = 0;
+  size_t total = 0;
+  size_t o_lens = 0, o_logits = 0, o_glogits = 0, o_nll = 0, o_scratch = 0, o_g[2] = {0, 0}, o_d1 = 0, o_d2 = 0, o_du = 0, o_dxr = 0;
+  size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0;
+  size_t scratch_bytes = 0, ctc_bytes = 0;
+};
+
+}  // namespace lasr
+
+using namespace lasr;
+
+struct lasr_model {
+  lasr_model_config cfg;
+  std::vector<TensorInfo> tensors;
+  std::vector<Unit> units;
+  int64_t n_param = 0, n_buffer = 0;
+  int64_t w_dec = -1, b_dec = -1;
+  Plan plan;
+  bool planned = false;
+
+  int64_t add_tensor(const std::string& name, std::initializer_list<int64_t> shape, int kind) {
+    TensorInfo t;
+    t.name = name;
+    t.kind = kind;
+    t.ndim = (int)shape.size();
+    int i = 0;
+    for (int64_t s : shape) { t.shape[i++] = s; t.numel *= s; }
+    if (kind == 0) { t.offset = n_param; n_param += t.numel; }
+    else if (kind == 1) { t.offset = n_buffer; n_buffer += t.numel; }
+    tensors.push_back(t);
+    return t.offset;
+  }
+  BnRef add_bn(const std::string& p, int64_t c) {
+    BnRef r;
+    r.gamma = add_tensor(p + ".weight", {c}, 0);
+    r.beta = add_tensor(p + ".bias", {c}, 0);
+    r.rmean = add_tensor(p + ".running_mean", {c}, 1);
+    r.rvar = add_tensor(p + ".running_var", {c}, 1);
+    add_tensor(p + ".num_batches_tracked", {}, 2);
+    return r;
+  }
+  void add_sep(Unit& u, const std::string& p) {
+    u.w_dw = add_tensor(p + ".depthwise_conv.weight", {u.ci, 1, u.k}, 0);
+    u.w_pw = add_tensor(p + ".pointwise_conv.weight", {u.co, u.ci, 1}, 0);
+    u.bn = add_bn(p + ".bn", u.co);
+  }
+};
+
+static int build_model(lasr_model* m) {
+  const lasr_model_config& c = m->cfg;
+  const bool ctx = c.variant != LASR_VARIANT_PLAIN;
+  {  // first_cnn: SeprationConv(in_c, 256, k=33, stride=2)            models/QuartNet.py:129
+    Unit u;
+    u.tap = "first_cnn"; u.ci = c.in_c; u.co = 256; u.k = 33; u.stride = 2; u.has_dw = true; u.masked = c.mask != 0;
+    m->add_sep(u, "encoder.first_cnn");
+    m->units.push_back(u);
+  }
+  struct B { const char* name; int ci, co, k; };
+  std::vector<B> blocks = {{"block1", 256, 256, 33}, {"block12", 256, 256, 33}, {"block13", 256, 256, 33},
+                           {"block2", 256, 256, 39}, {"block22", 256, 256, 39}, {"block23", 256, 256, 39},
+                           {"block3", ctx ? 336 : 256, 512, 51}, {"block32", 512, 512, 51}, {"block33", 512, 512, 51},
+                           {"block4", 512, 512, 63}, {"block42", 512, 512, 63}, {"block43", 512, 512, 63},
+                           {"block5", 512, 512, 75}};
+  if (ctx) blocks.push_back({"block6", 512, 512, 87});
+  for (const B& b : blocks) {  // QuartNetBlock(repeat=1)                 models/QuartNet.py:55-78
+    Unit u;
+    u.tap = b.name; u.ci = b.ci; u.co = b.co; u.k = b.k; u.has_dw = true; u.has_res = true; u.masked = c.mask != 0;
+    const std::string p = std::string("encoder.") + b.name;
+    u.w_res = m->add_tensor(p + ".reside.0.weight", {u.co, u.ci, 1}, 0);
+    u.bn_res = m->add_bn(p + ".reside.1", u.co);
+    m->add_sep(u, p + ".seq.0");
+    m->units.push_back(u);
+  }
+  {  // last_cnn2: 1x1 512->1024 (no bias) + BN + ReLU, never masked     models/QuartNet.py:145-150
+    Unit u;
+    u.tap = "last_cnn2"; u.ci = 512; u.co = 1024;
+    u.w_pw = m->add_tensor("encoder.last_cnn2.0.weight", {1024, 512, 1}, 0);
+    u.bn = m->add_bn("encoder.last_cnn2.1", 1024);
+    m->units.push_back(u);
+  }
+  if (ctx) return fail(LASR_E_SHAPE, "lasr_model_create: the Context/ContextSE variants are not wired into the native plan yet");
+  m->w_dec = m->add_tensor("decoder.weight", {c.n_class, 1024, 1}, 0);
+  m->b_dec = m->add_tensor("decoder.bias", {c.n_class}, 0);
+  return 0;
+}
+
+static int64_t out_frames(int64_t T_in) { return (T_in + 2 * 16 - 33) / 2 + 1; }
+
+static size_t take(size_t& cur, size_t bytes) {
+  const size_t o = cur;
+  cur += align_up(bytes, 256);
+  return o;
+}
+
+static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
+  Plan& p = m->plan;
+  if (m->planned && p.B == B && p.T_in == T_in && p.S_max == S_max) return;
+  p = Plan();
+  p.B = B; p.T_in = T_in; p.T = out_frames(T_in); p.S_max = S_max;
+  const size_t es = dtype_size(m->cfg.dtype);
+  const int64_t N = B * p.T;
+  size_t cur = 0;
+  p.o_lens = take(cur, (size_t)B * sizeof(int32_t));
+  size_t scratch = 0;
+  int64_t cmax = 0;
+  for (Unit& u : m->units) {
+    if (u.has_dw) u.o_u = take(cur, (size_t)N * u.ci * es);
+    u.o_y = take(cur, (size_t)N * u.co * es);
+    if (u.has_res) u.o_y2 = take(cur, (size_t)N * u.co * es);
+    u.o_out = take(cur, (size_t)N * u.co * es);
+    u.o_coef = take(cur, 2 * u.co * sizeof(float));
+    u.o_saved = take(cur, 2 * u.co * sizeof(float));
+    u.o_stats = take(cur, 2 * u.co * sizeof(float));
+    if (u.has_res) {
+      u.o_coef2 = take(cur, 2 * u.co * sizeof(float));
+      u.o_saved2 = take(cur, 2 * u.co * sizeof(float));
+      u.o_stats2 = take(cur, 2 * u.co * sizeof(float));
+    }
+    cmax = std::max<int64_t>(cmax, std::max(u.ci, u.co));
+    scratch = std::max(scratch, lasr_gemm_workspace_bytes(N, u.co, 1, 1));
+    scratch = std::max(scratch, lasr_bn_bwd_workspace_bytes(B, p.T, u.co));
+    scratch = std::max(scratch, lasr_gemm_workspace_bytes(u.co, u.ci, 16, 0));
+    if (u.has_dw) scratch = std::max(scratch, lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k));
+  }
+  const int64_t C = m->cfg.n_class;
+  scratch = std::max(scratch, lasr_gemm_workspace_bytes(C, 1024, 16, 0));
+  scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, C));
+  p.o_logits = take(cur, (size_t)N * C * sizeof(float));
+  p.o_glogits = take(cur, (size_t)N * C * sizeof(float));
+  p.o_nll = take(cur, (size_t)(B + 1) * sizeof(float));
+  p.scratch_bytes = scratch;
+  p.o_scratch = take(cur, scratch);
+  p.o_g[0] = take(cur, (size_t)N * cmax * es);
+  p.o_g[1] = take(cur, (size_t)N * cmax * es);
+  p.o_d1 = take(cur, (size_t)N * std::max<int64_t>(cmax, C) * es);
+  p.o_d2 = take(cur, (size_t)N * cmax * es);
+  p.o_du = take(cur, (size_t)N * cmax * es);
+  p.o_dxr = take(cur, (size_t)N * cmax * es);
+  p.o_sums = take(cur, 2 * cmax * sizeof(float));
+  p.o_sums2 = take(cur, 2 * cmax * sizeof(float));
+  p.ctc_bytes = lasr_ctc_workspace_bytes(B, p.T, S_max);
+  p.o_ctc = take(cur, p.ctc_bytes);
+  if (m->cfg.dtype == LASR_BF16) p.o_wbf16 = take(cur, (size_t)m->n_param * sizeof(bf16_t));
+  p.total = cur;
+  m->planned = true;
+}
+
+extern "C" int lasr_model_create(const lasr_model_config* cfg, lasr_model_t** out) {
+  LASR_CHECK_ARG(cfg && out, "lasr_model_create: null pointer");
+  LASR_CHECK_ARG(cfg->variant >= 0 && cfg->variant <= 2 && cfg->n_class >= 2 && cfg->in_c > 0 && cfg->in_c % 4 == 0,
+                 "lasr_model_create: bad config (variant=%d n_class=%d in_c=%d)", cfg->variant, cfg->n_class, cfg->in_c);
+  LASR_CHECK_ARG(cfg->dtype == LASR_F32 || cfg->dtype == LASR_BF16, "lasr_model_create: bad dtype");
+  LASR_CHECK_ARG(cfg->act == LASR_ACT_RELU || cfg->act == LASR_ACT_SWISH, "lasr_model_create: bad activation");
+  lasr_model* m = new lasr_model();
+  m->cfg = *cfg;
+  int rc = build_model(m);
+  if (rc) { delete m; return rc; }
+  *out = m;
+  return 0;
+}
+
+extern "C" void lasr_model_destroy(lasr_model_t* m) { delete m; }
+
+extern "C" int64_t lasr_model_tensor_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap, int64_t shape[4],
+                                          int32_t* ndim, int32_t* kind, int64_t* offset) {
+  if (!m) return -1;
+  if (i >= 0 && i < (int64_t)m->tensors.size()) {
+    const TensorInfo& t = m->tensors[i];
+    if (name && name_cap) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (shape) for (int d = 0; d < 4; ++d) shape[d] = t.shape[d];
+    if (ndim) *ndim = t.ndim;
+    if (kind) *kind = t.kind;
+    if (offset) *offset = t.offset;
+  }
+  return (int64_t)m->tensors.size();
+}
+extern "C" int64_t lasr_model_param_elems(const lasr_model_t* m) { return m ? m->n_param : -1; }
+extern "C" int64_t lasr_model_buffer_elems(const lasr_model_t* m) { return m ? m->n_buffer : -1; }
+extern "C" int64_t lasr_model_out_frames(const lasr_model_t* m, int64_t T_in) { (void)m; return out_frames(T_in); }
+
+extern "C" size_t lasr_model_workspace_bytes(lasr_model_t* m, int64_t B, int64_t T_in, int64_t S_max) {
+  if (!m || B <= 0 || T_in <= 0) return 0;
+  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
+  return m->plan.total;
+}
+
+extern "C" int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, int64_t T_in, int64_t S_max, int64_t shape[3]) {
+  if (!m || !name) return -1;
+  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
+  const Plan& p = m->plan;
+  const std::string n(name);
+  for (const Unit& u : m->units) {
+    if (n == u.tap) { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_out; }
+    if (n == u.tap + ".y") { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_y; }
+    if (n == u.tap + ".u" && u.has_dw) { shape[0] = B; shape[1] = p.T; shape[2] = u.ci; return (int64_t)u.o_u; }
+  }
+  if (n == "logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_logits; }
+  if (n == "grad_logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_glogits; }
+  if (n == "lens") { shape[0] = B; shape[1] = 1; shape[2] = 1; return (int64_t)p.o_lens; }
+  return -1;
+}
+
+static inline char* at(void* ws, size_t off) { return reinterpret_cast<char*>(ws) + off; }
+static inline float* atf(void* ws, size_t off) { return reinterpret_cast<float*>(at(ws, off)); }
+
+// weights as the GEMM's B operand: f32 params directly, or the bf16 shadow copy
+static inline const void* wptr(const lasr_model* m, const float* params, void* ws, int64_t off) {
+  if (m->cfg.dtype == LASR_BF16) return reinterpret_cast<const bf16_t*>(at(ws, m->plan.o_wbf16)) + off;
+  return params + off;
+}
+
+extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
+                                  int64_t B, int64_t T_in, int training, float* logp_out, int32_t* argmax_out, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  LASR_CHECK_ARG(m && params && buffers && feats && pct && logp_out && ws, "lasr_model_forward: null pointer");
+  LASR_CHECK_SHAPE(B > 0 && B < 65536 && T_in >= 33, "lasr_model_forward: B=%lld T_in=%lld", (long long)B, (long long)T_in);
+  make_plan(m, B, T_in, m->planned ? m->plan.S_max : 1);
+  const Plan& p = m->plan;
+  if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "lasr_model_forward: workspace %zu < %zu", ws_bytes, p.total);
+  const int dt = m->cfg.dtype;
+  const int64_t T = p.T, N = B * T;
+  int32_t* lens = reinterpret_cast<int32_t*>(at(ws, p.o_lens));
+  LASR_TRY(lasr_mask_lengths(pct, B, T, lens, stream));
+  if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
+  void* scratch = at(ws, p.o_scratch);
+  const void* x = feats;
+  int64_t Tx = T_in;
+  for (const Unit& u : m->units) {
+    const void* gin = x;
+    if (u.has_dw) {
+      LASR_TRY(lasr_dwconv_fwd(x, params + u.w_dw, nullptr, at(ws, u.o_u), dt, B, Tx, u.ci, u.k, u.stride, 0, stream));
+      gin = at(ws, u.o_u);
+    }
+    float* stats = training ? atf(ws, u.o_stats) : nullptr;
+    LASR_TRY(lasr_gemm(gin, wptr(m, params, ws, u.w_pw), at(ws, u.o_y), dt, dt, N, u.co, u.ci, 0, 0, nullptr, nullptr,
+                       u.masked ? lens : nullptr, T, stats, 1, scratch, p.scratch_bytes, stream));
+    LASR_TRY(lasr_bn_finalize(stats, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
+                              atf(ws, u.o_coef), atf(ws, u.o_saved), u.co, N, kBnEps, kBnMom, training, stream));
+    if (u.has_res) {
+      float* stats2 = training ? atf(ws, u.o_stats2) : nullptr;
+      LASR_TRY(lasr_gemm(x, wptr(m, params, ws, u.w_res), at(ws, u.o_y2), dt, dt, N, u.co, u.ci, 0, 0, nullptr, nullptr, nullptr, 0,
+                         stats2, 1, scratch, p.scratch_bytes, stream));
+      LASR_TRY(lasr_bn_finalize(stats2, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
+                                buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
+                                training, stream));
+    }
+    LASR_TRY(lasr_bn_act_fwd(at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
+                             u.has_res ? atf(ws, u.o_coef2) : nullptr, nullptr, at(ws, u.o_out), dt, B, T, u.co,
+                             u.act ? m->cfg.act : LASR_ACT_NONE, stream));
+    x = at(ws, u.o_out);
+    Tx = T;
+  }
+  // decoder 1x1 1024 -> C with bias (models/QuartNet.py:275), f32 logits, then log_softmax (+argmax)
+  const int64_t C = m->cfg.n_class;
+  LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->w_dec), atf(ws, p.o_logits), dt, LASR_F32, N, C, 1024, 0, 0, params + m->b_dec,
+                     nullptr, nullptr, 0, nullptr, 1, scratch, p.scratch_bytes, stream));
+  LASR_TRY(lasr_log_softmax(atf(ws, p.o_logits), logp_out, argmax_out, N, C, stream));
+  return 0;
+}
+
+// backward from d(loss)/d(logits) already in the workspace (o_glogits)
+static int backward_from_glogits(lasr_model* m, const float* params, const void* feats, int64_t B, int64_t T_in, float* grads,
+                                 void* ws, void* stream) {
+  const Plan& p = m->plan;
+  const int dt = m->cfg.dtype;
+  const int64_t T = p.T, N = B * T, C = m->cfg.n_class;
+  void* scratch = at(ws, p.o_scratch);
+  const size_t sb = p.scratch_bytes;
+  const int32_t* lens = reinterpret_cast<const int32_t*>(at(ws, p.o_lens));
+  float* gl = atf(ws, p.o_glogits);
+  const Unit& last = m->units.back();
+  // decoder (models/QuartNet.py:275): dW = gl^T h, db = colsum(gl), dh = gl W
+  const void* gl_ab = gl;
+  if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient
+    LASR_TRY(lasr_cast_f32_to_bf16(gl, at(ws, p.o_d1), N * C, stream));
+    gl_ab = at(ws, p.o_d1);
+  }
+  LASR_TRY(lasr_gemm(gl_ab, at(ws, last.o_out), grads + m->w_dec, dt, LASR_F32, C, 1024, N, 1, 1, nullptr, nullptr, nullptr, 0,
+                     nullptr, 16, scratch, sb, stream));
+  LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
+  int cur = 0;
+  LASR_TRY(lasr_gemm(gl_ab, wptr(m, params, ws, m->w_dec), at(ws, p.o_g[cur]), dt, dt, N, 1024, C, 0, 1, nullptr, nullptr, nullptr,
+                     0, nullptr, 1, scratch, sb, stream));
+  for (int ui = (int)m->units.size() - 1; ui >= 0; --ui) {
+    const Unit& u = m->units[ui];
+    const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
+    const int64_t Tx = ui > 0 ? T : T_in;
+    const int act = u.act ? m->cfg.act : LASR_ACT_NONE;
+    void* dout = at(ws, p.o_g[cur]);
+    void* dy = at(ws, p.o_d1);
+    void* dy2 = u.has_res ? at(ws, p.o_d2) : nullptr;
+    LASR_TRY(lasr_bn_act_bwd_stats(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), u.has_res ? at(ws, u.o_y2) : nullptr,
+                                   u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_res ? atf(ws, u.o_saved2) : nullptr, nullptr,
+                                   nullptr, atf(ws, p.o_sums), atf(ws, p.o_sums2), dt, B, T, u.co, act, scratch, sb, stream));
+    LASR_TRY(lasr_bn_act_bwd_apply(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma,
+                                   u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
+                                   u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, nullptr,
+                                   nullptr, atf(ws, p.o_sums), atf(ws, p.o_sums2), u.masked ? lens : nullptr, dy, dy2,
+                                   grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
+                                   u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, stream));
+    // main 1x1: dW[co][ci] = dy^T gin
+    const void* gin = u.has_dw ? at(ws, u.o_u) : x_in;
+    LASR_TRY(lasr_gemm(dy, gin, grads + u.w_pw, dt, LASR_F32, u.co, u.ci, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16, scratch,
+                       sb, stream));
+    const bool need_dx = ui > 0;
+    void* dx = at(ws, p.o_g[cur ^ 1]);
+    if (u.has_res) {  // residual 1x1: dWr = dy2^T x ; dx_res = dy2 Wr
+      LASR_TRY(lasr_gemm(dy2, x_in, grads + u.w_res, dt, LASR_F32, u.co, u.ci, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16,
+                         scratch, sb, stream));
+      if (need_dx)
+        LASR_TRY(lasr_gemm(dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), dt, dt, N, u.ci, u.co, 0, 1, nullptr, nullptr, nullptr,
+                           0, nullptr, 1, scratch, sb, stream));
+    }
+    if (u.has_dw) {
+      // d(dw output) = dy Wp ; depthwise dW from (x, du) ; dx = flipped depthwise conv of du (+ residual dx)
+      LASR_TRY(lasr_gemm(dy, wptr(m, params, ws, u.w_pw), at(ws, p.o_du), dt, dt, N, u.ci, u.co, 0, 1, nullptr, nullptr, nullptr, 0,
+                         nullptr, 1, scratch, sb, stream));
+      LASR_TRY(lasr_dwconv_wgrad(x_in, at(ws, p.o_du), grads + u.w_dw, dt, B, Tx, u.ci, u.k, u.stride, scratch, sb, stream));
+      if (need_dx)
+        LASR_TRY(lasr_dwconv_fwd(at(ws, p.o_du), params + u.w_dw, u.has_res ? at(ws, p.o_dxr) : nullptr, dx, dt, B, T, u.ci, u.k, 1,
+                                 1, stream));
+    } else if (need_dx) {
+      LASR_TRY(lasr_gemm(dy, wptr(m, params, ws, u.w_pw), dx, dt, dt, N, u.ci, u.co, 0, 1, nullptr, u.has_res ? at(ws, p.o_dxr) : nullptr,
+                         nullptr, 0, nullptr, 1, scratch, sb, stream));
+    }
+    cur ^= 1;
+  }
+  return 0;
+}
+
+extern "C" int lasr_model_backward(lasr_model_t* m, const float* params, const void* feats, const float* logp,
+                                   const float* grad_logp, int64_t B, int64_t T_in, float* grads, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  LASR_CHECK_ARG(m && params && feats && logp && grad_logp && grads && ws, "lasr_model_backward: null pointer");
+  LASR_CHECK_ARG(m->planned && m->plan.B == B && m->plan.T_in == T_in, "lasr_model_backward: no matching forward in this workspace");
+  if (ws_bytes < m->plan.total) return fail(LASR_E_WORKSPACE, "lasr_model_backward: workspace");
+  const int64_t N = B * m->plan.T;
+  LASR_TRY(lasr_log_softmax_bwd(logp, grad_logp, atf(ws, m->plan.o_glogits), N, m->cfg.n_class, stream));
+  return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream);
+}
+
+extern "C" int lasr_model_loss_backward(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
+                                        const int64_t* targets, const int32_t* tgt_lens, int64_t B, int64_t T_in, int64_t S_max,
+                                        float* logp_out, float* loss_out, float* nll_out, int32_t* argmax_out, float* grads,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  LASR_CHECK_ARG(m && targets && tgt_lens && logp_out && loss_out && nll_out && grads, "lasr_model_loss_backward: null pointer");
+  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
+  const Plan& p = m->plan;
+  if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "lasr_model_loss_backward: workspace %zu < %zu", ws_bytes, p.total);
+  LASR_TRY(lasr_model_forward(m, params, buffers, feats, pct, B, T_in, 1, logp_out, argmax_out, ws, ws_bytes, stream));
+  const int C = m->cfg.n_class;
+  // mean_b CTC(blank = C-1) with lengths int(T'*pct) (train.py:76-78); its gradient w.r.t. the
+  // log-probs is (softmax - occupancy)/B, which log_softmax backward maps to itself.
+  LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
+                         nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
+  LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
+  return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream);
+}

@@ -1,0 +1,184 @@
+"""Python handle on the native execution plan (lasr_model_* in include/lasr.h): flat f32 parameter /
+buffer / gradient storage on the GPU plus per-tensor views named like the reference state_dict."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call
+from .ops import _p, _stream, torch_dtype
+
+
+class TensorInfo:
+    __slots__ = ("name", "shape", "kind", "offset", "numel")
+
+    def __init__(self, name, shape, kind, offset):
+        self.name, self.shape, self.kind, self.offset = name, tuple(shape), kind, offset
+        n = 1
+        for s in shape:
+            n *= s
+        self.numel = n
+
+
+class NativeModel:
+    """Owns the lasr_model_t handle and the caller-side buffers the C ABI works on."""
+
+    def __init__(self, variant: str, n_class: int, mask: bool = True, act: str = "relu", dtype=torch.float32,
+                 in_c: int = 64, device="cuda"):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LasrError("NativeModel runs on the GPU only (hand-written HIP); no CPU fallback exists")
+        self.cfg = _lib.ModelConfig(_lib.VARIANT[variant], n_class, in_c, int(mask), {"relu": 1, "swish": 2}[act],
+                                    _lib.F32 if dtype == torch.float32 else _lib.BF16)
+        self.variant, self.n_class, self.act_dtype = variant, n_class, dtype
+        h = C.c_void_p()
+        _lib.check(lib.lasr_model_create(C.byref(self.cfg), C.byref(h)), "lasr_model_create")
+        self._h = h
+        self._lib = lib
+        self.tensors: List[TensorInfo] = []
+        n = lib.lasr_model_tensor_info(h, -1, None, 0, None, None, None, None)
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        ndim, kind, off = C.c_int32(), C.c_int32(), C.c_int64()
+        for i in range(n):
+            lib.lasr_model_tensor_info(h, i, name, 256, shape, C.byref(ndim), C.byref(kind), C.byref(off))
+            self.tensors.append(TensorInfo(name.value.decode(), [shape[d] for d in range(ndim.value)], kind.value, off.value))
+        self.n_param = lib.lasr_model_param_elems(h)
+        self.n_buffer = lib.lasr_model_buffer_elems(h)
+        self.params = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
+        self.buffers = torch.zeros(max(self.n_buffer, 1), dtype=torch.float32, device=self.device)
+        self.counters: Dict[str, torch.Tensor] = OrderedDict()   # num_batches_tracked (host side, int64)
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key: Optional[Tuple[int, int, int]] = None
+        self._last_feats = None
+        self._last_logp = None
+        for t in self.tensors:
+            if t.kind == 1 and t.name.endswith("running_var"):
+                self.buffers[t.offset:t.offset + t.numel] = 1.0
+            if t.kind == 2:
+                self.counters[t.name] = torch.zeros((), dtype=torch.int64)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.lasr_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- state --------------------------------------------------------------------------------
+    def param_infos(self) -> List[TensorInfo]:
+        return [t for t in self.tensors if t.kind == 0]
+
+    def view(self, t: TensorInfo, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        base = flat if flat is not None else (self.params if t.kind == 0 else self.buffers)
+        return base[t.offset:t.offset + t.numel].view(t.shape)
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        sd = OrderedDict()
+        for t in self.tensors:
+            sd[t.name] = self.counters[t.name].clone() if t.kind == 2 else self.view(t).detach().clone()
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        names = {t.name for t in self.tensors}
+        if strict:
+            missing, extra = names - set(sd), set(sd) - names
+            if missing or extra:
+                raise KeyError("state_dict mismatch: missing %s unexpected %s" % (sorted(missing)[:5], sorted(extra)[:5]))
+        with torch.no_grad():
+            for t in self.tensors:
+                if t.name not in sd:
+                    continue
+                v = sd[t.name]
+                if t.kind == 2:
+                    self.counters[t.name] = v.detach().to("cpu", torch.int64).clone()
+                else:
+                    if tuple(v.shape) != t.shape:
+                        raise ValueError("%s: shape %s != %s" % (t.name, tuple(v.shape), t.shape))
+                    self.view(t).copy_(v.to(self.device, torch.float32))
+
+    def param_offsets(self) -> torch.Tensor:
+        offs = [t.offset for t in self.param_infos()] + [self.n_param]
+        return torch.tensor(offs, dtype=torch.int64, device=self.device)
+
+    # ---- execution ------------------------------------------------------------------------------
+    def out_frames(self, T_in: int) -> int:
+        return int(self._lib.lasr_model_out_frames(self._h, T_in))
+
+    def workspace(self, B: int, T_in: int, S_max: int = 1) -> torch.Tensor:
+        key = (B, T_in, max(S_max, 1))
+        if self._ws is None or self._ws_key != key:
+            nb = self._lib.lasr_model_workspace_bytes(self._h, B, T_in, key[2])
+            if self._ws is None or self._ws.numel() < nb:
+                self._ws = None
+                self._ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def tap(self, name: str) -> torch.Tensor:
+        """Intermediate of the last forward, as a [B][T][C] view of the workspace."""
+        B, T_in, S = self._ws_key
+        shape = (C.c_int64 * 3)()
+        off = self._lib.lasr_model_tap(self._h, name.encode(), B, T_in, S, shape)
+        if off < 0:
+            raise KeyError(name)
+        shp = tuple(shape[i] for i in range(3))
+        if name in ("logits", "grad_logits"):
+            dt = torch.float32
+        elif name == "lens":
+            return self._ws[off:off + 4 * B].view(torch.int32)
+        else:
+            dt = self.act_dtype
+        n = shp[0] * shp[1] * shp[2] * (4 if dt == torch.float32 else 2)
+        return self._ws[off:off + n].view(dt).view(shp)
+
+    def forward(self, feats_btc: torch.Tensor, pct: torch.Tensor, training: bool = True, want_argmax: bool = True):
+        """feats [B][T_in][in_c] (act dtype), pct (B) f32 -> (logp (B,T',C) f32, argmax (B,T') i32 | None)."""
+        B, T_in, _ = feats_btc.shape
+        if feats_btc.dtype != self.act_dtype:
+            raise TypeError("features must be %s" % self.act_dtype)
+        ws = self.workspace(B, T_in, self._ws_key[2] if self._ws_key and self._ws_key[:2] == (B, T_in) else 1)
+        T = self.out_frames(T_in)
+        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        am = torch.empty(B, T, dtype=torch.int32, device=self.device) if want_argmax else None
+        call("lasr_model_forward", self._h, _p(self.params), _p(self.buffers), _p(feats_btc), _p(pct), B, T_in, int(training),
+             _p(logp), _p(am), _p(ws), ws.numel(), _stream())
+        if training:
+            for k in self.counters:
+                self.counters[k] += 1
+            self._last_feats, self._last_logp = feats_btc, logp
+        return logp, am
+
+    def backward(self, grad_logp: torch.Tensor) -> torch.Tensor:
+        """dL/d(log-probs) -> flat gradient buffer (views via ``view(t, self.grads)``)."""
+        if self._last_feats is None:
+            raise RuntimeError("backward() needs a preceding training forward()")
+        B, T_in, _ = self._last_feats.shape
+        ws = self._ws
+        call("lasr_model_backward", self._h, _p(self.params), _p(self._last_feats), _p(self._last_logp),
+             _p(grad_logp.contiguous()), B, T_in, _p(self.grads), _p(ws), ws.numel(), _stream())
+        return self.grads
+
+    def loss_backward(self, feats_btc, pct, targets, tgt_lens, want_argmax: bool = True):
+        """forward + mean CTC + backward.  Returns (loss (1), nll (B), logp, argmax)."""
+        B, T_in, _ = feats_btc.shape
+        S = targets.shape[1]
+        ws = self.workspace(B, T_in, S)
+        T = self.out_frames(T_in)
+        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        am = torch.empty(B, T, dtype=torch.int32, device=self.device) if want_argmax else None
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        nll = torch.empty(B, dtype=torch.float32, device=self.device)
+        call("lasr_model_loss_backward", self._h, _p(self.params), _p(self.buffers), _p(feats_btc), _p(pct), _p(targets),
+             _p(tgt_lens), B, T_in, S, _p(logp), _p(loss), _p(nll), _p(am), _p(self.grads), _p(ws), ws.numel(), _stream())
+        for k in self.counters:
+            self.counters[k] += 1
+        self._last_feats, self._last_logp = feats_btc, logp
+        return loss, nll, logp, am

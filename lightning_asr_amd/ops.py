@@ -1,0 +1,203 @@
+"""Torch-tensor wrappers over the C ABI.  PyTorch is only the container for device memory and the
+stream; every computation below is a liblasr.so (HIP, gfx950) call.  Tensors must live on the GPU:
+there is no CPU path."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, call
+
+ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "swish": _lib.ACT_SWISH}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("activations must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.LasrError("liblasr ops need GPU tensors (got a %s tensor); there is no CPU fallback" % t.device)
+    if not t.is_contiguous():
+        raise ValueError("liblasr ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------- features
+def mel_num_frames(n_samples: int) -> int:
+    return int(_lib.load().lasr_mel_num_frames(n_samples))
+
+
+def mel(wave: torch.Tensor, sample_lens: Optional[torch.Tensor] = None, dither: Optional[torch.Tensor] = None,
+        aug: Optional[torch.Tensor] = None, normalize: bool = True, dtype=torch.float32, want_bft: bool = True,
+        want_btf: bool = True):
+    """wave (B, L) f32 -> (feats_bft (B,64,T) f32 | None, feats_btf (B,T,64) dtype | None, frames (B) i32, pct (B) f32)."""
+    B, L = wave.shape
+    T = mel_num_frames(L)
+    dev = wave.device
+    bft = torch.empty(B, 64, T, dtype=torch.float32, device=dev) if want_bft else None
+    btf = torch.empty(B, T, 64, dtype=dtype, device=dev) if want_btf else None
+    frames = torch.empty(B, dtype=torch.int32, device=dev)
+    pct = torch.empty(B, dtype=torch.float32, device=dev)
+    nb = _lib.load().lasr_mel_workspace_bytes(B, T)
+    ws = _ws(nb, dev)
+    call("lasr_mel_fwd", _p(wave), _p(sample_lens), _p(dither), _p(aug), B, L, int(normalize), _p(bft), _p(btf),
+         F32 if dtype == torch.float32 else BF16, _p(frames), _p(pct), _p(ws), nb, _stream())
+    return bft, btf, frames, pct
+
+
+def bct_to_btc(x: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    B, Cc, T = x.shape
+    out = torch.empty(B, T, Cc, dtype=dtype, device=x.device)
+    call("lasr_bct_to_btc", _p(x), _p(out), _dt(out), B, Cc, T, _stream())
+    return out
+
+
+def btc_to_bct(x: torch.Tensor) -> torch.Tensor:
+    B, T, Cc = x.shape
+    out = torch.empty(B, Cc, T, dtype=torch.float32, device=x.device)
+    call("lasr_btc_to_bct", _p(x), _dt(x), _p(out), B, Cc, T, _stream())
+    return out
+
+
+def mask_lengths(pct: torch.Tensor, T: int) -> torch.Tensor:
+    lens = torch.empty(pct.numel(), dtype=torch.int32, device=pct.device)
+    call("lasr_mask_lengths", _p(pct), pct.numel(), T, _p(lens), _stream())
+    return lens
+
+
+# ---------------------------------------------------------------------------------- conv pieces
+def dwconv(x: torch.Tensor, w: torch.Tensor, stride: int = 1, flip: bool = False,
+           addend: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B][T][C], w (C, k) or (C,1,k) f32."""
+    B, Tin, Cc = x.shape
+    k = w.shape[-1]
+    Tout = (Tin + 2 * (k // 2) - k) // stride + 1
+    y = torch.empty(B, Tout, Cc, dtype=x.dtype, device=x.device)
+    call("lasr_dwconv_fwd", _p(x), _p(w), _p(addend), _p(y), _dt(x), B, Tin, Cc, k, stride, int(flip), _stream())
+    return y
+
+
+def dwconv_wgrad(x: torch.Tensor, dy: torch.Tensor, k: int, stride: int = 1) -> torch.Tensor:
+    B, Tin, Cc = x.shape
+    dw = torch.empty(Cc, k, dtype=torch.float32, device=x.device)
+    nb = _lib.load().lasr_dwconv_wgrad_workspace_bytes(B, dy.shape[1], Cc, k)
+    ws = _ws(nb, x.device)
+    call("lasr_dwconv_wgrad", _p(x), _p(dy), _p(dw), _dt(x), B, Tin, Cc, k, stride, _p(ws), nb, _stream())
+    return dw
+
+
+def gemm(A: torch.Tensor, Bm: torch.Tensor, M: int, N: int, K: int, transA: bool = False, transB: bool = False,
+         bias: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None,
+         row_lens: Optional[torch.Tensor] = None, rows_per_seq: int = 0, want_stats: bool = False, split_k: int = 1,
+         out_dtype=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    out_dtype = out_dtype or A.dtype
+    Cm = torch.empty(M, N, dtype=out_dtype, device=A.device)
+    stats = torch.empty(2 * N, dtype=torch.float32, device=A.device) if want_stats else None
+    nb = _lib.load().lasr_gemm_workspace_bytes(M, N, split_k, int(want_stats))
+    ws = _ws(nb, A.device)
+    call("lasr_gemm", _p(A), _p(Bm), _p(Cm), _dt(A), _dt(Cm), M, N, K, int(transA), int(transB), _p(bias), _p(addend),
+         _p(row_lens), rows_per_seq, _p(stats), split_k, _p(ws), nb, _stream())
+    return Cm, stats
+
+
+def bn_finalize(stats, gamma, beta, running_mean, running_var, n_rows: int, eps: float = 1e-3, momentum: float = 0.1,
+                training: bool = True):
+    Cc = gamma.numel()
+    coef = torch.empty(2 * Cc, dtype=torch.float32, device=gamma.device)
+    saved = torch.empty(2 * Cc, dtype=torch.float32, device=gamma.device)
+    call("lasr_bn_finalize", _p(stats), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(coef), _p(saved), Cc,
+         n_rows, eps, momentum, int(training), _stream())
+    return coef, saved
+
+
+def bn_act(y, coef, y2=None, coef2=None, se_scale=None, act: str = "relu") -> torch.Tensor:
+    B, T, Cc = y.shape
+    out = torch.empty_like(y)
+    call("lasr_bn_act_fwd", _p(y), _p(coef), _p(y2), _p(coef2), _p(se_scale), _p(out), _dt(y), B, T, Cc, ACT[act], _stream())
+    return out
+
+
+def bn_act_bwd(dout, y, coef, saved, gamma, y2=None, coef2=None, saved2=None, gamma2=None, se_scale=None, se_grad=None,
+               row_lens=None, act: str = "relu"):
+    """Returns (dy, dy2, dgamma, dbeta, dgamma2, dbeta2)."""
+    B, T, Cc = y.shape
+    dev = y.device
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+    sums2 = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
+    nb = _lib.load().lasr_bn_bwd_workspace_bytes(B, T, Cc)
+    ws = _ws(nb, dev)
+    call("lasr_bn_act_bwd_stats", _p(dout), _p(y), _p(coef), _p(saved), _p(y2), _p(coef2), _p(saved2), _p(se_scale),
+         _p(se_grad), _p(sums), _p(sums2), _dt(y), B, T, Cc, ACT[act], _p(ws), nb, _stream())
+    dy = torch.empty_like(y)
+    dy2 = torch.empty_like(y) if y2 is not None else None
+    dg, db = (torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(2))
+    dg2, db2 = ((torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(2)) if y2 is not None else (None, None))
+    call("lasr_bn_act_bwd_apply", _p(dout), _p(y), _p(coef), _p(saved), _p(gamma), _p(y2), _p(coef2), _p(saved2), _p(gamma2),
+         _p(se_scale), _p(se_grad), _p(sums), _p(sums2), _p(row_lens), _p(dy), _p(dy2), _p(dg), _p(db), _p(dg2), _p(db2),
+         _dt(y), B, T, Cc, ACT[act], _stream())
+    return dy, dy2, dg, db, dg2, db2
+
+
+# ---------------------------------------------------------------------------------- head + loss
+def log_softmax(logits: torch.Tensor, want_argmax: bool = True):
+    shp = logits.shape
+    Cc = shp[-1]
+    N = logits.numel() // Cc
+    out = torch.empty_like(logits)
+    am = torch.empty(shp[:-1], dtype=torch.int32, device=logits.device) if want_argmax else None
+    call("lasr_log_softmax", _p(logits), _p(out), _p(am), N, Cc, _stream())
+    return out, am
+
+
+def ctc_loss(logp: torch.Tensor, targets: torch.Tensor, in_lens: torch.Tensor, tgt_lens: torch.Tensor, blank: int,
+             want_grad: bool = True, gscale: Optional[torch.Tensor] = None):
+    """logp (B,T,C) f32 -> (nll (B), grad (B,T,C) | None); grad is torch's CTCLoss backward for grad_output=gscale."""
+    B, T, Cc = logp.shape
+    S = targets.shape[1] if targets.dim() == 2 else 0
+    nll = torch.empty(B, dtype=torch.float32, device=logp.device)
+    grad = torch.empty_like(logp) if want_grad else None
+    nb = _lib.load().lasr_ctc_workspace_bytes(B, T, max(S, 1))
+    ws = _ws(nb, logp.device)
+    call("lasr_ctc_loss", _p(logp), _p(targets), _p(in_lens), _p(tgt_lens), B, T, Cc, max(S, 1), blank, _p(nll), _p(grad),
+         _p(gscale), _p(ws), nb, _stream())
+    return nll, grad
+
+
+def greedy_decode(ids: torch.Tensor, lens: Optional[torch.Tensor], blank: int):
+    B, T = ids.shape
+    tokens = torch.empty(B, T, dtype=torch.int32, device=ids.device)
+    n = torch.empty(B, dtype=torch.int32, device=ids.device)
+    call("lasr_greedy_decode", _p(ids), _p(lens), B, T, blank, _p(tokens), _p(n), _stream())
+    return tokens, n
+
+
+# ---------------------------------------------------------------------------------- optimiser
+def novograd_step(params, grads, exp_avg, exp_avg_sq, offsets, lr_dev, beta1=0.8, beta2=0.5, eps=1e-8, weight_decay=0.0,
+                  grad_scale=1.0):
+    n_t = exp_avg_sq.numel()
+    n = params.numel()
+    nb = _lib.load().lasr_novograd_workspace_bytes(n_t, n)
+    ws = _ws(nb, params.device)
+    call("lasr_novograd_step", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(offsets), n_t, n, _p(lr_dev), beta1,
+         beta2, eps, weight_decay, grad_scale, _p(ws), nb, _stream())

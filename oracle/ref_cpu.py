@@ -79,13 +79,14 @@ def preemphasis(y: torch.Tensor) -> torch.Tensor:
 
 
 def mel_power(y: torch.Tensor) -> torch.Tensor:
-    """y: (1, L) pre-emphasised wave -> (1, 64, T) power mel spectrogram."""
+    """y: (1, L) pre-emphasised wave -> (1, 64, T) power mel spectrogram (in y's dtype: f32 is
+    the reference arithmetic, f64 is used by tests to price f32 FFT round-off)."""
     y = F.pad(y, (PAD, PAD), "constant")
-    spec = torch.stft(y, N_FFT, hop_length=HOP, win_length=N_FFT, window=hann_window_padded(),
+    spec = torch.stft(y, N_FFT, hop_length=HOP, win_length=N_FFT, window=hann_window_padded().to(y.dtype),
                       center=True, pad_mode="reflect", normalized=False, onesided=True,
                       return_complex=True)
     power = spec.real ** 2 + spec.imag ** 2                    # |.|^2, (1, 257, T)
-    fb = mel_filterbank()
+    fb = mel_filterbank().to(y.dtype)
     return torch.matmul(power.transpose(1, 2), fb).transpose(1, 2)
 
 
@@ -136,9 +137,10 @@ def parse_wave(y: torch.Tensor, dither: Optional[torch.Tensor] = None,
                aug: Optional[Tuple[int, int, int, int]] = None, normalize: bool = True) -> torch.Tensor:
     """(1, L) wave -> (1, 64, T) normalised log-mel, the chain of data_module.py:150-174
     with the random dither passed in explicitly (None = dither off)."""
-    y = y.float()
+    if y.dtype != torch.float64:
+        y = y.float()
     if dither is not None:
-        y = y + DITHER * dither
+        y = y + DITHER * dither.to(y.dtype)
     y = preemphasis(y)
     db = amplitude_to_db(mel_power(y))
     if aug is not None:

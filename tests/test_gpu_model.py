@@ -1,0 +1,103 @@
+"""Whole-model parity of the native plan (HIP, via the C ABI) against the golden fixtures captured
+from the reference and against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from oracle.make_golden import golden_inputs, checksum
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _native(variant, n_class, dev, dtype=torch.float32):
+    from lightning_asr_amd.engine import NativeModel
+    m = NativeModel(variant, n_class, mask=True, act="relu", dtype=dtype, device=dev)
+    m.load_state_dict(R.formula_state(variant, n_class))
+    return m
+
+
+def test_state_dict_layout_matches_reference(dev):
+    m = _native("plain", 28, dev)
+    assert [(t.name, t.shape) for t in m.tensors] == [(k, tuple(s)) for k, s in R.state_shapes("plain", 28)]
+    assert m.n_param == 5044572          # SURVEY §6 [probe]
+    assert len(m.tensors) == 184
+
+
+def test_plain_forward_matches_golden_f32(dev):
+    from lightning_asr_amd import ops
+    gold = np.load("tests/golden/model_plain.npz")
+    x, tg, pct, tsz = golden_inputs()
+    m = _native("plain", 28, dev)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    # eval mode first (running stats are the formula ones: mean 0, var 1)
+    lp_e, _ = m.forward(feats, pct.to(dev), training=False)
+    assert np.abs(lp_e.cpu().numpy() - gold["eval_logprobs"]).max() < 2e-4
+    lp, am = m.forward(feats, pct.to(dev), training=True)
+    assert m.tap("lens").cpu().tolist() == gold["t_lengths"].tolist()
+    err = np.abs(lp.cpu().numpy() - gold["logprobs"]).max()
+    assert err < 2e-4, err
+    # bit-exact token-id argmax decode vs the reference CPU path
+    assert np.array_equal(am.cpu().numpy().astype(np.int16), gold["argmax"])
+    for name in ["first_cnn", "block1", "block23", "block3", "block43", "block5", "last_cnn2"]:
+        got = checksum(m.tap(name).transpose(1, 2).contiguous().cpu())
+        assert np.abs(got - gold["tap_" + name]).max() < 1e-4, name
+
+
+def test_plain_loss_backward_matches_golden_f32(dev):
+    from lightning_asr_amd import ops
+    gold = np.load("tests/golden/model_plain.npz")
+    x, tg, pct, tsz = golden_inputs()
+    m = _native("plain", 28, dev)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    loss, nll, lp, am = m.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert np.abs(nll.cpu().numpy() - gold["nll"]).max() / np.abs(gold["nll"]).max() < 1e-4
+    assert abs(loss.item() - gold["losses"][0]) / gold["losses"][0] < 1e-4
+    norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
+    assert np.abs(norms / gold["grad_norms"] - 1).max() < 5e-3
+    # full gradients against the oracle (bit-identical to the reference for this variant)
+    o = R.OracleModel("plain", 28, mask=True, state=R.formula_state("plain", 28))
+    st = R.NovogradState(len(o.parameters()))
+    _, grads = R.train_step(o, st, x, tg, pct, tsz, 1e-2, 1e-3)
+    worst = max(rel_l2(m.view(t, m.grads), g) for t, g in zip(m.param_infos(), grads))
+    assert worst < 2e-3, worst
+    # running statistics after one training forward
+    for t in m.tensors:
+        if t.kind == 1:
+            assert rel_l2(m.view(t), o.state[t.name]) < 1e-4, t.name
+
+
+def test_generic_backward_equals_fused(dev):
+    from lightning_asr_amd import ops
+    x, tg, pct, tsz = golden_inputs()
+    m = _native("plain", 28, dev)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    loss, nll, lp, _ = m.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    g_fused = m.grads.clone()
+    m2 = _native("plain", 28, dev)
+    lp2, _ = m2.forward(feats, pct.to(dev), training=True)
+    lens = ops.mask_lengths(pct.to(dev), lp2.shape[1])
+    _, g_lp = ops.ctc_loss(lp2, tg.to(dev), lens, tsz.to(dev), 27)
+    m2.backward(g_lp)
+    assert rel_l2(m2.grads, g_fused) < 1e-4      # log_softmax backward sees sum_c(grad) ~ 1e-7, not exactly 0
+
+
+def test_aishell_vocab_large_C(dev):
+    from lightning_asr_amd import ops
+    gold = np.load("tests/golden/model_plain_aishell.npz")
+    V = 4333
+    x, tg, pct, tsz = golden_inputs(B=2, T_in=81, S=6, V=V)
+    pct = torch.tensor([1.0, 0.75])
+    m = _native("plain", V + 1, dev)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    loss, nll, lp, am = m.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert np.abs(nll.cpu().numpy() - gold["nll"]).max() / np.abs(gold["nll"]).max() < 1e-4
+    assert np.abs(checksum(lp.cpu()) - gold["logprob_checksum"]).max() < 2e-4
+    assert np.array_equal(am.cpu().numpy().astype(np.int16), gold["argmax"])
+    norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
+    assert np.abs(norms / gold["grad_norms"] - 1).max() < 5e-3

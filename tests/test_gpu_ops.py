@@ -1,0 +1,345 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle / plain torch fp32."""
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def max_rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+# ----------------------------------------------------------------------------------------- mel
+@pytest.mark.parametrize("kind", ["noise", "tone"])
+def test_mel_matches_oracle(dev, kind):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    L = 16000 * 2 + 123
+    if kind == "noise":
+        wave = 0.1 * torch.randn(3, L, generator=g)
+    else:
+        t = torch.arange(L) / 16000.0
+        wave = torch.stack([0.3 * torch.sin(2 * math.pi * f * t) + 0.01 * torch.randn(L, generator=g) for f in (440., 1234., 3999.)])
+    lens = torch.tensor([L, L - 4000, 8000], dtype=torch.int32)
+    dither = torch.randn(3, L, generator=g)
+    bft, btf, frames, pct = ops.mel(wave.to(dev), lens.to(dev), dither.to(dev), None, True)
+    T = ops.mel_num_frames(L)
+    assert bft.shape == (3, 64, T)
+    for b in range(3):
+        Lb = int(lens[b])
+        ref = R.parse_wave(wave[b:b + 1, :Lb], dither[b:b + 1, :Lb])          # (1,64,Tb)
+        Tb = ref.shape[2]
+        assert int(frames[b]) == Tb == R.num_frames(Lb)
+        assert abs(float(pct[b]) - Tb / T) < 1e-7
+        got = bft[b, :, :Tb].cpu()
+        # north_star tolerance: mel features within 1e-4 relative (to the feature scale, O(1) after
+        # normalisation).  A pure tone has ~70 dB of dynamic range, where two f32 FFTs differ in the
+        # weak bins by their own round-off: price that with the f64 evaluation of the same oracle.
+        ref64 = R.parse_wave(wave[b:b + 1, :Lb].double(), dither[b:b + 1, :Lb].double())
+        tol = max(1e-4, 2.0 * max_rel(ref[0], ref64[0]))
+        assert max_rel(got, ref[0]) < tol, (kind, b, max_rel(got, ref[0]), tol)
+        assert max_rel(got, ref64[0]) < tol, (kind, b, max_rel(got, ref64[0]), tol)
+        assert torch.all(bft[b, :, Tb:] == 0)
+        assert torch.equal(btf[b].t().contiguous().cpu(), bft[b].cpu())
+
+
+def test_mel_db_and_specaugment(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    L = 16000
+    wave = 0.05 * torch.randn(2, L, generator=g)
+    rng = random.Random(7)
+    T = R.num_frames(L)
+    augs = [R.spec_augment_draw(rng, 64, T) for _ in range(2)]
+    aug = torch.tensor(augs, dtype=torch.int32)
+    # dB only (normalize=0), no aug
+    bft, _, _, _ = ops.mel(wave.to(dev), None, None, None, False)
+    ref_db = torch.stack([R.parse_wave(wave[b:b + 1], None, None, normalize=False)[0] for b in range(2)])
+    assert (bft.cpu() - ref_db).abs().max() < 2e-3          # dB units (values ~ -60..0)
+    # full chain with SpecAugment zeros applied before the statistics
+    bft2, _, _, _ = ops.mel(wave.to(dev), None, None, aug.to(dev), True)
+    for b in range(2):
+        ref = R.parse_wave(wave[b:b + 1], None, augs[b])
+        assert max_rel(bft2[b].cpu(), ref[0]) < 1e-4
+
+
+def test_layout_roundtrip_and_mask_lengths(dev):
+    from lightning_asr_amd import ops
+    x = torch.randn(3, 70, 45)
+    y = ops.bct_to_btc(x.to(dev))
+    assert torch.equal(y.cpu(), x.transpose(1, 2).contiguous())
+    assert torch.equal(ops.btc_to_bct(y).cpu(), x)
+    yb = ops.bct_to_btc(x.to(dev), torch.bfloat16)
+    assert torch.equal(yb.cpu(), x.transpose(1, 2).contiguous().bfloat16())
+    gold = np.load("tests/golden/mask_lengths.npz")
+    for T, p, l in zip(gold["T"], gold["pct"], gold["lens"]):
+        got = ops.mask_lengths(torch.tensor([p], dtype=torch.float32, device=dev), int(T))
+        assert int(got[0]) == int(l)
+
+
+# ----------------------------------------------------------------------------------------- depthwise conv
+@pytest.mark.parametrize("C,k,stride,T", [(64, 33, 2, 201), (256, 39, 1, 101), (512, 75, 1, 260), (336, 51, 1, 77), (512, 87, 1, 130)])
+def test_dwconv_fwd_bwd(dev, C, k, stride, T):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C + k)
+    B = 3
+    x = torch.randn(B, C, T, generator=g, requires_grad=True)
+    w = (torch.randn(C, 1, k, generator=g) / math.sqrt(k)).requires_grad_(True)
+    y = F.conv1d(x, w, None, stride, k // 2, 1, C)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xg = x.detach().transpose(1, 2).contiguous().to(dev)
+    got = ops.dwconv(xg, w.detach().to(dev), stride)
+    assert max_rel(got.transpose(1, 2), y.detach()) < 2e-6
+    dyg = dy.transpose(1, 2).contiguous().to(dev)
+    dw = ops.dwconv_wgrad(xg, dyg, k, stride)
+    assert max_rel(dw, w.grad[:, 0]) < 2e-5
+    if stride == 1:
+        add = torch.randn(B, T, C, generator=g)
+        dx = ops.dwconv(dyg, w.detach().to(dev), 1, flip=True, addend=add.to(dev))
+        assert max_rel(dx.cpu() - add, x.grad.transpose(1, 2)) < 2e-6
+
+
+def test_dwconv_bf16(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 256, 90, generator=g).bfloat16()
+    w = torch.randn(256, 1, 33, generator=g) / 6
+    ref = F.conv1d(x.float(), w, None, 1, 16, 1, 256)
+    got = ops.dwconv(x.transpose(1, 2).contiguous().to(dev), w.to(dev))
+    assert got.dtype == torch.bfloat16
+    assert max_rel(got.float().transpose(1, 2), ref) < 1e-2
+
+
+# ----------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,tA,tB", [(300, 256, 64, 0, 0), (257, 130, 100, 0, 1), (96, 200, 515, 1, 1), (128, 28, 1024, 1, 0),
+                                         (1000, 28, 1024, 0, 0), (70, 1024, 28, 0, 1), (33, 50, 4334, 0, 0), (200, 4334, 64, 0, 0)])
+def test_gemm_layouts(dev, M, N, K, tA, tB):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    Bm = torch.randn((K, N) if tB else (N, K), generator=g)
+    ref = (A.t() if tA else A).double() @ (Bm if tB else Bm.t()).double()
+    got, _ = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, tA, tB)
+    assert max_rel(got, ref) < 2e-6
+    got2, _ = ops.gemm(A.to(dev), Bm.to(dev), M, N, K, tA, tB, split_k=4)
+    assert max_rel(got2, ref) < 2e-6
+
+
+def test_gemm_epilogue_bias_addend_mask_stats(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, T, K, N = 3, 50, 96, 200
+    M = B * T
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    add = torch.randn(M, N, generator=g)
+    lens = torch.tensor([50, 31, 0], dtype=torch.int32)
+    ref = A @ W.t() + bias + add
+    keep = (torch.arange(T).view(1, T) < lens.view(B, 1)).view(M, 1)
+    ref = ref * keep
+    got, stats = ops.gemm(A.to(dev), W.to(dev), M, N, K, bias=bias.to(dev), addend=add.to(dev), row_lens=lens.to(dev),
+                          rows_per_seq=T, want_stats=True)
+    assert max_rel(got, ref) < 2e-6
+    assert max_rel(stats[:N], ref.sum(0)) < 1e-5
+    assert max_rel(stats[N:], (ref * ref).sum(0)) < 1e-5
+
+
+def test_gemm_bf16_inputs(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 260, 136, 256
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = torch.randn(N, K, generator=g).bfloat16()
+    ref = A.double() @ W.double().t()
+    got, stats = ops.gemm(A.to(dev), W.to(dev), M, N, K, want_stats=True)
+    assert got.dtype == torch.bfloat16
+    assert max_rel(got.float(), ref) < 6e-3
+    assert max_rel(stats[:N], got.float().sum(0)) < 1e-4
+    got32, _ = ops.gemm(A.to(dev), W.to(dev), M, N, K, out_dtype=torch.float32)
+    assert max_rel(got32, ref) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------- BN + residual + act
+@pytest.mark.parametrize("C,has_res,act,masked", [(256, True, "relu", True), (512, False, "relu", False), (1024, False, "relu", False),
+                                                  (336, True, "swish", True), (64, True, "none", False)])
+def test_bn_act_fwd_bwd(dev, C, has_res, act, masked):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C)
+    B, T = 3, 37
+    y = torch.randn(B, C, T, generator=g)
+    lens = torch.tensor([37, 20, 5], dtype=torch.int32)
+    keep = (torch.arange(T).view(1, 1, T) < lens.view(B, 1, 1)).float()
+    if masked:
+        y = y * keep
+    y = y.requires_grad_(True)
+    y2 = torch.randn(B, C, T, generator=g, requires_grad=True) if has_res else None
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True), (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    gam2, bet2 = (1 + 0.1 * torch.randn(C, generator=g)).requires_grad_(True), (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    rm2, rv2 = torch.zeros(C), torch.ones(C)
+    ym = y * keep if masked else y          # mask is part of the graph: its zeros block the gradient
+    z = F.batch_norm(ym, rm, rv, gam, bet, True, 0.1, 1e-3)
+    if has_res:
+        z = z + F.batch_norm(y2, rm2, rv2, gam2, bet2, True, 0.1, 1e-3)
+    out = {"relu": F.relu, "swish": lambda v: v * torch.sigmoid(v), "none": lambda v: v}[act](z)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+
+    def cl(t):
+        return t.detach().transpose(1, 2).contiguous().to(dev)
+    yg, y2g = cl(ym), (cl(y2) if has_res else None)
+    N = B * T
+
+    def stats_of(t):
+        f = t.reshape(N, C).double()
+        return torch.cat([f.sum(0), (f * f).sum(0)]).float()
+    grm, grv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    coef, saved = ops.bn_finalize(stats_of(yg), gam.detach().to(dev), bet.detach().to(dev), grm, grv, N)
+    assert max_rel(grm, rm) < 1e-5 and max_rel(grv, rv) < 1e-5
+    coef2 = saved2 = None
+    if has_res:
+        coef2, saved2 = ops.bn_finalize(stats_of(y2g), gam2.detach().to(dev), bet2.detach().to(dev), torch.zeros(C, device=dev),
+                                        torch.ones(C, device=dev), N)
+    got = ops.bn_act(yg, coef, y2g, coef2, None, act)
+    assert max_rel(got.transpose(1, 2), out.detach()) < 5e-6
+    dy, dy2, dg, db, dg2, db2 = ops.bn_act_bwd(cl(dout), yg, coef, saved, gam.detach().to(dev), y2g, coef2, saved2,
+                                               gam2.detach().to(dev) if has_res else None, row_lens=lens.to(dev) if masked else None,
+                                               act=act)
+    assert max_rel(dy.transpose(1, 2), y.grad) < 2e-5
+    assert max_rel(dg, gam.grad) < 2e-5 and max_rel(db, bet.grad) < 2e-5
+    if has_res:
+        assert max_rel(dy2.transpose(1, 2), y2.grad) < 2e-5
+        assert max_rel(dg2, gam2.grad) < 2e-5 and max_rel(db2, bet2.grad) < 2e-5
+    # eval mode: coefficients from the running statistics
+    coef_e, _ = ops.bn_finalize(None, gam.detach().to(dev), bet.detach().to(dev), grm, grv, N, training=False)
+    ref_e = F.batch_norm(ym.detach(), grm.cpu(), grv.cpu(), gam.detach(), bet.detach(), False, 0.1, 1e-3)
+    got_e = ops.bn_act(yg, coef_e, None, None, None, "none")
+    assert max_rel(got_e.transpose(1, 2), ref_e) < 5e-6
+
+
+# ----------------------------------------------------------------------------------------- log_softmax / CTC / decode
+@pytest.mark.parametrize("C", [28, 4334])
+def test_log_softmax_argmax(dev, C):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(5, 41, C, generator=g) * 3
+    x[0, 0, 3] = x[0, 0, 7] = 50.0          # exact tie -> lowest index
+    lp, am = ops.log_softmax(x.to(dev))
+    ref = F.log_softmax(x, -1)
+    assert (lp.cpu() - ref).abs().max() < 2e-6
+    assert torch.equal(am.cpu().long(), ref.argmax(-1))
+    assert int(am[0, 0]) == 3
+
+
+def _ctc_case(B, T, C, S, seed, repeats=False):
+    g = torch.Generator().manual_seed(seed)
+    lp = F.log_softmax(torch.randn(B, T, C, generator=g) * 2, -1)
+    tg = torch.randint(0, C - 1, (B, S), generator=g)
+    if repeats:
+        tg[:, 1::2] = tg[:, 0::2][:, :tg[:, 1::2].shape[1]]
+    il = torch.randint(max(2 * S + 1, T // 2), T + 1, (B,), generator=g, dtype=torch.int32)
+    il[0] = T
+    tl = torch.randint(1, S + 1, (B,), generator=g, dtype=torch.int32)
+    tl[0] = S
+    return lp, tg, il, tl
+
+
+@pytest.mark.parametrize("B,T,C,S,rep", [(3, 20, 5, 4, True), (4, 101, 28, 12, False), (2, 60, 28, 25, True), (2, 120, 4334, 45, False),
+                                         (2, 501, 28, 100, True), (1, 300, 28, 140, False), (1, 600, 40, 290, False)])
+def test_ctc_matches_torch(dev, B, T, C, S, rep):
+    from lightning_asr_amd import ops
+    lp, tg, il, tl = _ctc_case(B, T, C, S, B * 1000 + T, rep)
+    lpr = lp.clone().requires_grad_(True)
+    ref = F.ctc_loss(lpr.transpose(0, 1), tg, il, tl, blank=C - 1, reduction="none")
+    gs = torch.rand(B) + 0.5
+    (ref * gs).sum().backward()
+    nll, grad = ops.ctc_loss(lp.to(dev), tg.to(dev), il.to(dev), tl.to(dev), C - 1, True, gs.to(dev))
+    assert torch.isfinite(ref).all()
+    # north_star: fp32 CTC loss within 1e-4 relative of the CPU reference
+    assert ((nll.cpu() - ref.detach()).abs() / ref.detach().abs()).max() < 1e-4
+    gref = lpr.grad
+    assert (grad.cpu() - gref).abs().max() < 2e-3 * gref.abs().max() + 1e-6
+    assert rel_l2(grad, gref) < 2e-3
+    # default scale = 1/B (batch mean, train.py:77)
+    _, grad_m = ops.ctc_loss(lp.to(dev), tg.to(dev), il.to(dev), tl.to(dev), C - 1, True, None)
+    lpr2 = lp.clone().requires_grad_(True)
+    F.ctc_loss(lpr2.transpose(0, 1), tg, il, tl, blank=C - 1, reduction="none").mean().backward()
+    assert rel_l2(grad_m, lpr2.grad) < 2e-3
+
+
+def test_ctc_small_vs_numpy_and_edge_cases(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(0)
+    B, T, C = 4, 9, 5
+    lp = F.log_softmax(torch.randn(B, T, C, generator=g), -1)
+    tg = torch.tensor([[0, 0, 1], [1, 2, 0], [3, 3, 3], [2, 0, 0]])
+    il = torch.tensor([9, 6, 3, 0], dtype=torch.int32)       # sample 2 infeasible (needs 5 frames), sample 3 empty input
+    tl = torch.tensor([3, 2, 3, 0], dtype=torch.int32)
+    nll, grad = ops.ctc_loss(lp.to(dev), tg.to(dev), il.to(dev), tl.to(dev), C - 1, True, torch.ones(B, device=dev))
+    nll, grad = nll.cpu(), grad.cpu()
+    for b in (0, 1):
+        n_ref, g_ref = R.ctc_numpy(lp[b, :il[b]].numpy(), tg[b, :tl[b]].tolist(), C - 1)
+        assert abs(nll[b].item() - n_ref) < 1e-4 * abs(n_ref)
+        # torch convention: grad = exp(lp) - occupancy; ctc_numpy returns the true derivative -occupancy
+        full = np.exp(lp[b, :il[b]].numpy().astype(np.float64)) + g_ref
+        assert np.abs(grad[b, :il[b]].numpy() - full).max() < 1e-4
+        assert torch.all(grad[b, il[b]:] == 0)
+    assert math.isinf(nll[2].item()) and nll[2] > 0           # zero_infinity=False (train.py:196)
+    assert torch.isnan(grad[2, :3]).all() and torch.all(grad[2, 3:] == 0)
+    assert nll[3].item() == 0.0 and torch.all(grad[3] == 0)
+
+
+def test_greedy_decode(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, T, blank = 5, 300, 27
+    ids = torch.randint(0, 28, (B, T), generator=g, dtype=torch.int32)
+    ids[0, :40] = 3
+    ids[1] = blank
+    lens = torch.tensor([300, 300, 150, 1, 0], dtype=torch.int32)
+    tok, n = ops.greedy_decode(ids.to(dev), lens.to(dev), blank)
+    for b in range(B):
+        ref = R.greedy_collapse(ids[b, :lens[b]].tolist(), blank)
+        assert int(n[b]) == len(ref)
+        assert tok[b, :len(ref)].cpu().tolist() == ref
+    tok2, n2 = ops.greedy_decode(ids.to(dev), None, blank)
+    assert tok2[0, :int(n2[0])].cpu().tolist() == R.greedy_collapse(ids[0].tolist(), blank)
+
+
+# ----------------------------------------------------------------------------------------- optimiser
+def test_novograd_matches_oracle(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    shapes = [(256, 1, 33), (256, 64, 1), (256,), (3,), (1024, 512, 1), (28,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    offs = np.cumsum([0] + [p.numel() for p in ps])
+    flat = torch.cat([p.flatten() for p in ps]).to(dev)
+    m = torch.zeros_like(flat)
+    v = torch.zeros(len(ps), device=dev)
+    offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+    lr = torch.tensor([0.01], device=dev)
+    st = R.NovogradState(len(ps))
+    ref_p = [p.clone() for p in ps]
+    for step in range(3):
+        gr = [torch.randn(s, generator=g) * (step + 1) for s in shapes]
+        R.novograd_step(ref_p, [x.clone() for x in gr], st, 0.01, 0.8, 0.5, 1e-8, 1e-3)
+        gflat = torch.cat([x.flatten() for x in gr]).to(dev) * 4.0
+        ops.novograd_step(flat, gflat, m, v, offsets, lr, 0.8, 0.5, 1e-8, 1e-3, grad_scale=0.25)
+    ref_flat = torch.cat([p.flatten() for p in ref_p])
+    assert max_rel(flat, ref_flat) < 2e-6
+    assert max_rel(v, torch.stack([x for x in st.exp_avg_sq])) < 5e-5     # oracle sums ||g||^2 in f32
