@@ -174,6 +174,16 @@ int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float*
                        float eps, float weight_decay, float grad_scale, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- measurement --------------
+ * Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's
+ * roofline leg; off by default, costs two event records per instrumented launch when on).
+ * lasr_prof_collect synchronises the recorded events and returns, per class: summed milliseconds,
+ * summed algorithmic FLOPs and bytes (operands + result, each counted once) and launch count.     */
+#define LASR_PROF_KINDS 4
+enum { LASR_PROF_GEMM = 0, LASR_PROF_DWCONV = 1, LASR_PROF_BN = 2, LASR_PROF_OTHER = 3 };
+int lasr_prof_enable(int on);
+int lasr_prof_collect(double* ms, double* flops, double* bytes, int64_t* count);
+
 /* small helpers used by the plan and by the host */
 int lasr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C);

@@ -25,3 +25,59 @@ int hip_fail(hipError_t e, const char* what) {
 
 extern "C" int lasr_version(void) { return LASR_VERSION; }
 extern "C" const char* lasr_last_error(void) { return lasr::g_err; }
+
+// ---- in-library kernel timer (bench.py's roofline leg) -----------------------------------------
+// When enabled, launches of the instrumented kernel classes are bracketed by HIP events on the
+// stream they are launched on; lasr_prof_collect() synchronises the events and returns the sums.
+#include <vector>
+namespace lasr {
+struct ProfRec { hipEvent_t a, b; int kind; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static double g_flops[LASR_PROF_KINDS], g_bytes[LASR_PROF_KINDS];
+static int64_t g_count[LASR_PROF_KINDS];
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+int prof_begin(int kind, hipStream_t st, double flops, double bytes) {
+  if (!g_prof_on || kind < 0 || kind >= LASR_PROF_KINDS) return -1;
+  ProfRec r{get_event(), get_event(), kind};
+  (void)hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+  g_flops[kind] += flops; g_bytes[kind] += bytes; g_count[kind] += 1;
+  return (int)g_prof.size() - 1;
+}
+void prof_end(int token, hipStream_t st) {
+  if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, st);
+}
+}  // namespace lasr
+
+extern "C" int lasr_prof_enable(int on) {
+  lasr::g_prof_on = on != 0;
+  if (on) {
+    for (auto& r : lasr::g_prof) { lasr::g_pool.push_back(r.a); lasr::g_pool.push_back(r.b); }
+    lasr::g_prof.clear();
+    for (int k = 0; k < LASR_PROF_KINDS; ++k) { lasr::g_flops[k] = lasr::g_bytes[k] = 0; lasr::g_count[k] = 0; }
+  }
+  return 0;
+}
+
+extern "C" int lasr_prof_collect(double* ms, double* flops, double* bytes, int64_t* count) {
+  using namespace lasr;
+  LASR_CHECK_ARG(ms && flops && bytes && count, "lasr_prof_collect: null pointer");
+  for (int k = 0; k < LASR_PROF_KINDS; ++k) { ms[k] = 0; flops[k] = g_flops[k]; bytes[k] = g_bytes[k]; count[k] = g_count[k]; }
+  for (auto& r : g_prof) {
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e, "lasr_prof_collect");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e, "lasr_prof_collect");
+    ms[r.kind] += (double)t;
+  }
+  return 0;
+}

@@ -35,6 +35,10 @@ int hip_fail(hipError_t e, const char* what);
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// in-library kernel timer (capi.hip); kinds are LASR_PROF_* in lasr.h
+int prof_begin(int kind, hipStream_t st, double flops, double bytes);
+void prof_end(int token, hipStream_t st);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

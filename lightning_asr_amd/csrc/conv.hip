@@ -179,6 +179,8 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
   const int in_rows = (kTT - 1) * stride + k;
   const size_t shmem = ((size_t)in_rows + k) * kCB * sizeof(float);
   dim3 grid((unsigned)cdiv(Tout, kTT), (unsigned)cdiv(C, kCB), (unsigned)B);
+  const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 2.0 * (double)B * Tout * C * k,
+                             (double)B * (Tin + Tout * (addend ? 2 : 1)) * C * dtype_size(dtype));
   if (dtype == LASR_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(256), shmem, as_stream(stream), (const float*)x, w,
@@ -188,6 +190,7 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
     hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, grid, dim3(256), shmem, as_stream(stream), (const bf16_t*)x, w,
                        (const bf16_t*)addend, (bf16_t*)y, Tin, Tout, C, k, stride, flip);
   }
+  prof_end(tok, as_stream(stream));
   LASR_LAUNCH_CHECK("dwconv_fwd_kernel");
   return 0;
 }

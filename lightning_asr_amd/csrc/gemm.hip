@@ -285,9 +285,12 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
   if (stats) g.stat_partials = reinterpret_cast<float*>(wsp);
   dim3 grid((unsigned)cdiv(N, BN), (unsigned)grid_m, (unsigned)split_k);
   hipStream_t st = as_stream(stream);
+  const double gbytes = (double)(M * K + N * K) * esz + (double)M * N * dtype_size(dtype_c);
+  const int tok = prof_begin(LASR_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K, gbytes);
   int rc;
   if (dtype_ab == LASR_F32) rc = dtype_c == LASR_F32 ? launch_f32<float, float>(g, transA, transB, grid, st) : launch_f32<float, bf16_t>(g, transA, transB, grid, st);
   else rc = dtype_c == LASR_F32 ? launch_f32<bf16_t, float>(g, transA, transB, grid, st) : launch_f32<bf16_t, bf16_t>(g, transA, transB, grid, st);
+  prof_end(tok, st);
   if (rc) return rc;
   if (g.split_ws) {
     const int64_t mn = M * N;

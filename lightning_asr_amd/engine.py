@@ -104,6 +104,30 @@ class NativeModel:
                         raise ValueError("%s: shape %s != %s" % (t.name, tuple(v.shape), t.shape))
                     self.view(t).copy_(v.to(self.device, torch.float32))
 
+    def init_parameters(self, seed: int = 0) -> None:
+        """PyTorch-default initialisation of the reference modules (Conv1d/Linear/LSTM:
+        U(-1/sqrt(fan_in), 1/sqrt(fan_in)); BatchNorm: weight 1, bias 0, mean 0, var 1)."""
+        g = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for t in self.tensors:
+                if t.kind == 2:
+                    self.counters[t.name].zero_()
+                elif t.kind == 1:
+                    self.view(t).fill_(1.0 if t.name.endswith("running_var") else 0.0)
+                elif ".bn." in t.name or ".reside.1." in t.name or ".last_cnn2.1." in t.name:
+                    self.view(t).fill_(1.0 if t.name.endswith("weight") else 0.0)
+                else:
+                    if "rnn" in t.name:
+                        fan_in = 40
+                    elif t.name == "decoder.bias":
+                        fan_in = 1024
+                    else:
+                        fan_in = 1
+                        for s_ in t.shape[1:]:
+                            fan_in *= s_
+                    bound = 1.0 / (fan_in ** 0.5)
+                    self.view(t).copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * bound).to(self.device))
+
     def param_offsets(self) -> torch.Tensor:
         offs = [t.offset for t in self.param_infos()] + [self.n_param]
         return torch.tensor(offs, dtype=torch.int64, device=self.device)

@@ -1,0 +1,68 @@
+"""One data-parallel training step of the hot path, entirely on the GPU:
+
+    wave (HBM) -> log-mel features -> QuartzNet forward -> mean CTC -> backward
+               -> gradient all-reduce (RCCL over xGMI, world > 1) -> NovoGrad -> LR schedule
+
+This is what ``LightingModule.training_step`` + Lightning's optimiser loop do in the reference
+(train.py:64-86, scheduler/novograd.py:75-145); here each stage is one or a few C-ABI calls."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .engine import NativeModel
+from .schedule import CosineAnnealingWarmupRestarts
+
+
+class TrainStep:
+    def __init__(self, model: NativeModel, learning_rate: float = 1e-2, weight_decay: float = 1e-3,
+                 betas=(0.8, 0.5), eps: float = 1e-8, schedule: Optional[CosineAnnealingWarmupRestarts] = None,
+                 process_group=None):
+        self.model = model
+        self.wd, self.betas, self.eps = weight_decay, betas, eps
+        dev = model.device
+        self.exp_avg = torch.zeros_like(model.params)
+        self.exp_avg_sq = torch.zeros(len(model.param_infos()), dtype=torch.float32, device=dev)
+        self.offsets = model.param_offsets()
+        self.schedule = schedule
+        self.lr = schedule.lr if schedule is not None else learning_rate
+        self.lr_dev = torch.tensor([self.lr], dtype=torch.float32, device=dev)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.global_step = 0
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """DDP wrap-time broadcast of parameters and buffers from rank 0."""
+        if self.world > 1:
+            torch.distributed.broadcast(self.model.params, src, group=self.pg)
+            torch.distributed.broadcast(self.model.buffers, src, group=self.pg)
+
+    def features(self, wave, sample_lens=None, dither=None, aug=None):
+        """wave (B, L) f32 on the GPU -> ([B][T][64] features in the activation dtype, pct (B))."""
+        _, btf, _, pct = ops.mel(wave, sample_lens, dither, aug, True, self.model.act_dtype, want_bft=False, want_btf=True)
+        return btf, pct
+
+    def optimizer_step(self) -> None:
+        m = self.model
+        if self.world > 1:
+            # one flat 20 MB SUM all-reduce; the 1/world average is folded into the optimiser's grad scale
+            torch.distributed.all_reduce(m.grads, group=self.pg)
+        ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
+                          self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+        if self.schedule is not None:
+            self.lr = self.schedule.step()
+            self.lr_dev.fill_(self.lr)
+        self.global_step += 1
+
+    def step_features(self, feats, pct, targets, tgt_lens):
+        loss, nll, logp, am = self.model.loss_backward(feats, pct, targets, tgt_lens)
+        self.optimizer_step()
+        return loss, nll, logp, am
+
+    def step(self, wave, targets, tgt_lens, sample_lens=None, dither=None, aug=None):
+        feats, pct = self.features(wave, sample_lens, dither, aug)
+        return self.step_features(feats, pct, targets, tgt_lens)
