@@ -1,0 +1,22 @@
+// Shared between the f32-MFMA (gemm.hip) and bf16-MFMA (gemm_bf16.hip) GEMM kernels.
+#pragma once
+#include "common.h"
+
+namespace lasr {
+
+struct GemmArgs {
+  const void* A; const void* B; void* C;
+  int64_t M, N, K, lda, ldb, ldc;
+  const float* bias; const void* addend;
+  const int32_t* row_lens; int64_t rows_per_seq;
+  float* stat_partials;  // [gridM][2][N] or null
+  float* split_ws;       // [split][M][N] or null
+  int64_t k_per_split;
+  int vecA, vecB;
+};
+
+// bf16-MFMA path (gemm_bf16.hip); returns LASR_E_SHAPE-free 0 on launch, or -100 when the
+// request needs the f32 path (f32 operands or an addend).
+int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim3 grid, hipStream_t st);
+
+}  // namespace lasr

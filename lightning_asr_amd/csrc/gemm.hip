@@ -8,6 +8,8 @@
 // Both operands are staged K-major in LDS ([k][m], [k][n]) so a fragment read is 32 consecutive
 // floats per half-wave (conflict-free ds_read_b32) whatever the global layout was.
 #include "common.h"
+#include "gemm.h"
+#include <stdlib.h>
 
 namespace lasr {
 
@@ -74,16 +76,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const float (&
   }
 }
 
-struct GemmArgs {
-  const void* A; const void* B; void* C;
-  int64_t M, N, K, lda, ldb, ldc;
-  const float* bias; const void* addend;
-  const int32_t* row_lens; int64_t rows_per_seq;
-  float* stat_partials;  // [gridM][2][N] or null
-  float* split_ws;       // [split][M][N] or null
-  int64_t k_per_split;
-  int vecA, vecB;
-};
 
 // grid: (ceil(N/BN), ceil(M/BM), split_k)
 template <typename TAB, typename TC, bool TRANS_A, bool TRANS_B>
@@ -268,14 +260,17 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
   g.bias = bias; g.addend = addend; g.row_lens = row_lens; g.rows_per_seq = rows_per_seq;
   g.stat_partials = nullptr; g.split_ws = nullptr;
   const size_t esz = dtype_size(dtype_ab);
-  // 4-element vector loads need the row pitch and base to keep every 4-group aligned
-  g.vecA = (g.lda % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % (4 * esz) == 0);
-  g.vecB = (g.ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(B) % (4 * esz) == 0);
+  // bf16 operands without an addend take the bf16-MFMA kernel (gemm_bf16.hip); everything else the f32-MFMA one
+  const bool use_bf16 = dtype_ab == LASR_BF16 && addend == nullptr && !getenv("LASR_FORCE_F32_MFMA");
+  // vector loads (4 elements, or 8 for the bf16 kernel) need the row pitch and base to keep every group aligned
+  const int vw = use_bf16 ? 8 : 4;
+  g.vecA = (g.lda % vw == 0) && (reinterpret_cast<uintptr_t>(A) % (vw * esz) == 0);
+  g.vecB = (g.ldb % vw == 0) && (reinterpret_cast<uintptr_t>(B) % (vw * esz) == 0);
   char* wsp = reinterpret_cast<char*>(workspace);
   if (split_k > 1) {
     g.split_ws = reinterpret_cast<float*>(wsp);
     wsp += align_up((size_t)split_k * M * N * sizeof(float), 256);
-    const int64_t per = cdiv(cdiv(K, split_k), BK) * BK;
+    const int64_t per = cdiv(cdiv(K, split_k), 64) * 64;  // whole K tiles of either kernel
     g.k_per_split = per;
     split_k = (int)cdiv(K, per);
   } else {
@@ -288,7 +283,8 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
   const double gbytes = (double)(M * K + N * K) * esz + (double)M * N * dtype_size(dtype_c);
   const int tok = prof_begin(LASR_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K, gbytes);
   int rc;
-  if (dtype_ab == LASR_F32) rc = dtype_c == LASR_F32 ? launch_f32<float, float>(g, transA, transB, grid, st) : launch_f32<float, bf16_t>(g, transA, transB, grid, st);
+  if (use_bf16) rc = launch_gemm_bf16(g, dtype_c, transA, transB, grid, st);
+  else if (dtype_ab == LASR_F32) rc = dtype_c == LASR_F32 ? launch_f32<float, float>(g, transA, transB, grid, st) : launch_f32<float, bf16_t>(g, transA, transB, grid, st);
   else rc = dtype_c == LASR_F32 ? launch_f32<bf16_t, float>(g, transA, transB, grid, st) : launch_f32<bf16_t, bf16_t>(g, transA, transB, grid, st);
   prof_end(tok, st);
   if (rc) return rc;

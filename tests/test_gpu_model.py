@@ -101,3 +101,21 @@ def test_aishell_vocab_large_C(dev):
     assert np.array_equal(am.cpu().numpy().astype(np.int16), gold["argmax"])
     norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
     assert np.abs(norms / gold["grad_norms"] - 1).max() < 5e-3
+
+
+def test_plain_bf16_mode_tracks_f32(dev):
+    """bf16 activation mode (bench dtype): same plan on the bf16-MFMA kernels.  Not a parity mode:
+    reported against the f32 golden with its own tolerance."""
+    from lightning_asr_amd import ops
+    gold = np.load("tests/golden/model_plain.npz")
+    x, tg, pct, tsz = golden_inputs()
+    m = _native("plain", 28, dev, torch.bfloat16)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev), torch.bfloat16)
+    loss, nll, lp, am = m.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert abs(loss.item() - gold["losses"][0]) / gold["losses"][0] < 2e-2
+    assert np.abs(lp.cpu().numpy() - gold["logprobs"]).max() < 0.25
+    agree = (am.cpu().numpy().astype(np.int16) == gold["argmax"]).mean()
+    assert agree > 0.9, agree
+    norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
+    assert np.median(np.abs(norms / gold["grad_norms"] - 1)) < 5e-2
+    assert torch.isfinite(m.grads).all()

@@ -343,3 +343,40 @@ def test_novograd_matches_oracle(dev):
     ref_flat = torch.cat([p.flatten() for p in ref_p])
     assert max_rel(flat, ref_flat) < 2e-6
     assert max_rel(v, torch.stack([x for x in st.exp_avg_sq])) < 5e-5     # oracle sums ||g||^2 in f32
+
+
+# ----------------------------------------------------------------------------------------- bf16 MFMA GEMM
+@pytest.mark.parametrize("M,N,K,tA,tB", [(300, 256, 64, 0, 0), (257, 130, 100, 0, 1), (96, 200, 515, 1, 1), (128, 28, 1024, 1, 0),
+                                         (1000, 28, 1024, 0, 0), (70, 1024, 28, 0, 1), (512, 512, 1603, 1, 1), (640, 336, 512, 0, 1)])
+def test_gemm_bf16_mfma_exact_integers(dev, M, N, K, tA, tB):
+    """Small-integer operands: every product and partial sum is exact in bf16 x bf16 -> f32, so the
+    bf16-MFMA kernel (b128 and transposed ds_read_b64_tr_b16 fragments) must match bit for bit."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randint(-4, 5, (K, M) if tA else (M, K), generator=g).float()
+    Bm = torch.randint(-4, 5, (K, N) if tB else (N, K), generator=g).float()
+    ref = (A.t() if tA else A).double() @ (Bm if tB else Bm.t()).double()
+    got, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, tA, tB, out_dtype=torch.float32)
+    assert torch.equal(got.cpu().double(), ref)
+    got2, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, tA, tB, out_dtype=torch.float32, split_k=5)
+    assert torch.equal(got2.cpu().double(), ref)
+
+
+def test_gemm_bf16_mfma_epilogue(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, T, K, N = 3, 77, 256, 336
+    M = B * T
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / 16).bfloat16()
+    bias = torch.randn(N, generator=g)
+    lens = torch.tensor([77, 40, 0], dtype=torch.int32)
+    keep = (torch.arange(T).view(1, T) < lens.view(B, 1)).view(M, 1)
+    ref = ((A.double() @ W.double().t() + bias.double()) * keep).float()
+    got, stats = ops.gemm(A.to(dev), W.to(dev), M, N, K, bias=bias.to(dev), row_lens=lens.to(dev), rows_per_seq=T, want_stats=True)
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got.cpu(), ref.bfloat16()) or max_rel(got.float(), ref) < 4e-3
+    gf = got.float().cpu().double()
+    assert max_rel(stats[:N], gf.sum(0)) < 1e-5           # statistics of the values as stored
+    assert max_rel(stats[N:], (gf * gf).sum(0)) < 1e-5
+    assert torch.all(got[T + 40:] == 0)
