@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblasr.so")
+LIB_PATH = os.environ.get("LASR_LIB_PATH", os.path.join(_HERE, "liblasr.so"))   # override: A/B of two builds
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2

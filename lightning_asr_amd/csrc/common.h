@@ -89,6 +89,40 @@ struct Elem<bf16_t> {
   }
 };
 
+// 16-byte vectors of activations: 4 f32 or 8 bf16 per lane per access
+template <typename T>
+struct Vec;
+template <>
+struct Vec<float> {
+  static constexpr int kN = 4;
+  __device__ static __forceinline__ void load(const float* p, float (&o)[4]) { Elem<float>::ld4(p, o); }
+  __device__ static __forceinline__ void store(float* p, const float (&o)[4]) { Elem<float>::st4(p, o); }
+};
+template <>
+struct Vec<bf16_t> {
+  static constexpr int kN = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+    uint4 v;
+    v.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+    v.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
+    v.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+};
+
+// out[i] = sum_p partials[p][i] for i < ncols, in a fixed order; i < split goes to out0, the rest to
+// out1[i - split] (out1 may be null).  One launch, 32 columns x 8 partial lanes per block (norm.hip).
+int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, float* out0, int64_t split, float* out1,
+                           hipStream_t st);
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

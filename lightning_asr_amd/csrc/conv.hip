@@ -162,6 +162,191 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
   out[i] = s;
 }
 
+
+// ------------------------------------------------------------------ stride-1 fast paths --------
+// LDS keeps the activation tile in its storage type (bf16 halves the footprint -> 3 workgroups/CU);
+// a lane reads 4 channels of one frame with one ds_read (b128 for f32, b64 for bf16).
+template <typename T>
+__device__ __forceinline__ float4 lds_ld4(const T* p);
+template <>
+__device__ __forceinline__ float4 lds_ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 lds_ld4<bf16_t>(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+template <typename T>
+__device__ __forceinline__ void lds_copy4(T* dst, const T* src, bool ok);
+template <>
+__device__ __forceinline__ void lds_copy4<float>(float* dst, const float* src, bool ok) {
+  *reinterpret_cast<float4*>(dst) = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <>
+__device__ __forceinline__ void lds_copy4<bf16_t>(bf16_t* dst, const bf16_t* src, bool ok) {
+  *reinterpret_cast<uint2*>(dst) = ok ? *reinterpret_cast<const uint2*>(src) : make_uint2(0u, 0u);
+}
+
+// Forward / data-gradient, stride 1.  Each lane owns 4 channels x 8 consecutive output frames and
+// slides an 8-frame register window over the taps: per tap one new frame and one tap vector are
+// read from LDS for 32 FMAs (the generic kernel above reads 9 vectors for the same work).
+// The taps are zero-padded to kpad = 8*ceil(k/8) so the window rotation unrolls with static indices.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_s1_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const T* __restrict__ addend, T* __restrict__ y, int64_t Tlen, int64_t C,
+                                                        int k, int flip) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int pad = k / 2;
+  const int kpad = (k + 7) & ~7;
+  const int in_rows = kTT + kpad + 8;
+  float* s_w = reinterpret_cast<float*>(smem_raw);                                  // [kpad][kCB]
+  T* s_x = reinterpret_cast<T*>(smem_raw + (size_t)kpad * kCB * sizeof(float));     // [in_rows][kCB]
+  const int b = blockIdx.z;
+  const int64_t c0 = (int64_t)blockIdx.y * kCB;
+  const int64_t t0 = (int64_t)blockIdx.x * kTT;
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int64_t c = c0 + cl * 4;
+  const bool c_ok = c < C;
+  const T* xb = x + (int64_t)b * Tlen * C;
+  for (int i = threadIdx.x; i < kpad * kCB; i += 256) {
+    const int ch = i / kpad, j = i - ch * kpad;
+    float v = 0.f;
+    if (j < k && c0 + ch < C) v = w[(c0 + ch) * k + (flip ? (k - 1 - j) : j)];
+    s_w[j * kCB + ch] = v;
+  }
+  const int64_t in0 = t0 - pad;
+  for (int r = tl; r < in_rows; r += 16) {
+    const int64_t ti = in0 + r;
+    lds_copy4<T>(s_x + (size_t)r * kCB + cl * 4, xb + ti * C + c, c_ok && ti >= 0 && ti < Tlen);
+  }
+  __syncthreads();
+
+  float4 acc[kR], win[8];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const T* xs = s_x + (size_t)(tl * kR) * kCB + cl * 4;
+  const float* ws = s_w + cl * 4;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) win[i] = lds_ld4<T>(xs + (size_t)i * kCB);
+  for (int j0 = 0; j0 < kpad; j0 += 8) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      win[(jj + 7) & 7] = lds_ld4<T>(xs + (size_t)(j0 + jj + 7) * kCB);
+      const float4 wv = *reinterpret_cast<const float4*>(ws + (j0 + jj) * kCB);
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const float4 xv = win[(jj + r) & 7];
+        acc[r].x = fmaf(wv.x, xv.x, acc[r].x);
+        acc[r].y = fmaf(wv.y, xv.y, acc[r].y);
+        acc[r].z = fmaf(wv.z, xv.z, acc[r].z);
+        acc[r].w = fmaf(wv.w, xv.w, acc[r].w);
+      }
+    }
+  }
+  if (!c_ok) return;
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int64_t t = t0 + tl * kR + r;
+    if (t < Tlen) {
+      const int64_t off = ((int64_t)b * Tlen + t) * C + c;
+      float o[4] = {acc[r].x, acc[r].y, acc[r].z, acc[r].w};
+      if (addend) {
+        float a[4];
+        Elem<T>::ld4(addend + off, a);
+        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
+      }
+      Elem<T>::st4(y + off, o);
+    }
+  }
+}
+
+// Weight gradient, stride 1.  Lane = 4 channels x 8 consecutive taps (group jg) x one time split;
+// the 8 frames x[t+j0 .. t+j0+7] slide through a register window as t advances, so a frame costs
+// two LDS vector reads (new x row, dy row) for 32 FMAs.  16 lane groups per workgroup are dealt as
+// ceil(k/8) tap groups x ts time splits; the splits are summed through LDS at the end.
+static constexpr int kSub = 32;  // frames per time split per LDS step
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                              float* __restrict__ partials, int64_t Tlen, int64_t C, int k,
+                                                              int ts) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int pad = k / 2;
+  const int ng = (k + 7) >> 3;          // tap groups
+  const int kpad = ng * 8;
+  const int WT = kSub * ts;             // frames per LDS step
+  const int in_rows = WT + kpad + 8;
+  T* s_x = reinterpret_cast<T*>(smem_raw);                         // [in_rows][kCB]
+  T* s_d = s_x + (size_t)in_rows * kCB;                             // [WT][kCB]
+  const int b = blockIdx.z;
+  const int64_t c0 = (int64_t)blockIdx.y * kCB;
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int jg = grp % ng, sp = grp / ng;
+  const bool active = sp < ts;
+  const int64_t c = c0 + cl * 4;
+  const bool c_ok = c < C;
+  const T* xb = x + (int64_t)b * Tlen * C;
+  const T* db = dy + (int64_t)b * Tlen * C;
+  float4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t tbeg = (int64_t)blockIdx.x * kWChunk;
+  const int64_t tend = tbeg + kWChunk < Tlen ? tbeg + kWChunk : Tlen;
+  for (int64_t t0 = tbeg; t0 < tend; t0 += WT) {
+    __syncthreads();
+    const int64_t in0 = t0 - pad;
+    for (int r = grp; r < in_rows; r += 16) {
+      const int64_t ti = in0 + r;
+      lds_copy4<T>(s_x + (size_t)r * kCB + cl * 4, xb + ti * C + c, c_ok && ti >= 0 && ti < Tlen);
+    }
+    for (int r = grp; r < WT; r += 16) {
+      const int64_t t = t0 + r;
+      lds_copy4<T>(s_d + (size_t)r * kCB + cl * 4, db + t * C + c, c_ok && t < tend);
+    }
+    __syncthreads();
+    if (active) {
+      const T* xs = s_x + (size_t)(sp * kSub + jg * 8) * kCB + cl * 4;   // frame t, tap j0 -> row t + j0
+      const T* ds = s_d + (size_t)(sp * kSub) * kCB + cl * 4;
+      float4 win[8];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) win[i] = lds_ld4<T>(xs + (size_t)i * kCB);
+      for (int tq = 0; tq < kSub; tq += 8) {
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          win[(tt + 7) & 7] = lds_ld4<T>(xs + (size_t)(tq + tt + 7) * kCB);
+          const float4 dv = lds_ld4<T>(ds + (size_t)(tq + tt) * kCB);
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const float4 xv = win[(tt + jj) & 7];
+            acc[jj].x = fmaf(dv.x, xv.x, acc[jj].x);
+            acc[jj].y = fmaf(dv.y, xv.y, acc[jj].y);
+            acc[jj].z = fmaf(dv.z, xv.z, acc[jj].z);
+            acc[jj].w = fmaf(dv.w, xv.w, acc[jj].w);
+          }
+        }
+      }
+    }
+  }
+  // sum the time splits through LDS: s_red[sp][j][channel]
+  __syncthreads();
+  float* s_red = reinterpret_cast<float*>(smem_raw);
+  if (active) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      *reinterpret_cast<float4*>(s_red + ((size_t)(sp * kpad + jg * 8 + jj)) * kCB + cl * 4) = acc[jj];
+  }
+  __syncthreads();
+  float* out = partials + ((int64_t)b * gridDim.x + blockIdx.x) * C * k;
+  for (int i = threadIdx.x; i < k * kCB; i += 256) {
+    const int ch = i / k, j = i - ch * k;
+    if (c0 + ch < C) {
+      float s = 0.f;
+      for (int q = 0; q < ts; ++q) s += s_red[((size_t)(q * kpad + j)) * kCB + ch];
+      out[(c0 + ch) * k + j] = s;
+    }
+  }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -181,7 +366,19 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
   dim3 grid((unsigned)cdiv(Tout, kTT), (unsigned)cdiv(C, kCB), (unsigned)B);
   const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 2.0 * (double)B * Tout * C * k,
                              (double)B * (Tin + Tout * (addend ? 2 : 1)) * C * dtype_size(dtype));
-  if (dtype == LASR_F32) {
+  if (stride == 1) {
+    const int kpad = (k + 7) & ~7;
+    const size_t sh1 = (size_t)kpad * kCB * sizeof(float) + (size_t)(kTT + kpad + 8) * kCB * dtype_size(dtype);
+    if (dtype == LASR_F32) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(dwconv_s1_kernel<float>, grid, dim3(256), sh1, as_stream(stream), (const float*)x, w, (const float*)addend,
+                         (float*)y, Tin, C, k, flip);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(dwconv_s1_kernel<bf16_t>, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, w,
+                         (const bf16_t*)addend, (bf16_t*)y, Tin, C, k, flip);
+    }
+  } else if (dtype == LASR_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(256), shmem, as_stream(stream), (const float*)x, w,
                        (const float*)addend, (float*)y, Tin, Tout, C, k, stride, flip);
@@ -212,7 +409,24 @@ extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int d
   const size_t shmem = ((size_t)in_rows + kWT) * kCB * sizeof(float);
   dim3 grid((unsigned)n_chunks, (unsigned)cdiv(C, kCB), (unsigned)B);
   float* partials = reinterpret_cast<float*>(workspace);
-  if (dtype == LASR_F32) {
+  if (stride == 1) {
+    const int ng = (k + 7) >> 3;
+    int ts = 16 / ng;
+    if (ts > 3) ts = 3;
+    const int WT = kSub * ts, kpad = ng * 8;
+    size_t sh1 = (size_t)(WT + kpad + 8 + WT) * kCB * dtype_size(dtype);
+    const size_t red = (size_t)ts * kpad * kCB * sizeof(float);
+    if (red > sh1) sh1 = red;
+    if (dtype == LASR_F32) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_s1_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(dwconv_wgrad_s1_kernel<float>, grid, dim3(256), sh1, as_stream(stream), (const float*)x, (const float*)dy,
+                         partials, Tin, C, k, ts);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_s1_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(dwconv_wgrad_s1_kernel<bf16_t>, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, (const bf16_t*)dy,
+                         partials, Tin, C, k, ts);
+    }
+  } else if (dtype == LASR_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, grid, dim3(256), shmem, as_stream(stream), (const float*)x, (const float*)dy,
                        partials, Tin, Tout, C, k, stride);
@@ -223,8 +437,5 @@ extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int d
   }
   LASR_LAUNCH_CHECK("dwconv_wgrad_kernel");
   const int64_t n = C * k;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), partials,
-                     (int)(B * n_chunks), n, dw);
-  LASR_LAUNCH_CHECK("sum_partials_kernel");
-  return 0;
+  return launch_reduce_partials(partials, (int)(B * n_chunks), n, dw, n, nullptr, as_stream(stream));
 }

@@ -56,6 +56,9 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ CTC ------------------------
+// Accurate expf/logf: the gradient is exp(alpha + beta - ll - lp) of O(1000)-magnitude log values and
+// the network's backward map amplifies relative noise in it ~100x, so the fast v_exp/v_log forms
+// (1e-6 per step, 1e-4 after 500 steps) are not good enough for the f32 parity mode.
 __device__ __forceinline__ float lse2(float a, float b) {
   const float m = fmaxf(a, b);
   if (m == kNegInf) return kNegInf;
@@ -130,10 +133,19 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
     a[i] = (start && s >= 0 && s < SS) ? em[i] : kNegInf;
     out[(int64_t)t_first * SP + s] = a[i];
   }
+  // emissions of the next step are fetched one step ahead of their use
+  float em_next[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    em_next[i] = (Tb > 1 && lane * NS + i < SS) ? lp[(int64_t)(t_first + dt) * C + cls[i]] : kNegInf;
   for (int step = 1; step < Tb; ++step) {
     const int t = t_first + dt * step;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) em[i] = (lane * NS + i < SS) ? lp[(int64_t)t * C + cls[i]] : kNegInf;
+    for (int i = 0; i < NS; ++i) em[i] = em_next[i];
+    if (step + 1 < Tb) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) em_next[i] = (lane * NS + i < SS) ? lp[(int64_t)(t + dt) * C + cls[i]] : kNegInf;
+    }
     float n[NS];
     if (!is_beta) {
       float p1 = __shfl_up(a[NS - 1], 1, 64);

@@ -297,8 +297,7 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
     LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
   }
   if (stats) {
-    hipLaunchKernelGGL(gemm_stats_reduce_kernel, dim3((unsigned)cdiv(2 * N, 256)), dim3(256), 0, st, g.stat_partials, grid_m, 2 * N, stats);
-    LASR_LAUNCH_CHECK("gemm_stats_reduce_kernel");
+    LASR_TRY(launch_reduce_partials(g.stat_partials, grid_m, 2 * N, stats, 2 * N, nullptr, st));
   }
   return 0;
 }

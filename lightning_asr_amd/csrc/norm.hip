@@ -70,39 +70,50 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
   if (saved) { saved[c] = mean; saved[C + c] = rstd; }
 }
 
-// ------------------------------------------------------------------ BN apply + add + act -----
-// vectorised by 4 channels; C % 4 == 0.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
-                                                         const T* __restrict__ y2, const float* __restrict__ coef2,
-                                                         const float* __restrict__ se, T* __restrict__ out,
-                                                         int64_t rows, int64_t Tt, int64_t C, int act) {
-  const int64_t c4n = C >> 2;
-  const int64_t total = rows * c4n;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / c4n;
-    const int64_t c = (i - row * c4n) << 2;
-    float v[4], r[4], o[4];
-    Elem<T>::ld4(y + row * C + c, v);
-    const float4 a = *reinterpret_cast<const float4*>(coef + c);
-    const float4 bb = *reinterpret_cast<const float4*>(coef + C + c);
-    o[0] = fmaf(v[0], a.x, bb.x); o[1] = fmaf(v[1], a.y, bb.y); o[2] = fmaf(v[2], a.z, bb.z); o[3] = fmaf(v[3], a.w, bb.w);
-    if (se) {
-      const float4 s = *reinterpret_cast<const float4*>(se + (row / Tt) * C + c);
-      o[0] *= s.x; o[1] *= s.y; o[2] *= s.z; o[3] *= s.w;
+// ------------------------------------------------------------------ fixed-order partial sums ----
+// block = 32 columns x 8 partial lanes; each lane strides the partial rows with 4 independent sums.
+// Accumulation is f64: these sums are BatchNorm statistics and gradient reductions, and the
+// network's backward map amplifies relative noise in them by ~1e2-1e3 (measured), so f32 sums
+// of a few hundred partials cost visible gradient parity.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int n_part, int64_t ncols,
+                                                              float* __restrict__ out0, int64_t split, float* __restrict__ out1) {
+  __shared__ double s_acc[8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 32 + cl;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (c < ncols) {
+    int p = pl;
+    for (; p + 24 < n_part; p += 32) {
+      a0 += (double)partials[(int64_t)p * ncols + c];
+      a1 += (double)partials[(int64_t)(p + 8) * ncols + c];
+      a2 += (double)partials[(int64_t)(p + 16) * ncols + c];
+      a3 += (double)partials[(int64_t)(p + 24) * ncols + c];
     }
-    if (y2) {
-      Elem<T>::ld4(y2 + row * C + c, r);
-      const float4 a2 = *reinterpret_cast<const float4*>(coef2 + c);
-      const float4 b2 = *reinterpret_cast<const float4*>(coef2 + C + c);
-      o[0] += fmaf(r[0], a2.x, b2.x); o[1] += fmaf(r[1], a2.y, b2.y);
-      o[2] += fmaf(r[2], a2.z, b2.z); o[3] += fmaf(r[3], a2.w, b2.w);
-    }
+    for (; p < n_part; p += 8) a0 += (double)partials[(int64_t)p * ncols + c];
+  }
+  s_acc[pl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (pl == 0 && c < ncols) {
+    double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = act_fwd(o[j], act);
-    Elem<T>::st4(out + row * C + c, o);
+    for (int i = 0; i < 8; ++i) s += s_acc[i][cl];
+    if (c < split) out0[c] = (float)s;
+    else if (out1) out1[c - split] = (float)s;
   }
 }
+
+int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, float* out0, int64_t split, float* out1,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(ncols, 32)), dim3(256), 0, st, partials, n_part, ncols, out0, split, out1);
+  LASR_LAUNCH_CHECK("reduce_partials_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------ BN apply + add + act -----
+// Thread = one 16-byte column vector (4 f32 / 8 bf16 channels) walking a slab of rows, so the
+// per-channel coefficients are fetched once and every access is a full 16 B per lane.
+static constexpr int kFwdRows = 32;   // rows per workgroup, forward / backward-apply
+static constexpr int kRowsPerBlock = 64;  // rows per workgroup, backward statistics
 
 // d(act)/d(pre-activation)
 __device__ __forceinline__ float act_grad(float p, int act) {
@@ -114,26 +125,60 @@ __device__ __forceinline__ float act_grad(float p, int act) {
   return 1.f;
 }
 
-// Shared per-element backward math: returns d1 (grad into branch-1 BN output), d2 (branch 2), yhat1, yhat2
-struct BwdElem { float d1, d2, h1, h2; };
-__device__ __forceinline__ BwdElem bwd_elem(float dout, float y1, float a1, float b1, float mu1, float rs1, float se,
-                                            float seg, bool has2, float y2, float a2, float b2, float mu2, float rs2,
-                                            int act) {
-  const float z1 = fmaf(y1, a1, b1) * se;
-  const float z2 = has2 ? fmaf(y2, a2, b2) : 0.f;
-  const float d = dout * act_grad(z1 + z2, act);
-  BwdElem e;
-  e.d1 = fmaf(d, se, seg);
-  e.d2 = d;
-  e.h1 = (y1 - mu1) * rs1;
-  e.h2 = has2 ? (y2 - mu2) * rs2 : 0.f;
-  return e;
+struct ColGeom { int cv, col_threads, row_lanes, cl, rl; };
+template <int V>
+__device__ __forceinline__ ColGeom col_geom(int64_t C) {
+  ColGeom g;
+  g.cv = (int)(C / V);
+  g.col_threads = g.cv < 256 ? g.cv : 256;
+  g.row_lanes = 256 / g.col_threads;
+  g.cl = threadIdx.x % g.col_threads;
+  g.rl = threadIdx.x / g.col_threads;
+  return g;
 }
 
-static constexpr int kRowsPerBlock = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
+                                                         const T* __restrict__ y2, const float* __restrict__ coef2,
+                                                         const float* __restrict__ se, T* __restrict__ out,
+                                                         int64_t rows, int64_t Tt, int64_t C, int act) {
+  constexpr int V = Vec<T>::kN;
+  const ColGeom g = col_geom<V>(C);
+  if (g.rl >= g.row_lanes) return;
+  const int64_t r0 = (int64_t)blockIdx.x * kFwdRows;
+  const int64_t r1 = r0 + kFwdRows < rows ? r0 + kFwdRows : rows;
+  for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
+    const int64_t c = (int64_t)cvi * V;
+    float a[V], b[V], a2[V], b2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      a[j] = coef[c + j]; b[j] = coef[C + c + j];
+      a2[j] = y2 ? coef2[c + j] : 0.f; b2[j] = y2 ? coef2[C + c + j] : 0.f;
+    }
+    for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
+      float v[V], o[V];
+      Vec<T>::load(y + r * C + c, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = fmaf(v[j], a[j], b[j]);
+      if (se) {
+        const float* sp = se + (r / Tt) * C + c;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] *= sp[j];
+      }
+      if (y2) {
+        float w[V];
+        Vec<T>::load(y2 + r * C + c, w);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] += fmaf(w[j], a2[j], b2[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = act_fwd(o[j], act);
+      Vec<T>::store(out + r * C + c, o);
+    }
+  }
+}
 
-// pass 1: per-block partial sums -> partials[blk][4][C]  (s1, s2, s1', s2')
-// block = 256 threads: threads split as (C/4 column-vectors) x (row lanes)
+// pass 1: per-block partial sums -> partials[blk][4][C]  (s1, s2 of branch 1; s1', s2' of branch 2)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const float* __restrict__ coef, const float* __restrict__ saved,
@@ -142,65 +187,62 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
                                                            const float* __restrict__ seg, float* __restrict__ partials,
                                                            int64_t rows, int64_t Tt, int64_t C, int act) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [row_lanes][4][C]
-  const int c4n = (int)(C >> 2);
-  const int col_threads = c4n < 256 ? c4n : 256;
-  const int row_lanes = 256 / col_threads;
-  const int cl = threadIdx.x % col_threads, rl = threadIdx.x / col_threads;
+  constexpr int V = Vec<T>::kN;
+  const ColGeom g = col_geom<V>(C);
   const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
   const int64_t r1 = r0 + kRowsPerBlock < rows ? r0 + kRowsPerBlock : rows;
   const bool has2 = y2 != nullptr;
-  for (int cv = cl; cv < c4n; cv += col_threads) {
-    const int c = cv << 2;
-    float a1[4], b1[4], m1[4], q1[4], a2[4] = {0, 0, 0, 0}, b2[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
+  if (g.rl < g.row_lanes) {
+    for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
+      const int64_t c = (int64_t)cvi * V;
+      float a1[V], b1[V], m1[V], q1[V], a2[V], b2[V], m2[V], q2[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      a1[j] = coef[c + j]; b1[j] = coef[C + c + j]; m1[j] = saved[c + j]; q1[j] = saved[C + c + j];
-      if (has2) { a2[j] = coef2[c + j]; b2[j] = coef2[C + c + j]; m2[j] = saved2[c + j]; q2[j] = saved2[C + c + j]; }
-    }
-    float acc[4][4] = {};
-    if (rl < row_lanes) {
-      for (int64_t r = r0 + rl; r < r1; r += row_lanes) {
-        float dv[4], yv[4], rv[4] = {0, 0, 0, 0}, sv[4] = {1, 1, 1, 1}, gv[4] = {0, 0, 0, 0};
-        Elem<T>::ld4(dout + r * C + c, dv);
-        Elem<T>::ld4(y + r * C + c, yv);
-        if (has2) Elem<T>::ld4(y2 + r * C + c, rv);
-        if (se) {
-          const int64_t b = r / Tt;
+      for (int j = 0; j < V; ++j) {
+        a1[j] = coef[c + j]; b1[j] = coef[C + c + j]; m1[j] = saved[c + j]; q1[j] = saved[C + c + j];
+        a2[j] = has2 ? coef2[c + j] : 0.f; b2[j] = has2 ? coef2[C + c + j] : 0.f;
+        m2[j] = has2 ? saved2[c + j] : 0.f; q2[j] = has2 ? saved2[C + c + j] : 0.f;
+      }
+      float acc[4][V];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { sv[j] = se[b * C + c + j]; gv[j] = seg ? seg[b * C + c + j] : 0.f; }
-        }
+      for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          BwdElem e = bwd_elem(dv[j], yv[j], a1[j], b1[j], m1[j], q1[j], sv[j], gv[j], has2, rv[j], a2[j], b2[j], m2[j], q2[j], act);
-          acc[0][j] += e.d1; acc[1][j] = fmaf(e.d1, e.h1, acc[1][j]);
-          acc[2][j] += e.d2; acc[3][j] = fmaf(e.d2, e.h2, acc[3][j]);
+        for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
+      for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
+        float dv[V], yv[V], rv[V];
+        Vec<T>::load(dout + r * C + c, dv);
+        Vec<T>::load(y + r * C + c, yv);
+        if (has2) Vec<T>::load(y2 + r * C + c, rv);
+        const float* sp = se ? se + (r / Tt) * C + c : nullptr;
+        const float* gp = (se && seg) ? seg + (r / Tt) * C + c : nullptr;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float sej = sp ? sp[j] : 1.f;
+          const float z = fmaf(yv[j], a1[j], b1[j]) * sej + (has2 ? fmaf(rv[j], a2[j], b2[j]) : 0.f);
+          const float d = dv[j] * act_grad(z, act);
+          const float d1 = fmaf(d, sej, gp ? gp[j] : 0.f);
+          acc[0][j] += d1;
+          acc[1][j] = fmaf(d1, (yv[j] - m1[j]) * q1[j], acc[1][j]);
+          if (has2) {
+            acc[2][j] += d;
+            acc[3][j] = fmaf(d, (rv[j] - m2[j]) * q2[j], acc[3][j]);
+          }
         }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s_part[((int64_t)rl * 4 + k) * C + c + j] = acc[k][j];
+        for (int j = 0; j < V; ++j) s_part[((int64_t)g.rl * 4 + k) * C + c + j] = acc[k][j];
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * C; i += 256) {
     float s = 0.f;
-    for (int l = 0; l < row_lanes; ++l) s += s_part[(int64_t)l * 4 * C + i];
+    for (int l = 0; l < g.row_lanes; ++l) s += s_part[(int64_t)l * 4 * C + i];
     partials[(int64_t)blockIdx.x * 4 * C + i] = s;
   }
 }
 
-// sums[k][c] = sum over blocks of partials[blk][k][c]; k<2 -> sums, k>=2 -> sums2
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ partials, int nblk, int64_t C,
-                                                            float* __restrict__ sums, float* __restrict__ sums2) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= 4 * C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partials[(int64_t)b * 4 * C + i];
-  if (i < 2 * C) sums[i] = (float)s;
-  else if (sums2) sums2[i - 2 * C] = (float)s;
-}
-
+// pass 2: dy = gamma*rstd*(d1 - s1/n - yhat*s2/n), rows past the utterance length zeroed on branch 1
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const float* __restrict__ coef, const float* __restrict__ saved,
@@ -209,50 +251,58 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma2, const float* __restrict__ se,
                                                            const float* __restrict__ seg, const float* __restrict__ sums,
                                                            const float* __restrict__ sums2, const int32_t* __restrict__ row_lens,
-                                                           T* __restrict__ dy, T* __restrict__ dy2, int64_t rows, int64_t Tt,
-                                                           int64_t C, int act) {
-  const int64_t c4n = C >> 2;
-  const int64_t total = rows * c4n;
+                                                           T* __restrict__ dy, T* __restrict__ dy2, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma2,
+                                                           float* __restrict__ dbeta2, int64_t rows, int64_t Tt, int64_t C, int act) {
+  constexpr int V = Vec<T>::kN;
+  const ColGeom g = col_geom<V>(C);
+  if (g.rl >= g.row_lanes) return;
+  const int64_t r0 = (int64_t)blockIdx.x * kFwdRows;
+  const int64_t r1 = r0 + kFwdRows < rows ? r0 + kFwdRows : rows;
   const float inv_n = 1.0f / (float)rows;
   const bool has2 = y2 != nullptr;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / c4n;
-    const int64_t c = (i - row * c4n) << 2;
-    const int64_t b = row / Tt;
-    const bool masked = row_lens && (row - b * Tt) >= row_lens[b];
-    float dv[4], yv[4], rv[4] = {0, 0, 0, 0}, o1[4], o2[4];
-    Elem<T>::ld4(dout + row * C + c, dv);
-    Elem<T>::ld4(y + row * C + c, yv);
-    if (has2) Elem<T>::ld4(y2 + row * C + c, rv);
+  for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
+    const int64_t c = (int64_t)cvi * V;
+    float a1[V], b1[V], m1[V], q1[V], g1[V], u1[V], w1[V], a2[V], b2[V], m2[V], q2[V], g2[V], u2[V], w2[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float sej = se ? se[b * C + c + j] : 1.f;
-      const float sgj = (se && seg) ? seg[b * C + c + j] : 0.f;
-      BwdElem e = bwd_elem(dv[j], yv[j], coef[c + j], coef[C + c + j], saved[c + j], saved[C + c + j], sej, sgj, has2,
-                           rv[j], has2 ? coef2[c + j] : 0.f, has2 ? coef2[C + c + j] : 0.f, has2 ? saved2[c + j] : 0.f,
-                           has2 ? saved2[C + c + j] : 0.f, act);
-      const float g1 = gamma[c + j] * saved[C + c + j];
-      o1[j] = masked ? 0.f : g1 * (e.d1 - sums[c + j] * inv_n - e.h1 * sums[C + c + j] * inv_n);
-      if (has2) {
-        const float g2 = gamma2[c + j] * saved2[C + c + j];
-        o2[j] = g2 * (e.d2 - sums2[c + j] * inv_n - e.h2 * sums2[C + c + j] * inv_n);
+    for (int j = 0; j < V; ++j) {
+      a1[j] = coef[c + j]; b1[j] = coef[C + c + j]; m1[j] = saved[c + j]; q1[j] = saved[C + c + j];
+      g1[j] = gamma[c + j] * q1[j]; u1[j] = sums[c + j] * inv_n; w1[j] = sums[C + c + j] * inv_n;
+      a2[j] = has2 ? coef2[c + j] : 0.f; b2[j] = has2 ? coef2[C + c + j] : 0.f;
+      m2[j] = has2 ? saved2[c + j] : 0.f; q2[j] = has2 ? saved2[C + c + j] : 0.f;
+      g2[j] = has2 ? gamma2[c + j] * q2[j] : 0.f; u2[j] = has2 ? sums2[c + j] * inv_n : 0.f; w2[j] = has2 ? sums2[C + c + j] * inv_n : 0.f;
+    }
+    if (blockIdx.x == 0 && g.rl == 0) {  // BatchNorm parameter gradients: dbeta = s1, dgamma = s2
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        if (dbeta) dbeta[c + j] = sums[c + j];
+        if (dgamma) dgamma[c + j] = sums[C + c + j];
+        if (has2 && dbeta2) dbeta2[c + j] = sums2[c + j];
+        if (has2 && dgamma2) dgamma2[c + j] = sums2[C + c + j];
       }
     }
-    Elem<T>::st4(dy + row * C + c, o1);
-    if (has2) Elem<T>::st4(dy2 + row * C + c, o2);
+    for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
+      const int64_t b = r / Tt;
+      const bool masked = row_lens && (r - b * Tt) >= row_lens[b];
+      float dv[V], yv[V], rv[V], o1[V], o2[V];
+      Vec<T>::load(dout + r * C + c, dv);
+      Vec<T>::load(y + r * C + c, yv);
+      if (has2) Vec<T>::load(y2 + r * C + c, rv);
+      const float* sp = se ? se + b * C + c : nullptr;
+      const float* gp = (se && seg) ? seg + b * C + c : nullptr;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float sej = sp ? sp[j] : 1.f;
+        const float z = fmaf(yv[j], a1[j], b1[j]) * sej + (has2 ? fmaf(rv[j], a2[j], b2[j]) : 0.f);
+        const float d = dv[j] * act_grad(z, act);
+        const float d1 = fmaf(d, sej, gp ? gp[j] : 0.f);
+        o1[j] = masked ? 0.f : g1[j] * (d1 - u1[j] - (yv[j] - m1[j]) * q1[j] * w1[j]);
+        o2[j] = g2[j] * (d - u2[j] - (rv[j] - m2[j]) * q2[j] * w2[j]);
+      }
+      Vec<T>::store(dy + r * C + c, o1);
+      if (has2) Vec<T>::store(dy2 + r * C + c, o2);
+    }
   }
-}
-
-__global__ void bn_param_grad_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t C) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  if (dbeta) dbeta[c] = sums[c];
-  if (dgamma) dgamma[c] = sums[C + c];
-}
-
-static inline int ew_grid(int64_t total) {
-  int64_t g = cdiv(total, 256);
-  return (int)(g > 256 * 8 ? 256 * 8 : (g < 1 ? 1 : g));
 }
 
 }  // namespace lasr
@@ -298,13 +348,20 @@ extern "C" int lasr_bn_finalize(const float* stats, const float* gamma, const fl
   return 0;
 }
 
+static int check_bn_shape(const char* who, int dtype, int64_t B, int64_t T_, int64_t C) {
+  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "%s: bad dtype", who);
+  const int v = dtype == LASR_F32 ? 4 : 8;
+  LASR_CHECK_SHAPE(C % v == 0 && C <= 4096 && B > 0 && T_ > 0, "%s: C=%lld must be a multiple of %d (16-byte channel vectors)", who,
+                   (long long)C, v);
+  return 0;
+}
+
 extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2, const float* coef2, const float* se_scale,
                                void* out, int dtype, int64_t B, int64_t T_, int64_t C, int act, void* stream) {
   LASR_CHECK_ARG(y && coef && out && (!y2 || coef2), "lasr_bn_act_fwd: null pointer");
-  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_bn_act_fwd: bad dtype");
-  LASR_CHECK_SHAPE(C % 4 == 0 && B > 0 && T_ > 0, "lasr_bn_act_fwd: C=%lld must be a multiple of 4", (long long)C);
+  LASR_TRY(check_bn_shape("lasr_bn_act_fwd", dtype, B, T_, C));
   const int64_t rows = B * T_;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, as_stream(stream),
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)cdiv(rows, kFwdRows)), dim3(256), 0, as_stream(stream),
                                            (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, rows, T_, C, act));
   LASR_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
@@ -320,13 +377,12 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
                                      void* workspace, size_t workspace_bytes, void* stream) {
   LASR_CHECK_ARG(dout && y && coef && saved && sums && workspace, "lasr_bn_act_bwd_stats: null pointer");
   LASR_CHECK_ARG(!y2 || (coef2 && saved2 && sums2), "lasr_bn_act_bwd_stats: branch-2 pointers");
-  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_bn_act_bwd_stats: bad dtype");
-  LASR_CHECK_SHAPE(C % 4 == 0 && C <= 4096 && B > 0 && T_ > 0, "lasr_bn_act_bwd_stats: C=%lld", (long long)C);
+  LASR_TRY(check_bn_shape("lasr_bn_act_bwd_stats", dtype, B, T_, C));
   const int64_t rows = B * T_;
   const int nblk = (int)cdiv(rows, kRowsPerBlock);
   if (workspace_bytes < lasr_bn_bwd_workspace_bytes(B, T_, C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_stats: workspace");
-  const int c4n = (int)(C / 4);
-  const int col_threads = c4n < 256 ? c4n : 256;
+  const int cv = (int)(C / (dtype == LASR_F32 ? 4 : 8));
+  const int col_threads = cv < 256 ? cv : 256;
   const int row_lanes = 256 / col_threads;
   const size_t shmem = (size_t)row_lanes * 4 * C * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_stats: C too large for LDS staging");
@@ -335,10 +391,7 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
                                            (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad, partials,
                                            rows, T_, C, act));
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)cdiv(4 * C, 256)), dim3(256), 0, as_stream(stream), partials, nblk, C,
-                     sums, sums2);
-  LASR_LAUNCH_CHECK("bn_bwd_reduce_kernel");
-  return 0;
+  return launch_reduce_partials(partials, nblk, 4 * C, sums, 2 * C, sums2, as_stream(stream));
 }
 
 extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const float* coef, const float* saved,
@@ -349,21 +402,13 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
                                      int act, void* stream) {
   LASR_CHECK_ARG(dout && y && coef && saved && gamma && sums && dy, "lasr_bn_act_bwd_apply: null pointer");
   LASR_CHECK_ARG(!y2 || (coef2 && saved2 && gamma2 && sums2 && dy2), "lasr_bn_act_bwd_apply: branch-2 pointers");
-  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_bn_act_bwd_apply: bad dtype");
-  LASR_CHECK_SHAPE(C % 4 == 0 && B > 0 && T_ > 0, "lasr_bn_act_bwd_apply: C=%lld", (long long)C);
+  LASR_TRY(check_bn_shape("lasr_bn_act_bwd_apply", dtype, B, T_, C));
   const int64_t rows = B * T_;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, as_stream(stream),
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)cdiv(rows, kFwdRows)), dim3(256), 0, as_stream(stream),
                                            (const T*)dout, (const T*)y, coef, saved, gamma, (const T*)y2, coef2, saved2, gamma2,
-                                           se_scale, se_grad, sums, sums2, row_lens, (T*)dy, (T*)dy2, rows, T_, C, act));
+                                           se_scale, se_grad, sums, sums2, row_lens, (T*)dy, (T*)dy2, dgamma, dbeta, dgamma2, dbeta2,
+                                           rows, T_, C, act));
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
-  if (dgamma || dbeta) {
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream), sums, dgamma, dbeta, C);
-    LASR_LAUNCH_CHECK("bn_param_grad_kernel");
-  }
-  if (y2 && (dgamma2 || dbeta2)) {
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream), sums2, dgamma2, dbeta2, C);
-    LASR_LAUNCH_CHECK("bn_param_grad_kernel");
-  }
   return 0;
 }
 

@@ -5,30 +5,48 @@
 
 namespace lasr {
 
-// grid = n_tensors, block 1024: v_i <- first ? ||g||^2 : b2 v + (1-b2)||g||^2 ; denom_i = sqrt(v_i)+eps
-__global__ __launch_bounds__(1024) void novograd_norm_kernel(const float* __restrict__ grads, const int64_t* __restrict__ offsets,
-                                                             float* __restrict__ exp_avg_sq, float* __restrict__ denom,
-                                                             float beta2, float eps, float grad_scale) {
-  __shared__ double s_red[16];
-  const int i = blockIdx.x;
-  const int64_t beg = offsets[i], end = offsets[i + 1];
-  double acc = 0.0;
-  for (int64_t e = beg + threadIdx.x; e < end; e += 1024) {
-    const float g = grads[e] * grad_scale;
-    acc += (double)g * (double)g;
+// Stage 1: every workgroup owns a 16K-element slice of the flat gradient, walks the tensor segments
+// that intersect it and adds each segment's sum of squares to norm2[tensor] (f64 atomics: a handful
+// per workgroup; f64 keeps the result independent of arrival order to well below f32 resolution).
+static constexpr int kNormChunk = 16384;
+__global__ __launch_bounds__(256) void novograd_norm_kernel(const float* __restrict__ grads, const int64_t* __restrict__ offsets,
+                                                            int n_tensors, int64_t n, double* __restrict__ norm2, float grad_scale) {
+  __shared__ double s_red[4];
+  const int64_t beg = (int64_t)blockIdx.x * kNormChunk;
+  const int64_t end = beg + kNormChunk < n ? beg + kNormChunk : n;
+  int lo = 0, hi = n_tensors;  // offsets[lo] <= beg < offsets[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (offsets[mid] <= beg) lo = mid; else hi = mid;
   }
-  acc = wave_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int w = 0; w < 16; ++w) s += s_red[w];
-    const float norm = (float)s;
-    float v = exp_avg_sq[i];
-    v = (v == 0.f) ? norm : beta2 * v + (1.f - beta2) * norm;  // "if exp_avg_sq == 0: copy" novograd.py:115
-    exp_avg_sq[i] = v;
-    denom[i] = sqrtf(v) + eps;
+  int64_t seg = beg;
+  for (int t = lo; t < n_tensors && seg < end; ++t) {
+    const int64_t tend = offsets[t + 1] < end ? offsets[t + 1] : end;
+    double acc = 0.0;
+    for (int64_t e = seg + threadIdx.x; e < tend; e += 256) {
+      const float g = grads[e] * grad_scale;
+      acc += (double)g * (double)g;
+    }
+    acc = wave_sum_d(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && tend > seg) atomicAdd(&norm2[t], (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+    seg = tend;
   }
+}
+
+// Stage 2: v_i <- first ? ||g||^2 : b2 v + (1-b2)||g||^2 ; denom_i = sqrt(v_i)+eps ; norm2 re-zeroed
+__global__ __launch_bounds__(256) void novograd_moment_kernel(double* __restrict__ norm2, float* __restrict__ exp_avg_sq,
+                                                              float* __restrict__ denom, int n_tensors, float beta2, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_tensors) return;
+  const float norm = (float)norm2[i];
+  norm2[i] = 0.0;
+  float v = exp_avg_sq[i];
+  v = (v == 0.f) ? norm : beta2 * v + (1.f - beta2) * norm;  // "if exp_avg_sq == 0: copy" novograd.py:115
+  exp_avg_sq[i] = v;
+  denom[i] = sqrtf(v) + eps;
 }
 
 __global__ __launch_bounds__(256) void novograd_update_kernel(float* __restrict__ params, const float* __restrict__ grads,
@@ -64,7 +82,7 @@ using namespace lasr;
 
 extern "C" size_t lasr_novograd_workspace_bytes(int64_t n_tensors, int64_t n_elems) {
   (void)n_elems;
-  return align_up((size_t)n_tensors * sizeof(float), 256);
+  return align_up((size_t)n_tensors * sizeof(float), 256) + align_up((size_t)n_tensors * sizeof(double), 256);
 }
 
 extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* offsets,
@@ -74,9 +92,16 @@ extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_
   LASR_CHECK_SHAPE(n_tensors > 0 && n_tensors < (1 << 20) && n_elems > 0, "lasr_novograd_step: n_tensors=%lld", (long long)n_tensors);
   if (workspace_bytes < lasr_novograd_workspace_bytes(n_tensors, n_elems)) return fail(LASR_E_WORKSPACE, "lasr_novograd_step: workspace");
   float* denom = reinterpret_cast<float*>(workspace);
+  double* norm2 = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)n_tensors * sizeof(float), 256));
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(novograd_norm_kernel, dim3((unsigned)n_tensors), dim3(1024), 0, st, grads, offsets, exp_avg_sq, denom, beta2, eps, grad_scale);
+  hipError_t me = hipMemsetAsync(norm2, 0, (size_t)n_tensors * sizeof(double), st);
+  if (me != hipSuccess) return hip_fail(me, "lasr_novograd_step memset");
+  hipLaunchKernelGGL(novograd_norm_kernel, dim3((unsigned)cdiv(n_elems, kNormChunk)), dim3(256), 0, st, grads, offsets, (int)n_tensors,
+                     n_elems, norm2, grad_scale);
   LASR_LAUNCH_CHECK("novograd_norm_kernel");
+  hipLaunchKernelGGL(novograd_moment_kernel, dim3((unsigned)cdiv(n_tensors, 256)), dim3(256), 0, st, norm2, exp_avg_sq, denom,
+                     (int)n_tensors, beta2, eps);
+  LASR_LAUNCH_CHECK("novograd_moment_kernel");
   int64_t blocks = cdiv(n_elems, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(novograd_update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, offsets, (int)n_tensors,
