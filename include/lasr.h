@@ -184,6 +184,10 @@ enum { LASR_PROF_GEMM = 0, LASR_PROF_DWCONV = 1, LASR_PROF_BN = 2, LASR_PROF_OTH
 int lasr_prof_enable(int on);
 int lasr_prof_collect(double* ms, double* flops, double* bytes, int64_t* count);
 
+/* Levenshtein distance between two token-id sequences, on the HOST (plain C++, no device work):
+ * replaces editdistance.eval at utils/asr_metrics.py:54,220.  Returns -1 on bad arguments.       */
+int64_t lasr_edit_distance(const int32_t* a, int64_t na, const int32_t* b, int64_t nb);
+
 /* small helpers used by the plan and by the host */
 int lasr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "lasr_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "lasr_colsum_f32": (_i32, [_p, _p, _i64, _i64, _p, _sz, _p]),
     "lasr_scale_sum_f32": (_i32, [_p, _i64, _f32, _p, _p]),
+    "lasr_edit_distance": (_i64, [_p, _i64, _p, _i64]),
     "lasr_prof_enable": (_i32, [_i32]),
     "lasr_prof_collect": (_i32, [_p, _p, _p, _p]),
     "lasr_model_create": (_i32, [C.POINTER(ModelConfig), C.POINTER(_p)]),

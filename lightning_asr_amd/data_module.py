@@ -1,0 +1,208 @@
+"""Data contract of the reference's data_module.py with the feature front-end moved to the GPU.
+
+Same public names and arguments: ``MyAudioDataset``, ``AudioParser``, ``LibriDataModule`` (manifest =
+JSON lines ``{"audio_filepath","duration","text"}``, scripts/get_libri.py:135).  What differs, by design:
+DataLoader workers only decode PCM; dither, pre-emphasis, STFT, mel, dB, SpecAugment zeros, per-utterance
+normalisation and pad-to-longest collate run as ONE batched HIP call (csrc/mel.hip) in
+``on_after_batch_transfer``, which hands ``training_step`` the reference's 5-tuple
+``(inputs (B,1,64,Tmax), targets, input_percentages, target_sizes, paths)`` (data_module.py:248)."""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import random
+import wave as _wave
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from . import ops
+from .lightning_compat import LightningDataModule
+
+
+def load_wav(path_or_file) -> torch.Tensor:
+    """16-bit PCM wav -> (1, L) f32 in [-1, 1) (what torchaudio.load returns, data_module.py:153)."""
+    with _wave.open(path_or_file, "rb") as w:
+        if w.getsampwidth() != 2:
+            raise ValueError("only 16-bit PCM wav is supported")
+        n, ch = w.getnframes(), w.getnchannels()
+        pcm = np.frombuffer(w.readframes(n), dtype="<i2").reshape(-1, ch).T
+    return torch.from_numpy(pcm[:1].astype(np.float32) / 32768.0)
+
+
+class AudioParser:
+    """``parse_audio(path, mask) -> (1, 64, T)`` (data_module.py:150-174), computed on the GPU."""
+
+    def __init__(self, win_len=0.02, sr=16000, device="cuda"):
+        if int(win_len * sr) != 320 or sr != 16000:
+            raise NotImplementedError("the HIP front-end is built for win_len=0.02, sr=16000 (data_module.py:59)")
+        self.win_len, self.sr = win_len, sr
+        self.rand = random.Random()
+        self.device = torch.device(device)
+
+    # -- the two random pieces of the training-time chain, drawn on the host like the reference ----
+    def sub_secquence(self, x: torch.Tensor, weight: float = 0.1) -> torch.Tensor:
+        """Bug-compatible: the slice END is target_length, not location+target_length (:138-148)."""
+        length = x.shape[1]
+        target_length = int(length * np.random.uniform(weight, 1))
+        location = int(np.random.uniform(0, length - target_length))
+        return x[:, location:target_length]
+
+    def draw_spec_augment(self, n_time: int, freq_mask: Union[int, float] = 27, time_mask: Union[int, float] = 0.07):
+        """(rect_x, w_x, rect_y, w_y) with the draw order of spec_augment (:97-122)."""
+        if isinstance(freq_mask, float):
+            freq_mask = int(64 * freq_mask)
+        if isinstance(time_mask, float):
+            time_mask = int(n_time * time_mask)
+        w_x = int(self.rand.uniform(0, freq_mask))
+        w_y = int(self.rand.uniform(0, time_mask))
+        rect_x = int(self.rand.uniform(0, 64 - w_x))
+        rect_y = int(self.rand.uniform(0, n_time - w_y))
+        return rect_x, w_x, rect_y, w_y
+
+    def parse_audio(self, audio_path, mask=False) -> torch.Tensor:
+        if isinstance(audio_path, str) and not os.path.exists(path=audio_path):
+            raise Exception("音频路径不存在 " + audio_path)
+        y = load_wav(audio_path)
+        if mask:
+            y = self.sub_secquence(y, weight=0.98)
+        return self.features([y[0]], mask)[0]
+
+    def features(self, waves: Sequence[torch.Tensor], mask: bool, dither: bool = True):
+        """list of (L_i,) f32 waves -> (inputs (B,1,64,Tmax) f32 with its channels-last twin attached,
+        input_percentages (B,)) on the GPU; frames past each utterance are zero."""
+        B = len(waves)
+        L = max(int(w.numel()) for w in waves)
+        host = torch.zeros(B, L)
+        lens = torch.empty(B, dtype=torch.int32)
+        for i, w in enumerate(waves):
+            host[i, :w.numel()] = w
+            lens[i] = w.numel()
+        dev = self.device
+        wave = host.to(dev, non_blocking=True)
+        noise = torch.randn(B, L, device=dev) if dither else None          # y += 1e-5*randn_like(y)  (:155)
+        aug = None
+        if mask:
+            aug = torch.tensor([self.draw_spec_augment(1 + (int(l) + 64) // 160) for l in lens], dtype=torch.int32).to(dev)
+        bft, btf, frames, pct = ops.mel(wave, lens.to(dev), noise, aug, True, self._act_dtype())
+        inputs = bft.unsqueeze(1)
+        inputs._lasr_btf = btf                                           # channels-last twin for the model
+        return inputs, pct
+
+    def _act_dtype(self):
+        return getattr(self, "act_dtype", torch.float32)
+
+
+class MyAudioDataset(Dataset):
+    def __init__(self, manifest_path: list, labels, max_duration=16.7, mask=False, win_len=0.02, sr=16000):
+        self.datasets = []
+        self.labels = labels
+        self.mask = mask
+        for item in manifest_path:
+            total_count, total_duration = 0, 0.0
+            with open(item, encoding="utf-8") as f:
+                for line in f.readlines():
+                    if not line.strip():
+                        continue
+                    data = json.loads(line)
+                    if data["duration"] > max_duration:
+                        total_count += 1
+                        total_duration += data["duration"]
+                        continue
+                    self.datasets.append(data)
+            logging.info("过滤音频条数:{:d}条".format(total_count))
+            logging.info("过滤音频时长:{:.2f}分钟".format(total_duration / 60))
+        self.index2char = dict((i, labels[i]) for i in range(len(labels)))
+        self.char2index = dict((labels[i], i) for i in range(len(labels)))
+
+    def __getitem__(self, index):
+        """-> (wave (L,) f32 on the host, token ids, path): PCM decode only, features are batched on the GPU."""
+        data = self.datasets[index]
+        text2id = [self.char2index[char] for char in data["text"]]
+        return load_wav(data["audio_filepath"])[0], text2id, data["audio_filepath"]
+
+    def id2txt(self, id_list):
+        for id in id_list:
+            if id >= len(self.index2char):
+                raise Exception("index out of the lengths请检查id的大小范围")
+        return "".join(self.index2char[id] for id in id_list)
+
+    def __len__(self):
+        return len(self.datasets)
+
+
+class WaveBatch(tuple):
+    """(waves list, targets (B,Smax) int64, target_sizes (B) int32, paths, mask flag) from the workers."""
+
+
+class LibriDataModule(LightningDataModule):
+    def __init__(self, train_manifest, dev_manifest, test_manifest, labels: list, train_bs=16, dev_bs=16, num_worker=0,
+                 train_max_duration=16.7, dev_max_duration=40, device="cuda", act_dtype=torch.float32):
+        super().__init__()
+        as_list = lambda m: list(m) if isinstance(m, (list, tuple)) else [m]  # noqa: E731
+        self.train_manifest, self.dev_manifest, self.test_manifest = as_list(train_manifest), as_list(dev_manifest), as_list(test_manifest)
+        self.train_bs, self.dev_bs = train_bs, dev_bs
+        self.labels = labels
+        self.num_worker = num_worker
+        self.train_max_duration, self.dev_max_duration = train_max_duration, dev_max_duration
+        self.audio_parser = AudioParser(device=device)
+        self.audio_parser.act_dtype = act_dtype
+
+    def setup(self, stage=None):
+        self.train_datasets = MyAudioDataset(self.train_manifest, self.labels, mask=True, max_duration=self.train_max_duration)
+        self.dev_datasets = MyAudioDataset(self.dev_manifest, self.labels, max_duration=self.dev_max_duration)
+        self.test_datasets = MyAudioDataset(self.test_manifest, self.labels, max_duration=self.dev_max_duration)
+
+    def _loader(self, ds, bs, train, distributed=None):
+        sampler = None
+        if distributed is not None:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(ds, num_replicas=distributed[0], rank=distributed[1], shuffle=train, drop_last=train)
+        collate = self._collate_train if train else self._collate_eval
+        return DataLoader(ds, batch_size=bs, num_workers=self.num_worker, pin_memory=False, collate_fn=collate, drop_last=train,
+                          shuffle=train and sampler is None, sampler=sampler)
+
+    def train_dataloader(self, distributed=None):
+        return self._loader(self.train_datasets, self.train_bs, True, distributed)
+
+    def val_dataloader(self):
+        return self._loader(self.dev_datasets, self.dev_bs, False)
+
+    def test_dataloader(self):
+        return self._loader(self.test_datasets, self.dev_bs, False)
+
+    def get_train_step(self):
+        return len(self.train_dataloader())
+
+    # ---- host half of the collate: ragged waves + padded targets (data_module.py:231-247) ---------
+    def _collate_wave(self, batch, mask: bool) -> WaveBatch:
+        waves = [b[0] for b in batch]
+        if mask:   # training-time random sub-sequence (data_module.py:158-159)
+            waves = [self.audio_parser.sub_secquence(w.unsqueeze(0), weight=0.98)[0] for w in waves]
+        max_trans = max(len(b[1]) for b in batch)
+        targets = torch.zeros(len(batch), max_trans, dtype=torch.int64)
+        target_sizes = torch.zeros(len(batch), dtype=torch.int32)
+        for i, b in enumerate(batch):
+            target_sizes[i] = len(b[1])
+            targets[i, :len(b[1])] = torch.tensor(b[1], dtype=torch.int64)
+        return WaveBatch((waves, targets, target_sizes, [b[2] for b in batch], mask))
+
+    def _collate_train(self, batch):
+        return self._collate_wave(batch, True)
+
+    def _collate_eval(self, batch):
+        return self._collate_wave(batch, False)
+
+    _collate_fn = _collate_eval
+
+    # ---- device half: ONE batched HIP mel call -> the reference's 5-tuple -------------------------
+    def on_after_batch_transfer(self, batch, dataloader_idx=0):
+        if not isinstance(batch, WaveBatch):
+            return batch
+        waves, targets, target_sizes, paths, mask = batch
+        inputs, pct = self.audio_parser.features(waves, mask)
+        dev = inputs.device
+        return inputs, targets.to(dev), pct, target_sizes.to(dev), paths

@@ -128,6 +128,27 @@ class NativeModel:
                     bound = 1.0 / (fan_in ** 0.5)
                     self.view(t).copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * bound).to(self.device))
 
+    def bucket_bounds(self) -> List[int]:
+        """Element offsets cutting the flat gradient into the all-reduce buckets of SURVEY §8e, in layer
+        order: first_cnn | 256-channel blocks | 512-channel blocks | last_cnn2 + (context) + decoder."""
+        cuts = [0]
+        group = None
+        for t in self.param_infos():
+            n = t.name
+            if n.startswith("encoder.first_cnn"):
+                g = 0
+            elif n.startswith(("encoder.block1", "encoder.block2")):
+                g = 1
+            elif n.startswith(("encoder.block3", "encoder.block4", "encoder.block5", "encoder.block6")):
+                g = 2
+            else:
+                g = 3
+            if group is not None and g != group:
+                cuts.append(t.offset)
+            group = g
+        cuts.append(self.n_param)
+        return cuts
+
     def param_offsets(self) -> torch.Tensor:
         offs = [t.offset for t in self.param_infos()] + [self.n_param]
         return torch.tensor(offs, dtype=torch.int64, device=self.device)

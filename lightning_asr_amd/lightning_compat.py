@@ -1,0 +1,296 @@
+"""The slice of pytorch-lightning 1.3 the reference's train.py touches, as a small native host:
+LightningModule / LightningDataModule base classes (the real ones when pytorch_lightning is
+importable), ``seed_everything`` and a ``Trainer`` that runs fit/validate/test with one process per
+GPU over torch.distributed (backend nccl = RCCL on ROCm; gloo on CPU for tests).
+
+Out of scope by SURVEY §2: Comet/TensorBoard loggers, AMP (activations are bf16 in the kernels),
+TPUs, profiler="simple".  Metrics go to stdout and a JSONL file."""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import random
+import time
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+try:  # pragma: no cover - not installed in the build image
+    import pytorch_lightning as _pl
+    HAVE_PL = True
+except Exception:  # noqa: BLE001
+    _pl = None
+    HAVE_PL = False
+
+logger = logging.getLogger(__name__)
+
+
+def seed_everything(seed: int) -> int:
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return seed
+
+
+class _ModuleBase(nn.Module):
+    """Duck-typed pl.LightningModule: what train.py uses (self.log / print / save_hyperparameters /
+    current_epoch / train_dataloader / load_from_checkpoint / hooks)."""
+
+    def __init__(self):
+        super().__init__()
+        self.trainer: Optional["Trainer"] = None
+        self.hparams: Dict[str, Any] = {}
+        self._logged: Dict[str, float] = {}
+
+    # -- what the reference calls -------------------------------------------------------------
+    def save_hyperparameters(self, *args, **kwargs) -> None:
+        import inspect
+        frame = inspect.currentframe().f_back
+        names = inspect.getargvalues(frame)
+        self.hparams = {k: names.locals[k] for k in names.args if k != "self"}
+
+    def log(self, name: str, value, on_step=None, on_epoch=None, prog_bar=False, logger=True, **kw) -> None:
+        v = float(value.detach().item()) if torch.is_tensor(value) else float(value)
+        self._logged[name] = v
+        if self.trainer is not None:
+            self.trainer._record(name, v)
+
+    def print(self, *args) -> None:
+        if self.trainer is None or self.trainer.is_global_zero:
+            print(*args)
+
+    @property
+    def current_epoch(self) -> int:
+        return self.trainer.current_epoch if self.trainer is not None else 0
+
+    @property
+    def global_step(self) -> int:
+        return self.trainer.global_step if self.trainer is not None else 0
+
+    def train_dataloader(self):
+        return self.trainer.datamodule.train_dataloader()
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        pass
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, **kwargs):
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(kwargs)
+        model = cls(**hp)
+        model.load_state_dict(ckpt["state_dict"])
+        return model
+
+
+class _DataModuleBase:
+    def __init__(self):
+        self.trainer = None
+
+    def setup(self, stage=None):
+        pass
+
+
+LightningModule = _pl.LightningModule if HAVE_PL else _ModuleBase
+LightningDataModule = _pl.LightningDataModule if HAVE_PL else _DataModuleBase
+
+
+def _to_device(x, device):
+    if torch.is_tensor(x):
+        return x.to(device, non_blocking=True)
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_device(v, device) for v in x)
+    return x
+
+
+class GradSync:
+    """Data-parallel gradient averaging over a flat buffer: bucketed SUM all-reduces issued in reverse
+    layer order (the order backward produces them), 1/world folded into the optimiser's grad scale.
+    Works on any backend (RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, bucket_bounds: List[int], process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bounds = bucket_bounds            # ascending element offsets, first 0, last n
+
+    def all_reduce(self, flat: torch.Tensor, async_op: bool = False):
+        if self.world == 1:
+            return []
+        works = []
+        for lo, hi in reversed(list(zip(self.bounds[:-1], self.bounds[1:]))):
+            works.append(self.dist.all_reduce(flat[lo:hi], group=self.pg, async_op=async_op))
+        return works
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+class Trainer:
+    """fit / test loops for the reference's LightingModule + LibriDataModule pair (train.py:233-253)."""
+
+    def __init__(self, gpus=None, max_epochs: int = 1, resume_from_checkpoint: Optional[str] = None,
+                 check_val_every_n_epoch: int = 1, limit_train_batches=1.0, limit_val_batches=1.0,
+                 accelerator: Optional[str] = None, num_nodes: int = 1, default_root_dir: str = ".",
+                 callbacks=None, logger=None, save_top_k: int = 3, monitor: str = "val_wer", max_steps: Optional[int] = None,
+                 device: Optional[str] = None, **ignored):
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.resume_from_checkpoint = resume_from_checkpoint
+        self.check_val_every_n_epoch = check_val_every_n_epoch
+        self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
+        self.root = default_root_dir
+        self.save_top_k, self.monitor = save_top_k, monitor
+        self.current_epoch = 0
+        self.global_step = 0
+        self.datamodule = None
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device(device) if device else torch.device("cuda", self.local_rank)
+        self.history: List[Dict[str, Any]] = []
+        self._epoch_metrics: Dict[str, List[float]] = {}
+        self._best: List[tuple] = []
+        self.callback_metrics: Dict[str, float] = {}
+
+    @property
+    def is_global_zero(self) -> bool:
+        return self.rank == 0
+
+    def _record(self, name: str, v: float) -> None:
+        self._epoch_metrics.setdefault(name, []).append(v)
+        self.callback_metrics[name] = v
+
+    def _limit(self, n: int, lim) -> int:
+        if isinstance(lim, float):
+            return max(1, int(n * lim)) if lim < 1.0 else n
+        return min(n, int(lim))
+
+    def _init_dist(self):
+        import torch.distributed as dist
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                dist.init_process_group("gloo")
+        return dist
+
+    def _batch(self, batch, dm, idx=0):
+        batch = _to_device(batch, self.device)
+        if hasattr(dm, "on_after_batch_transfer"):
+            batch = dm.on_after_batch_transfer(batch, idx)
+        return batch
+
+    def _save(self, model, opt, sched, name: str) -> str:
+        d = os.path.join(self.root, "checkpoints")
+        os.makedirs(d, exist_ok=True)
+        ckpt = {"epoch": self.current_epoch, "global_step": self.global_step, "state_dict": model.state_dict(),
+                "optimizer_states": [opt.state_dict()], "lr_schedulers": [sched.state_dict()] if sched else [],
+                "hyper_parameters": dict(getattr(model, "hparams", {})), "pytorch-lightning_version": "lasr-native"}
+        model.on_save_checkpoint(ckpt)
+        path = os.path.join(d, name)
+        torch.save(ckpt, path)
+        return path
+
+    def fit(self, model, datamodule=None):
+        dist = self._init_dist()
+        self.datamodule = datamodule
+        model.trainer = self
+        datamodule.trainer = self
+        datamodule.setup("fit")
+        optimizers, schedulers = model.configure_optimizers()
+        opt = optimizers[0]
+        sched = schedulers[0]["scheduler"] if schedulers else None
+        start_epoch = 0
+        if self.resume_from_checkpoint:
+            ckpt = torch.load(self.resume_from_checkpoint, map_location="cpu", weights_only=False)
+            model.load_state_dict(ckpt["state_dict"])
+            opt.load_state_dict(ckpt["optimizer_states"][0])
+            if sched and ckpt.get("lr_schedulers"):
+                sched.load_state_dict(ckpt["lr_schedulers"][0])
+            start_epoch, self.global_step = ckpt["epoch"] + 1, ckpt["global_step"]
+        native = getattr(getattr(model, "encoder", None), "native", None)
+        sync = None
+        if self.world > 1:
+            dist.broadcast(native.params, 0)
+            dist.broadcast(native.buffers, 0)
+            sync = GradSync(native.bucket_bounds(), None)
+            opt.grad_scale = sync.grad_scale
+        loader = datamodule.train_dataloader()
+        if self.world > 1:
+            loader = datamodule.train_dataloader(distributed=(self.world, self.rank))
+        os.makedirs(self.root, exist_ok=True)
+        log_path = os.path.join(self.root, "metrics.jsonl")
+        for epoch in range(start_epoch, self.max_epochs):
+            self.current_epoch = epoch
+            self._epoch_metrics = {}
+            model.train()
+            if hasattr(loader, "sampler") and hasattr(loader.sampler, "set_epoch"):
+                loader.sampler.set_epoch(epoch)
+            n = self._limit(len(loader), self.limit_train_batches)
+            t0 = time.time()
+            for batch_idx, batch in enumerate(loader):
+                if batch_idx >= n or (self.max_steps and self.global_step >= self.max_steps):
+                    break
+                batch = self._batch(batch, datamodule)
+                loss = model.training_step(batch, batch_idx)
+                opt.zero_grad()
+                loss.backward()
+                if sync is not None:
+                    sync.all_reduce(native.grads)
+                opt.step()
+                if sched is not None:
+                    sched.step()
+                self.global_step += 1
+            rec = {"epoch": epoch, "global_step": self.global_step, "train_time_s": time.time() - t0,
+                   "lr": opt.param_groups[0]["lr"]}
+            rec.update({k: float(np.mean(v)) for k, v in self._epoch_metrics.items()})
+            if (epoch + 1) % self.check_val_every_n_epoch == 0:
+                rec.update(self.validate(model, datamodule))
+            self.history.append(rec)
+            if self.is_global_zero:
+                with open(log_path, "a") as f:
+                    f.write(json.dumps(rec) + "\n")
+                self._save(model, opt, sched, "last.ckpt")
+                if self.monitor in rec:
+                    name = "asr-epoch=%02d-%s=%.2f.ckpt" % (epoch, self.monitor, rec[self.monitor])
+                    self._best.append((rec[self.monitor], self._save(model, opt, sched, name)))
+                    self._best.sort(key=lambda x: x[0])
+                    for _, p in self._best[self.save_top_k:]:
+                        if os.path.exists(p):
+                            os.remove(p)
+                    self._best = self._best[:self.save_top_k]
+            if self.max_steps and self.global_step >= self.max_steps:
+                break
+        return self.history
+
+    @torch.no_grad()
+    def validate(self, model, datamodule) -> Dict[str, float]:
+        model.eval()
+        self._epoch_metrics = {}
+        loader = datamodule.val_dataloader()
+        n = self._limit(len(loader), self.limit_val_batches)
+        outs = []
+        for batch_idx, batch in enumerate(loader):
+            if batch_idx >= n:
+                break
+            outs.append(model.validation_step(self._batch(batch, datamodule), batch_idx))
+        model.validation_epoch_end(outs)
+        model.train()
+        return {k: float(np.mean(v)) for k, v in self._epoch_metrics.items()}
+
+    @torch.no_grad()
+    def test(self, model, test_dataloaders=None, datamodule=None):
+        model.trainer = self
+        model.eval()
+        loader = test_dataloaders if test_dataloaders is not None else datamodule.test_dataloader()
+        dm = datamodule or self.datamodule
+        outs = [model.test_step(self._batch(batch, dm), i) for i, batch in enumerate(loader)]
+        model.test_epoch_end(outs)
+        return outs

@@ -1,0 +1,120 @@
+"""GPU tier: the Python host mirror (LightingModule / LibriDataModule / Trainer / Novograd / WER) drives
+the HIP path through the reference's call surface and matches the CPU oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LABELS = [c.strip() for c in open(os.path.join(ROOT, "data", "labels.txt")).readlines()]
+
+
+def _module(dev, **kw):
+    from lightning_asr_amd.train import LightingModule
+    m = LightingModule(learning_rate=1e-2, weight_decay=1e-3, labels=LABELS, total_epoch=2, drop_rate=0.0, mask=True,
+                       use_cer=True, device=str(dev), **kw)
+    m.encoder.load_state_dict(R.formula_state("plain", 28))
+    return m
+
+
+def test_state_dict_keys_have_lightning_prefix(dev):
+    m = _module(dev)
+    keys = list(m.state_dict().keys())
+    assert keys == ["encoder." + k for k, _ in R.state_shapes("plain", 28)]       # train.py:197 -> 'encoder.encoder....'
+    assert len(list(m.parameters())) == 100
+    assert sum(p.numel() for p in m.parameters()) == 5044572
+
+
+def test_training_step_matches_oracle_f32(dev):
+    from lightning_asr_amd.data_module import AudioParser
+    from lightning_asr_amd.scheduler.novograd import Novograd
+    B, L, S = 3, 16000, 7
+    wave, tg, tl = R.synth_batch(B, L, S, 27, seed=11)
+    lens = [16000, 12000, 8000]
+    waves = [wave[i, :lens[i]] for i in range(B)]
+    # oracle: per-utterance features, reference collate, train step
+    feats = [R.parse_wave(w.unsqueeze(0)) for w in waves]
+    inputs, targets, pct, tsz = R.collate(feats, [tg[i].tolist() for i in range(B)])
+    om = R.OracleModel("plain", 28, mask=True, state=R.formula_state("plain", 28))
+    st = R.NovogradState(len(om.parameters()))
+    loss_ref, grads_ref = R.train_step(om, st, inputs, targets, pct, tsz, 1e-2, 1e-3)
+    # product: GPU features -> the reference 5-tuple -> training_step -> backward -> Novograd
+    ap = AudioParser(device=str(dev))
+    x_gpu, pct_gpu = ap.features(waves, mask=False, dither=False)
+    assert x_gpu.shape == inputs.shape
+    assert (x_gpu.cpu() - inputs).abs().max() < 2e-4
+    assert torch.allclose(pct_gpu.cpu(), pct, atol=1e-7)
+    m = _module(dev)
+    m.train()
+    # identical inputs on both sides for the step itself (the f64-FFT features above differ from the f32
+    # oracle's by up to 2e-4, which this BN stack's backward map amplifies ~100x in the gradients)
+    batch = (inputs.to(dev), targets.to(dev), pct.to(dev), tsz.to(dev), ["a", "b", "c"])
+    loss = m.training_step(batch, 1)
+    assert abs(loss.item() - loss_ref) / abs(loss_ref) < 1e-4
+    opt = Novograd(m.parameters(), lr=1e-2, weight_decay=1e-3, betas=(0.8, 0.5))
+    opt.zero_grad()
+    loss.backward()
+    for p, g in zip(m.parameters(), grads_ref):
+        assert p.grad is not None and p.grad.shape == g.shape
+    worst = max(((p.grad.cpu().double() - g.double()).norm() / (g.double().norm() + 1e-30)).item()
+                for p, g in zip(m.parameters(), grads_ref))
+    assert worst < 3e-3, worst
+    opt.step()
+    worst = max(((p.detach().cpu().double() - q.detach().double()).norm() / (q.detach().double().norm() + 1e-30)).item()
+                for p, q in zip(m.parameters(), om.parameters()))
+    assert worst < 1e-3, worst
+    assert m._logged["train_loss"] == pytest.approx(loss.item())
+    assert 0.0 <= m._logged["train_wer"]
+
+
+def test_wer_metric_decodes_on_device(dev):
+    from lightning_asr_amd.utils.asr_metrics import WER
+    w = WER(LABELS, use_cer=True)
+    ids = torch.tensor([[1, 1, 27, 2, 2, 27, 27, 3], [27, 5, 5, 5, 27, 27, 27, 27]], dtype=torch.int32, device=dev)
+    lens = torch.tensor([8, 4], dtype=torch.int32, device=dev)
+    assert w.ctc_decoder_predictions_tensor(ids, lens) == ["abc", "e"]
+    tg = torch.tensor([[1, 2, 4], [5, 0, 0]])
+    val = w(ids, tg, torch.tensor([3, 1]), lens)
+    assert float(val) == pytest.approx(1 / 4)            # "abc" vs "abd": 1 edit over 3+1 reference characters
+    hyp = R.greedy_decode(ids.cpu(), lens.cpu(), LABELS)
+    assert hyp == ["abc", "e"]
+
+
+def test_fit_on_synthetic_corpus_and_resume(dev, tmp_path):
+    data = tmp_path / "synth"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_data.py"), "--out", str(data), "--n-train", "8",
+                    "--n-dev", "4", "--seconds", "2.0", "--ragged"], check=True)
+    from lightning_asr_amd.train import main
+    out = tmp_path / "run"
+    ov = ["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
+          "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % os.path.join(ROOT, "data", "labels.txt"),
+          "train.train_batch_size=4", "train.dev_batch_size=4", "train.total_epoch=2", "train.precision=32",
+          "train.warmup_steps=2", "output_dir=%s" % out]
+    tr = main(ov)
+    hist = tr.history
+    assert len(hist) == 2 and tr.global_step == 4
+    for rec in hist:
+        assert np.isfinite(rec["train_loss"]) and np.isfinite(rec["val_loss"]) and rec["val_wer"] >= 0
+    assert hist[0]["lr"] > 1e-4                                    # warm-up moved the LR off min_lr
+    lines = open(out / "metrics.jsonl").read().strip().splitlines()
+    assert len(lines) == 2 and "val_wer" in json.loads(lines[-1])
+    ckpt = torch.load(out / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
+    assert list(ckpt["state_dict"].keys())[0] == "encoder.encoder.first_cnn.depthwise_conv.weight"
+    assert ckpt["hyper_parameters"]["total_epoch"] == 2 and ckpt["global_step"] == 4
+    # resume: continues from epoch 2 with the saved optimiser state
+    tr2 = main(ov[:-1] + ["output_dir=%s" % (tmp_path / "run2"), "train.total_epoch=3", "train.checkpoint=%s" % (out / "checkpoints" / "last.ckpt")])
+    assert len(tr2.history) == 1 and tr2.history[0]["epoch"] == 2 and tr2.global_step == 6
+    # load_from_checkpoint + inference surface
+    from lightning_asr_amd.train import LightingModule
+    m = LightingModule.load_from_checkpoint(str(out / "checkpoints" / "last.ckpt"))
+    m.eval()
+    with torch.no_grad():
+        lp = m(torch.zeros(1, 1, 64, 101, device=dev), torch.ones(1, device=dev))
+    assert lp.shape == (1, 51, 28) and torch.isfinite(lp).all()

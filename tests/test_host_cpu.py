@@ -1,0 +1,148 @@
+"""CPU tier: host logic of the product (no compute calls: there is no GPU here) and the C-ABI surface."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "lasr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lasr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lightning_asr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", ROOT, "-j", "8"], check=True)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), "liblasr.so does not export %s declared in include/lasr.h" % s
+    assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
+    assert _lib.load().lasr_version() >= 100
+    assert _lib.load().lasr_last_error() is not None
+
+
+def test_host_routines_without_gpu():
+    from lightning_asr_amd import _lib
+    from lightning_asr_amd.utils.asr_metrics import word_error_rate
+    lib = _lib.load()
+    assert lib.lasr_mel_num_frames(160000) == 1001
+    assert lib.lasr_mel_num_frames(16000) == 101
+    a = np.array([1, 2, 3, 4], dtype=np.int32)
+    b = np.array([1, 3, 4, 5, 6], dtype=np.int32)
+    d = lib.lasr_edit_distance(a.ctypes.data_as(ctypes.c_void_p), 4, b.ctypes.data_as(ctypes.c_void_p), 5)
+    assert d == 3
+    assert word_error_rate(["a b c", "x"], ["a c", "x y"]) == pytest.approx(0.5)
+    assert word_error_rate(["kitten"], ["sitting"], use_cer=True) == pytest.approx(3 / 7)
+    with pytest.raises(ValueError):
+        word_error_rate(["a"], ["a", "b"])
+
+
+def test_error_convention_and_no_cpu_fallback():
+    from lightning_asr_amd import _lib, ops
+    lib = _lib.load()
+    rc = lib.lasr_gemm(None, None, None, 0, 0, 4, 4, 4, 0, 0, None, None, None, 0, None, 1, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.lasr_last_error()      # LASR_E_ARG, message set, nothing launched
+    with pytest.raises(_lib.LasrError):
+        ops.dwconv(torch.zeros(1, 8, 4), torch.zeros(4, 3))             # CPU tensors: refused, never emulated
+    from lightning_asr_amd.engine import NativeModel
+    with pytest.raises(_lib.LasrError):
+        NativeModel("plain", 28, device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lightning_asr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert "oracle" not in text.replace("oracle/", "").lower() or f == "__init__.py" or "import oracle" not in text, f
+                assert "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_config_loader_defaults_interpolation_overrides(tmp_path):
+    from lightning_asr_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "conf"), "conf", ["train.learning_rate=5e-3", "data.train_manifest=[a.json,b.json]",
+                                                            "model.variant=context_se", "+extra.flag=true"])
+    assert cfg.get("train").get("learning_rate") == 5e-3
+    assert cfg.get("data").get("train_manifest") == ["a.json", "b.json"]
+    assert cfg.get("model").get("mask") is True and cfg.model.variant == "context_se" and cfg.extra.flag is True
+    assert cfg.log.level == "INFO"                                        # defaults: - log: hypra_logger
+    name = cfg.loggers.tensorboard.experiment_fixed_name
+    assert "asr13x1-lr0.005-wc0.001-bs32" in name and "mask_True" in name   # ${a.b} interpolation sees the override
+    assert cfg.output_dir == "outputs/asr13x1"
+    assert cfg.get("train").get("checkpoint") is None and cfg.get("nothing", 7) == 7
+
+
+def test_schedule_syncs_optimizer_groups():
+    from lightning_asr_amd.schedule import CosineAnnealingWarmupRestarts
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-2)
+    s = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=20, cycle_mult=2, max_lr=1e-2, min_lr=1e-4, warmup_steps=5, gamma=0.5)
+    assert opt.param_groups[0]["lr"] == 1e-4                              # init_lr(): starts at min_lr
+    lrs = []
+    for _ in range(70):
+        lrs.append(s.step())
+        assert opt.param_groups[0]["lr"] == lrs[-1]
+    assert max(lrs[:20]) == pytest.approx(1e-2) and max(lrs[20:]) == pytest.approx(5e-3)   # restart with gamma
+    sd = s.state_dict()
+    s2 = CosineAnnealingWarmupRestarts(None, first_cycle_steps=20, cycle_mult=2, max_lr=1e-2, min_lr=1e-4, warmup_steps=5, gamma=0.5)
+    s2.load_state_dict(sd)
+    assert s2.step() == s.step()
+
+
+def test_dataset_manifest_and_wave_collate(tmp_path):
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_data.py"), "--out", str(tmp_path), "--n-train", "3",
+                    "--n-dev", "2", "--seconds", "1.0", "--ragged"], check=True)
+    from lightning_asr_amd.data_module import MyAudioDataset, load_wav
+    labels = [c.strip() for c in open(os.path.join(ROOT, "data", "labels.txt")).readlines()]
+    assert len(labels) == 27 and labels[0] == "'"
+    ds = MyAudioDataset([str(tmp_path / "train.json")], labels, max_duration=16.7, mask=True)
+    assert len(ds) == 3
+    wave, ids, path = ds[0]
+    assert wave.dtype == torch.float32 and wave.dim() == 1 and wave.abs().max() <= 1.0
+    assert ds.id2txt(ids) == __import__("json").loads(open(tmp_path / "train.json").readline())["text"]
+    assert len(MyAudioDataset([str(tmp_path / "train.json")], labels, max_duration=0.1)) == 0      # duration filter
+    assert load_wav(path).shape[0] == 1
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightning_asr_amd.lightning_compat import GradSync
+    torch.manual_seed(rank)
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    sync = GradSync([0, 3, 7, 10])
+    works = sync.all_reduce(flat, async_op=True)
+    for w in works:
+        w.wait()
+    q.put((rank, (flat * sync.grad_scale).tolist(), sync.world))
+    dist.destroy_process_group()
+
+
+def test_grad_sync_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = (torch.arange(10, dtype=torch.float32) * 1.5).tolist()       # mean of x*1 and x*2
+    for rank, vals, world in res:
+        assert world == 2 and vals == pytest.approx(expect)
