@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default=os.environ.get("LASR_BENCH_DTYPE", "f32"), choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default=os.environ.get("LASR_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
+                    help="activation dtype: bf16 (BASELINE config) or f32 (exact parity mode)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -81,7 +82,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path is hand-written HIP with no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)       # nccl backend IS RCCL on ROCm
