@@ -11,6 +11,7 @@
 //                  transpose), so no operand is ever transposed through HBM or VALU.
 // bf16 results leave through an LDS transpose so every global store is 16 B per lane.
 #include "gemm.h"
+#include <stdlib.h>
 
 namespace lasr {
 
@@ -27,31 +28,54 @@ static constexpr int EPI_LD = 144;           // bytes per row of a wave's 64x64 
 
 union Frag { uint4 u; s16x8 s; bf16x8 b; };
 
+// Compact kernel arguments: 32-bit element offsets inside a matrix (host checks M*ld < 2^31).
+struct Bf16Args {
+  const bf16_t* A; const bf16_t* B; void* C;
+  const float* bias; const int32_t* row_lens; float* stat_partials; float* split_ws;
+  int M, N, K, lda, ldb, ldc, rows_per_seq, k_per_split;
+  int gm, gn, gz;      // tile grid
+  int vecA, vecB, vecC;
+};
+
 // ---- global -> registers: 4 x 16 B per thread per operand tile ------------------------------------
 template <bool TRANS>
-__device__ __forceinline__ void load_oper(const bf16_t* __restrict__ X, int64_t ld, int64_t R, int64_t r0, int64_t k0,
-                                          int64_t kend, bool vec_ok, uint4 (&reg)[4]) {
+__device__ __forceinline__ void load_oper(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, bool vec_ok,
+                                          uint4 (&reg)[4]) {
   const int tid = threadIdx.x;
+  // Fast path, decided per TILE (wave-uniform, a scalar branch): four unconditional 16-byte loads in
+  // flight per lane.  Rows past the matrix edge are clamped to the last row: what they load is never
+  // stored (the epilogue masks m >= M / n >= N).  Per-lane bounds branches here serialise the loads.
+  const bool fast = vec_ok && (k0 + TK <= kend) && (TRANS ? (r0 + TM <= R) : true);
+  if (fast) {
 #pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int c = tid + 256 * p;
+      uint32_t off;
+      if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)(k0 + ((c & 7) << 3));
+      else off = (uint32_t)(k0 + (c >> 4)) * (uint32_t)ld + (uint32_t)(r0 + ((c & 15) << 3));
+      reg[p] = *reinterpret_cast<const uint4*>(X + off);
+    }
+    return;
+  }
+#pragma unroll 1
   for (int p = 0; p < 4; ++p) {
     const int c = tid + 256 * p;
-    int64_t row, col, row_lim, col_lim;
+    int row, col, row_lim, col_lim;
     if (!TRANS) { row = r0 + (c >> 3); col = k0 + ((c & 7) << 3); row_lim = R; col_lim = kend; }   // [r][k]
     else        { row = k0 + (c >> 4); col = r0 + ((c & 15) << 3); row_lim = kend; col_lim = R; }   // [k][r]
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < row_lim) {
-      const bf16_t* src = X + row * ld + col;
+    if (row < row_lim && col < col_lim) {
+      const bf16_t* src = X + (uint32_t)row * (uint32_t)ld + (uint32_t)col;
       if (vec_ok && col + 7 < col_lim) {
         v = *reinterpret_cast<const uint4*>(src);
       } else {
-        bf16_t e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = (col + i < col_lim) ? src[i] : (bf16_t)0;
-        v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-        v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int i = 0; i < 8; ++i)
+          if (col + i < col_lim) w[i >> 1] |= (uint32_t)src[i] << (16 * (i & 1));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
-    reg[p] = v;
+    if (p == 0) reg[0] = v; else if (p == 1) reg[1] = v; else if (p == 2) reg[2] = v; else reg[3] = v;
   }
 }
 
@@ -87,20 +111,41 @@ __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ s, int rb, 
   return f.b;
 }
 
-// grid: (ceil(N/TN), ceil(M/TM), split_k)
+// 1-D grid of gm*gn*gz tiles.  Workgroups are dealt round-robin to the 8 XCDs (b and b+8 share an
+// XCD's L2), so the linear id is remapped (bijectively) to give every XCD a contiguous run of tiles
+// in (z, m, n) order: the gn tiles that re-read one 128-row A panel, and the tiles of one split-K
+// slice, then hit the same L2 instead of fetching the panel from HBM once per XCD.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 template <typename TC, bool TRANS_A, bool TRANS_B>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args g) {
   __shared__ __attribute__((aligned(16))) char smem[2 * OPER_BYTES];
   __shared__ float s_stat[2][2][TN];
+  __shared__ float s_keep[TM];
   char* sA = smem;
   char* sB = smem + OPER_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
-  const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
-  const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(g.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(g.B);
+  const int lid = xcd_remap(blockIdx.x, g.gm * g.gn * g.gz);
+  const int tn = lid % g.gn, tm = (lid / g.gn) % g.gm, tz = lid / (g.gn * g.gm);
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int kbeg = tz * g.k_per_split;
+  const int kend = min(kbeg + g.k_per_split, g.K);
+
+  // 1.0 for output rows that are stored as computed, 0.0 for rows past the matrix edge or past their
+  // utterance's length (MaskCNN): one integer division per ROW here, none in the epilogue.
+  if (tid < TM) {
+    const int m = m0 + tid;
+    bool keep = m < g.M;
+    if (keep && g.row_lens) {
+      const int b = m / g.rows_per_seq;
+      keep = (m - b * g.rows_per_seq) < g.row_lens[b];
+    }
+    s_keep[tid] = keep ? 1.f : 0.f;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -110,135 +155,143 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[4], rb[4];
-  load_oper<TRANS_A>(A, g.lda, g.M, m0, kbeg, kend, g.vecA, ra);
-  load_oper<TRANS_B>(B, g.ldb, g.N, n0, kbeg, kend, g.vecB, rb);
-  for (int64_t k0 = kbeg; k0 < kend; k0 += TK) {
-    __syncthreads();
-    store_oper<TRANS_A>(sA, ra);
-    store_oper<TRANS_B>(sB, rb);
-    __syncthreads();
-    if (k0 + TK < kend) {
-      load_oper<TRANS_A>(A, g.lda, g.M, m0, k0 + TK, kend, g.vecA, ra);
-      load_oper<TRANS_B>(B, g.ldb, g.N, n0, k0 + TK, kend, g.vecB, rb);
-    }
-#pragma unroll
-    for (int ks = 0; ks < TK / 16; ++ks) {
-      const bf16x8 a0 = load_frag<TRANS_A>(sA, wm * 64, ks, lane);
-      const bf16x8 a1 = load_frag<TRANS_A>(sA, wm * 64 + 32, ks, lane);
-      const bf16x8 b0 = load_frag<TRANS_B>(sB, wn * 64, ks, lane);
-      const bf16x8 b1 = load_frag<TRANS_B>(sB, wn * 64 + 32, ks, lane);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-    }
+  // Two register sets: the global loads of K-tile i+2 are issued while tile i is multiplied, so a
+  // load has two full iterations to land (one CU holds 2 workgroups x 64 KB in flight).  With K of
+  // only 256-1024 the kernel is a short dependent chain of load latencies, not a bandwidth stream.
+  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+  load_oper<TRANS_A>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, ra0);
+  load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, rb0);
+  load_oper<TRANS_A>(g.A, g.lda, g.M, m0, kbeg + TK, kend, g.vecA, ra1);
+  load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, g.vecB, rb1);
+#define LASR_K_STEP(RA_, RB_, KNEXT_)                                                     \
+  {                                                                                      \
+    __syncthreads();                                                                     \
+    store_oper<TRANS_A>(sA, RA_);                                                        \
+    store_oper<TRANS_B>(sB, RB_);                                                        \
+    __syncthreads();                                                                     \
+    if ((KNEXT_) < kend) {                                                               \
+      load_oper<TRANS_A>(g.A, g.lda, g.M, m0, (KNEXT_), kend, g.vecA, RA_);               \
+      load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, (KNEXT_), kend, g.vecB, RB_);               \
+    }                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < TK / 16; ++ks) {                             \
+      const bf16x8 a0 = load_frag<TRANS_A>(sA, wm * 64, ks, lane);                       \
+      const bf16x8 a1 = load_frag<TRANS_A>(sA, wm * 64 + 32, ks, lane);                  \
+      const bf16x8 b0 = load_frag<TRANS_B>(sB, wn * 64, ks, lane);                       \
+      const bf16x8 b1 = load_frag<TRANS_B>(sB, wn * 64 + 32, ks, lane);                  \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);   \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);   \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);   \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);   \
+    }                                                                                    \
   }
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * TK) {
+    LASR_K_STEP(ra0, rb0, k0 + 2 * TK)
+    if (k0 + TK < kend) LASR_K_STEP(ra1, rb1, k0 + 3 * TK)
+  }
+#undef LASR_K_STEP
 
   const int half = lane >> 5, l31 = lane & 31;
   // acc[mi][ni][r]: row = wm*64 + mi*32 + (r&3) + 8*(r>>2) + 4*half, col = wn*64 + ni*32 + l31
-  if (g.split_ws || Elem<TC>::kDtype == LASR_F32) {
+  if constexpr (Elem<TC>::kDtype == LASR_F32) {
     // f32 destinations (split-K slabs, logits, weight gradients): straight from the accumulators,
     // 32 lanes x 4 B = one 128-byte segment per row
-    float* W = g.split_ws ? g.split_ws + (int64_t)blockIdx.z * g.M * g.N : reinterpret_cast<float*>(g.C);
-    const int64_t ldw = g.split_ws ? g.N : g.ldc;
+    float* W = g.split_ws ? g.split_ws + (size_t)tz * (size_t)g.M * (size_t)g.N : reinterpret_cast<float*>(g.C);
+    const int ldw = g.split_ws ? g.N : g.ldc;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      const int64_t n = n0 + wn * 64 + ni * 32 + l31;
+      const int n = n0 + wn * 64 + ni * 32 + l31;
       const float bv = (!g.split_ws && g.bias && n < g.N) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m < g.M && n < g.N) {
-            float v = acc[mi][ni][r] + bv;
-            if (!g.split_ws && g.row_lens) {
-              const int64_t b = m / g.rows_per_seq;
-              if (m - b * g.rows_per_seq >= g.row_lens[b]) v = 0.f;
-            }
-            W[m * ldw + n] = v;
-          }
+          const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int m = m0 + lr;
+          if (m < g.M && n < g.N) W[(uint32_t)m * (uint32_t)ldw + (uint32_t)n] = g.split_ws ? acc[mi][ni][r] : (acc[mi][ni][r] + bv) * s_keep[lr];
         }
     }
-    return;
-  }
-
-  // ---- bf16 destination: bias, row mask, round, column sums; then LDS transpose and 16-byte stores
-  __syncthreads();  // every wave is done reading the operand images
-  char* epi = smem + wid * (64 * EPI_LD);
-  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+  } else {
+    // ---- bf16 destination: row mask, round, column sums; then LDS transpose and 16-byte stores
+    __syncthreads();  // every wave is done reading the operand images
+    char* epi = smem + wid * (64 * EPI_LD);
+    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    const float bv0 = (g.bias && n0 + wn * 64 + l31 < g.N) ? g.bias[n0 + wn * 64 + l31] : 0.f;
+    const float bv1 = (g.bias && n0 + wn * 64 + 32 + l31 < g.N) ? g.bias[n0 + wn * 64 + 32 + l31] : 0.f;
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int64_t n = n0 + wn * 64 + ni * 32 + l31;
-    const bool n_ok = n < g.N;
-    const float bv = (g.bias && n_ok) ? g.bias[n] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int64_t m = m0 + wm * 64 + lr;
-        float v = acc[mi][ni][r] + bv;
-        if (g.row_lens && m < g.M) {
-          const int64_t b = m / g.rows_per_seq;
-          if (m - b * g.rows_per_seq >= g.row_lens[b]) v = 0.f;
-        }
-        const bf16_t q = f32_to_bf16(v);
-        if (m < g.M && n_ok) {
-          const float sv = bf16_to_f32(q);
-          csum[ni] += sv;
-          csq[ni] = fmaf(sv, sv, csq[ni]);
-        }
-        *reinterpret_cast<bf16_t*>(epi + lr * EPI_LD + (ni * 32 + l31) * 2) = q;
-      }
-  }
-  if (g.stat_partials) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      csum[ni] += __shfl_xor(csum[ni], 32, 64);
-      csq[ni] += __shfl_xor(csq[ni], 32, 64);
-      if (half == 0) {
-        s_stat[wm][0][wn * 64 + ni * 32 + l31] = csum[ni];
-        s_stat[wm][1][wn * 64 + ni * 32 + l31] = csq[ni];
+        const float kf = s_keep[wm * 64 + lr];
+        const bf16_t q0 = f32_to_bf16((acc[mi][0][r] + bv0) * kf);
+        const bf16_t q1 = f32_to_bf16((acc[mi][1][r] + bv1) * kf);
+        const float v0 = bf16_to_f32(q0), v1 = bf16_to_f32(q1);   // statistics of the values as stored
+        csum[0] += v0; csq[0] = fmaf(v0, v0, csq[0]);
+        csum[1] += v1; csq[1] = fmaf(v1, v1, csq[1]);
+        *reinterpret_cast<bf16_t*>(epi + lr * EPI_LD + l31 * 2) = q0;
+        *reinterpret_cast<bf16_t*>(epi + lr * EPI_LD + (32 + l31) * 2) = q1;
       }
     }
-  }
-  __syncthreads();
-  {
-    // each wave drains its own 64x64 image: lane -> (row = it*8 + lane/8, 8 columns at (lane%8)*8)
-    bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
-    const int cg = lane & 7, rr = lane >> 3;
-    const int64_t n = n0 + wn * 64 + cg * 8;
-    const bool vec_ok = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(C) % 16 == 0);
+    if (g.stat_partials) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int lr = it * 8 + rr;
-      const int64_t m = m0 + wm * 64 + lr;
-      if (m < g.M && n < g.N) {
-        const uint4 v = *reinterpret_cast<const uint4*>(epi + lr * EPI_LD + cg * 16);
-        bf16_t* dst = C + m * g.ldc + n;
-        if (vec_ok && n + 7 < g.N) {
-          *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-          for (int i = 0; i < 8 && n + i < g.N; ++i) dst[i] = e[i];
+      for (int ni = 0; ni < 2; ++ni) {
+        csum[ni] += __shfl_xor(csum[ni], 32, 64);
+        csq[ni] += __shfl_xor(csq[ni], 32, 64);
+        if (half == 0) {
+          s_stat[wm][0][wn * 64 + ni * 32 + l31] = csum[ni];
+          s_stat[wm][1][wn * 64 + ni * 32 + l31] = csq[ni];
         }
       }
     }
-  }
-  if (g.stat_partials && tid < TN) {
-    const int64_t n = n0 + tid;
-    if (n < g.N) {
-      float* P = g.stat_partials + (int64_t)blockIdx.y * 2 * g.N;
-      P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
-      P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+    __syncthreads();
+    {
+      // each wave drains its own 64x64 image: lane -> (row = it*8 + lane/8, 8 columns at (lane%8)*8)
+      bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+      const int cg = lane & 7, rr = lane >> 3;
+      const int n = n0 + wn * 64 + cg * 8;
+      const bool full_n = g.vecC && n + 7 < g.N;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 8 + rr;
+        const int m = m0 + wm * 64 + lr;
+        if (m < g.M && n < g.N) {
+          const uint4 v = *reinterpret_cast<const uint4*>(epi + lr * EPI_LD + cg * 16);
+          bf16_t* dst = C + (uint32_t)m * (uint32_t)g.ldc + (uint32_t)n;
+          if (full_n) {
+            *reinterpret_cast<uint4*>(dst) = v;
+          } else {
+            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+            for (int i = 0; i < 8 && n + i < g.N; ++i) dst[i] = e[i];
+          }
+        }
+      }
+    }
+    if (g.stat_partials && tid < TN) {
+      const int n = n0 + tid;
+      if (n < g.N) {
+        float* P = g.stat_partials + (size_t)tm * 2 * g.N;
+        P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
+        P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+      }
     }
   }
 }
 
 int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim3 grid, hipStream_t st) {
-#define LASR_BF16_CASE(TC_, TA_, TB_) hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_>), grid, dim3(256), 0, st, g)
+  const int64_t lim = (int64_t)1 << 31;
+  if (g.M * g.lda >= lim || g.K * g.lda >= lim || g.N * g.ldb >= lim || g.K * g.ldb >= lim || g.M * g.ldc >= lim ||
+      (int64_t)grid.x * grid.y * grid.z >= lim)
+    return fail(LASR_E_SHAPE, "lasr_gemm(bf16): matrix exceeds the kernel's 32-bit element offsets");
+  Bf16Args a;
+  a.A = reinterpret_cast<const bf16_t*>(g.A); a.B = reinterpret_cast<const bf16_t*>(g.B); a.C = g.C;
+  a.bias = g.bias; a.row_lens = g.row_lens; a.stat_partials = g.stat_partials; a.split_ws = g.split_ws;
+  a.M = (int)g.M; a.N = (int)g.N; a.K = (int)g.K; a.lda = (int)g.lda; a.ldb = (int)g.ldb; a.ldc = (int)g.ldc;
+  a.rows_per_seq = (int)(g.rows_per_seq > 0 ? g.rows_per_seq : 1); a.k_per_split = (int)g.k_per_split;
+  a.gn = (int)grid.x; a.gm = (int)grid.y; a.gz = (int)grid.z;
+  a.vecA = g.vecA; a.vecB = g.vecB;
+  a.vecC = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0);
+  const dim3 grid1((unsigned)(a.gn * a.gm * a.gz));
+#define LASR_BF16_CASE(TC_, TA_, TB_) hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_>), grid1, dim3(256), 0, st, a)
 #define LASR_BF16_TC(TC_)                                         \
   do {                                                            \
     if (!transA && !transB) LASR_BF16_CASE(TC_, false, false);    \
@@ -246,7 +299,7 @@ int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim
     else if (transA && !transB) LASR_BF16_CASE(TC_, true, false); \
     else LASR_BF16_CASE(TC_, true, true);                         \
   } while (0)
-  if (dtype_c == LASR_F32) LASR_BF16_TC(float); else LASR_BF16_TC(bf16_t);
+  if (dtype_c == LASR_F32 || g.split_ws) LASR_BF16_TC(float); else LASR_BF16_TC(bf16_t);   // split-K slabs are f32
 #undef LASR_BF16_TC
 #undef LASR_BF16_CASE
   LASR_LAUNCH_CHECK("gemm_bf16_kernel");
