@@ -134,6 +134,40 @@ int lasr_bn_act_bwd_apply(const void* dout, const void* y, const float* coef,
                           float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T, int64_t C, int act,
                           void* stream);
 
+/* ---------------------------------------------------------------- SE + BiLSTM context --------
+ * models/QuartNetContextSE.py:8-23,55  SELayer(reduction=8, no bias): s = sigmoid(W2 relu(W1 mean_T(BN(y)))),
+ * mean over ALL T' frames.  BN is affine per channel, so the squeeze needs only sums[b][c] = sum_t y[b,t,c]
+ * (lasr_seqsum) and the BN coefficients; the scale is applied inside lasr_bn_act_fwd (se_scale).          */
+int lasr_seqsum(const void* x, int dtype, int64_t B, int64_t T, int64_t C, float* sums, void* stream);
+/* pooled (B,C) = coef_a*sums/T + coef_b ; hidden (B,C/8) = relu(W1 pooled) ; scale (B,C) = sigmoid(W2 hidden) */
+int lasr_se_fwd(const float* sums, const float* coef, const float* W1, const float* W2, int64_t B, int64_t T, int64_t C,
+                float* pooled, float* hidden, float* scale, void* stream);
+/* Backward of the excite path: seg (B,C) = gradient reaching every frame of the BN output through the pooled
+ * mean (feed it to lasr_bn_act_bwd_* as se_grad), dW1 (C/8,C), dW2 (C,C/8).                               */
+size_t lasr_se_bwd_workspace_bytes(int64_t B, int64_t C);
+int lasr_se_bwd(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
+                const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
+                int64_t C, int act, float* seg, float* dW1, float* dW2, void* workspace, size_t workspace_bytes, void* stream);
+
+/* models/QuartNetContext.py:171-173,186-199: pack_padded_sequence -> nn.LSTM(256, 40, bidirectional) ->
+ * pad_packed_sequence.  gx_f/gx_r (B,T,160) f32 = x W_ih^T per direction (lasr_gemm; biases are added here),
+ * gate order i,f,g,o, reverse direction starts at each utterance's last valid frame, outputs zero for
+ * t >= lens[b].  Writes h into columns [col0, col0+80) of a [B][T][ld_out] tensor (the cat() of :173).
+ * saved: lasr_bilstm_saved_bytes(B,T) of f32 state for the backward pass.                                  */
+size_t lasr_bilstm_saved_bytes(int64_t B, int64_t T);
+int lasr_bilstm_fwd(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const float* bih_f,
+                    const float* bhh_f, const float* bih_r, const float* bhh_r, const int32_t* lens, int64_t B, int64_t T,
+                    void* out, int dtype, int64_t ld_out, int64_t col0, float* saved, void* stream);
+/* dout: columns [col0, col0+80) of a [B][T][ld_dout] gradient.  dg_f/dg_r (B,T,160) f32 = gradient w.r.t. the gate
+ * pre-activations (=> dW_ih = dg^T x, db = colsum(dg), dx = dg W_ih by lasr_gemm), dwhh_f/dwhh_r (160,40).  */
+size_t lasr_bilstm_bwd_workspace_bytes(int64_t B);
+int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f, const float* whh_r,
+                    const int32_t* lens, int64_t B, int64_t T, const float* saved, float* dg_f, float* dg_r, float* dwhh_f,
+                    float* dwhh_r, void* workspace, size_t workspace_bytes, void* stream);
+/* dst[n][dcol0+c] (+)= src[n][scol0+c], c < ncols, with dtype conversion (torch.cat / its backward slice, :173) */
+int lasr_copy_cols(const void* src, int src_dtype, int64_t ld_src, int64_t scol0, void* dst, int dst_dtype, int64_t ld_dst,
+                   int64_t dcol0, int64_t rows, int64_t ncols, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------- head + loss --------------
  * models/QuartNet.py:287-290 log_softmax over classes; train.py:76-78,196 CTCLoss(blank=C-1,
  * reduction='none', zero_infinity=False) and the batch mean; utils/asr_metrics.py:138-171.     */

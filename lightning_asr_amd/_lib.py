@@ -40,6 +40,15 @@ SIGNATURES = {
     "lasr_bn_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lasr_bn_act_bwd_stats": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),
     "lasr_bn_act_bwd_apply": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p]),
+    "lasr_seqsum": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p]),
+    "lasr_se_fwd": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p]),
+    "lasr_se_bwd_workspace_bytes": (_sz, [_i64, _i64]),
+    "lasr_se_bwd": (_i32, [_p] * 10 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    "lasr_bilstm_saved_bytes": (_sz, [_i64, _i64]),
+    "lasr_bilstm_fwd": (_i32, [_p] * 9 + [_i64, _i64, _p, _i32, _i64, _i64, _p, _p]),
+    "lasr_bilstm_bwd_workspace_bytes": (_sz, [_i64]),
+    "lasr_bilstm_bwd": (_i32, [_p, _i32, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lasr_copy_cols": (_i32, [_p, _i32, _i64, _i64, _p, _i32, _i64, _i64, _i64, _i64, _i32, _p]),
     "lasr_log_softmax": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "lasr_log_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "lasr_ctc_workspace_bytes": (_sz, [_i64, _i64, _i64]),

@@ -15,6 +15,23 @@ extern "C" int lasr_cast_f32_to_bf16(const float*, void*, int64_t, void*);
 extern "C" int lasr_colsum_f32(const float* x, float* out, int64_t rows, int64_t C, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C);
 extern "C" int lasr_scale_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream);
+extern "C" int lasr_seqsum(const void* x, int dtype, int64_t B, int64_t T, int64_t C, float* sums, void* stream);
+extern "C" int lasr_se_fwd(const float* sums, const float* coef, const float* W1, const float* W2, int64_t B, int64_t T, int64_t C,
+                           float* pooled, float* hidden, float* scale, void* stream);
+extern "C" size_t lasr_se_bwd_workspace_bytes(int64_t B, int64_t C);
+extern "C" int lasr_se_bwd(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
+                           const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
+                           int64_t C, int act, float* seg, float* dW1, float* dW2, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" size_t lasr_bilstm_saved_bytes(int64_t B, int64_t T);
+extern "C" int lasr_bilstm_fwd(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const float* bih_f,
+                               const float* bhh_f, const float* bih_r, const float* bhh_r, const int32_t* lens, int64_t B, int64_t T,
+                               void* out, int dtype, int64_t ld_out, int64_t col0, float* saved, void* stream);
+extern "C" size_t lasr_bilstm_bwd_workspace_bytes(int64_t B);
+extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f, const float* whh_r,
+                               const int32_t* lens, int64_t B, int64_t T, const float* saved, float* dg_f, float* dg_r, float* dwhh_f,
+                               float* dwhh_r, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" int lasr_copy_cols(const void* src, int src_dtype, int64_t ld_src, int64_t scol0, void* dst, int dst_dtype, int64_t ld_dst,
+                              int64_t dcol0, int64_t rows, int64_t ncols, int accumulate, void* stream);
 
 namespace lasr {
 
@@ -36,18 +53,23 @@ struct BnRef { int64_t gamma = -1, beta = -1, rmean = -1, rvar = -1; };
 struct Unit {
   std::string tap;
   int ci = 0, co = 0, k = 0, stride = 1;
-  bool has_dw = false, has_res = false, masked = false, act = true;
-  int64_t w_dw = -1, w_pw = -1, w_res = -1;
+  bool has_dw = false, has_res = false, masked = false, act = true, has_se = false, ctx_before = false;
+  int64_t w_dw = -1, w_pw = -1, w_res = -1, w_se1 = -1, w_se2 = -1;
   BnRef bn, bn_res;
   // workspace offsets (bytes) filled by plan()
   size_t o_u = 0, o_y = 0, o_y2 = 0, o_out = 0, o_coef = 0, o_saved = 0, o_coef2 = 0, o_saved2 = 0, o_stats = 0, o_stats2 = 0;
+  size_t o_se_sum = 0, o_se_pool = 0, o_se_hid = 0, o_se_scale = 0, o_se_grad = 0;   // SE: [B][co] (hid: [B][co/8]) f32
 };
+
+// BiLSTM context branch (Context / ContextSE): parameter offsets per direction
+struct LstmRef { int64_t w_ih[2] = {-1, -1}, w_hh[2] = {-1, -1}, b_ih[2] = {-1, -1}, b_hh[2] = {-1, -1}; };
 
 struct Plan {
   int64_t B = 0, T_in = 0, T = 0, S_max = 0;
   size_t total = 0;
   size_t o_lens = 0, o_logits = 0, o_glogits = 0, o_nll = 0, o_scratch = 0, o_g[2] = {0, 0}, o_d1 = 0, o_d2 = 0, o_du = 0, o_dxr = 0;
   size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0;
+  size_t o_cat = 0, o_gx[2] = {0, 0}, o_lstm_saved = 0, o_dg[2] = {0, 0};   // context: [N][336] | [N][160] f32 x2 | saved | [N][160] f32 x2
   size_t scratch_bytes = 0, ctc_bytes = 0;
 };
 
@@ -61,6 +83,7 @@ struct lasr_model {
   std::vector<Unit> units;
   int64_t n_param = 0, n_buffer = 0;
   int64_t w_dec = -1, b_dec = -1;
+  LstmRef lstm;
   Plan plan;
   bool planned = false;
 
@@ -89,6 +112,11 @@ struct lasr_model {
     u.w_dw = add_tensor(p + ".depthwise_conv.weight", {u.ci, 1, u.k}, 0);
     u.w_pw = add_tensor(p + ".pointwise_conv.weight", {u.co, u.ci, 1}, 0);
     u.bn = add_bn(p + ".bn", u.co);
+    if (cfg.variant == LASR_VARIANT_CONTEXT_SE) {   // SELayer(out_ch, reduction=8)  models/QuartNetContextSE.py:46
+      u.has_se = true;
+      u.w_se1 = add_tensor(p + ".se.fc.0.weight", {u.co / 8, u.co}, 0);
+      u.w_se2 = add_tensor(p + ".se.fc.2.weight", {u.co, u.co / 8}, 0);
+    }
   }
 };
 
@@ -111,6 +139,7 @@ static int build_model(lasr_model* m) {
   for (const B& b : blocks) {  // QuartNetBlock(repeat=1)                 models/QuartNet.py:55-78
     Unit u;
     u.tap = b.name; u.ci = b.ci; u.co = b.co; u.k = b.k; u.has_dw = true; u.has_res = true; u.masked = c.mask != 0;
+    u.ctx_before = ctx && std::string(b.name) == "block3";   // cat(x, BiLSTM(x)) feeds block3  (QuartNetContext.py:171-174)
     const std::string p = std::string("encoder.") + b.name;
     u.w_res = m->add_tensor(p + ".reside.0.weight", {u.co, u.ci, 1}, 0);
     u.bn_res = m->add_bn(p + ".reside.1", u.co);
@@ -124,7 +153,16 @@ static int build_model(lasr_model* m) {
     u.bn = m->add_bn("encoder.last_cnn2.1", 1024);
     m->units.push_back(u);
   }
-  if (ctx) return fail(LASR_E_SHAPE, "lasr_model_create: the Context/ContextSE variants are not wired into the native plan yet");
+  if (ctx) {  // context_rnn = nn.LSTM(256, 40, bidirectional)   models/QuartNetContext.py:157
+    const std::string r = "encoder.context_rnn.rnn.";
+    for (int d = 0; d < 2; ++d) {
+      const std::string sfx = d ? "_reverse" : "";
+      m->lstm.w_ih[d] = m->add_tensor(r + "weight_ih_l0" + sfx, {160, 256}, 0);
+      m->lstm.w_hh[d] = m->add_tensor(r + "weight_hh_l0" + sfx, {160, 40}, 0);
+      m->lstm.b_ih[d] = m->add_tensor(r + "bias_ih_l0" + sfx, {160}, 0);
+      m->lstm.b_hh[d] = m->add_tensor(r + "bias_hh_l0" + sfx, {160}, 0);
+    }
+  }
   m->w_dec = m->add_tensor("decoder.weight", {c.n_class, 1024, 1}, 0);
   m->b_dec = m->add_tensor("decoder.bias", {c.n_class}, 0);
   return 0;
@@ -162,6 +200,14 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
       u.o_saved2 = take(cur, 2 * u.co * sizeof(float));
       u.o_stats2 = take(cur, 2 * u.co * sizeof(float));
     }
+    if (u.has_se) {
+      u.o_se_sum = take(cur, (size_t)B * u.co * sizeof(float));
+      u.o_se_pool = take(cur, (size_t)B * u.co * sizeof(float));
+      u.o_se_hid = take(cur, (size_t)B * (u.co / 8) * sizeof(float));
+      u.o_se_scale = take(cur, (size_t)B * u.co * sizeof(float));
+      u.o_se_grad = take(cur, (size_t)B * u.co * sizeof(float));
+      scratch = std::max(scratch, lasr_se_bwd_workspace_bytes(B, u.co));
+    }
     cmax = std::max<int64_t>(cmax, std::max(u.ci, u.co));
     scratch = std::max(scratch, lasr_gemm_workspace_bytes(N, u.co, 1, 1));
     scratch = std::max(scratch, lasr_bn_bwd_workspace_bytes(B, p.T, u.co));
@@ -171,6 +217,14 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   const int64_t C = m->cfg.n_class;
   scratch = std::max(scratch, lasr_gemm_workspace_bytes(C, 1024, 16, 0));
   scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, C));
+  if (m->cfg.variant != LASR_VARIANT_PLAIN) {
+    p.o_cat = take(cur, (size_t)N * 336 * es);
+    for (int d = 0; d < 2; ++d) { p.o_gx[d] = take(cur, (size_t)N * 160 * sizeof(float)); p.o_dg[d] = take(cur, (size_t)N * 160 * sizeof(float)); }
+    p.o_lstm_saved = take(cur, lasr_bilstm_saved_bytes(B, p.T));
+    scratch = std::max(scratch, lasr_bilstm_bwd_workspace_bytes(B));
+    scratch = std::max(scratch, lasr_gemm_workspace_bytes(160, 256, 16, 0));
+    scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, 160));
+  }
   p.o_logits = take(cur, (size_t)N * C * sizeof(float));
   p.o_glogits = take(cur, (size_t)N * C * sizeof(float));
   p.o_nll = take(cur, (size_t)(B + 1) * sizeof(float));
@@ -240,6 +294,7 @@ extern "C" int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, 
     if (n == u.tap + ".y") { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_y; }
     if (n == u.tap + ".u" && u.has_dw) { shape[0] = B; shape[1] = p.T; shape[2] = u.ci; return (int64_t)u.o_u; }
   }
+  if (n == "ctx_in" && m->cfg.variant != LASR_VARIANT_PLAIN) { shape[0] = B; shape[1] = p.T; shape[2] = 336; return (int64_t)p.o_cat; }
   if (n == "logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_logits; }
   if (n == "grad_logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_glogits; }
   if (n == "lens") { shape[0] = B; shape[1] = 1; shape[2] = 1; return (int64_t)p.o_lens; }
@@ -272,6 +327,17 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
   const void* x = feats;
   int64_t Tx = T_in;
   for (const Unit& u : m->units) {
+    if (u.ctx_before) {
+      // context branch: gates' input projection as two GEMMs (f32 out), the recurrence, then cat(x, lstm) -> [N][336]
+      for (int d = 0; d < 2; ++d)
+        LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->lstm.w_ih[d]), atf(ws, p.o_gx[d]), dt, LASR_F32, N, 160, 256, 0, 0, nullptr, nullptr,
+                           nullptr, 0, nullptr, 1, scratch, p.scratch_bytes, stream));
+      LASR_TRY(lasr_copy_cols(x, dt, 256, 0, at(ws, p.o_cat), dt, 336, 0, N, 256, 0, stream));
+      LASR_TRY(lasr_bilstm_fwd(atf(ws, p.o_gx[0]), atf(ws, p.o_gx[1]), params + m->lstm.w_hh[0], params + m->lstm.w_hh[1],
+                               params + m->lstm.b_ih[0], params + m->lstm.b_hh[0], params + m->lstm.b_ih[1], params + m->lstm.b_hh[1],
+                               lens, B, T, at(ws, p.o_cat), dt, 336, 256, atf(ws, p.o_lstm_saved), stream));
+      x = at(ws, p.o_cat);
+    }
     const void* gin = x;
     if (u.has_dw) {
       LASR_TRY(lasr_dwconv_fwd(x, params + u.w_dw, nullptr, at(ws, u.o_u), dt, B, Tx, u.ci, u.k, u.stride, 0, stream));
@@ -290,9 +356,14 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
                                 buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
                                 training, stream));
     }
+    if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
+      LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
+      LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
+                           atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), stream));
+    }
     LASR_TRY(lasr_bn_act_fwd(at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
-                             u.has_res ? atf(ws, u.o_coef2) : nullptr, nullptr, at(ws, u.o_out), dt, B, T, u.co,
-                             u.act ? m->cfg.act : LASR_ACT_NONE, stream));
+                             u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_se ? atf(ws, u.o_se_scale) : nullptr, at(ws, u.o_out), dt, B,
+                             T, u.co, u.act ? m->cfg.act : LASR_ACT_NONE, stream));
     x = at(ws, u.o_out);
     Tx = T;
   }
@@ -330,18 +401,26 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   for (int ui = (int)m->units.size() - 1; ui >= 0; --ui) {
     const Unit& u = m->units[ui];
     const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
+    if (u.ctx_before) x_in = at(ws, p.o_cat);
     const int64_t Tx = ui > 0 ? T : T_in;
     const int act = u.act ? m->cfg.act : LASR_ACT_NONE;
     void* dout = at(ws, p.o_g[cur]);
     void* dy = at(ws, p.o_d1);
     void* dy2 = u.has_res ? at(ws, p.o_d2) : nullptr;
+    const float* se_scale = u.has_se ? atf(ws, u.o_se_scale) : nullptr;
+    const float* se_grad = u.has_se ? atf(ws, u.o_se_grad) : nullptr;
+    if (u.has_se)
+      LASR_TRY(lasr_se_bwd(dout, at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
+                           u.has_res ? atf(ws, u.o_coef2) : nullptr, se_scale, atf(ws, u.o_se_hid), atf(ws, u.o_se_pool), params + u.w_se1,
+                           params + u.w_se2, dt, B, T, u.co, act, atf(ws, u.o_se_grad), grads + u.w_se1, grads + u.w_se2, scratch, sb,
+                           stream));
     LASR_TRY(lasr_bn_act_bwd_stats(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), u.has_res ? at(ws, u.o_y2) : nullptr,
-                                   u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_res ? atf(ws, u.o_saved2) : nullptr, nullptr,
-                                   nullptr, atf(ws, p.o_sums), atf(ws, p.o_sums2), dt, B, T, u.co, act, scratch, sb, stream));
+                                   u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_res ? atf(ws, u.o_saved2) : nullptr, se_scale,
+                                   se_grad, atf(ws, p.o_sums), atf(ws, p.o_sums2), dt, B, T, u.co, act, scratch, sb, stream));
     LASR_TRY(lasr_bn_act_bwd_apply(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma,
                                    u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
-                                   u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, nullptr,
-                                   nullptr, atf(ws, p.o_sums), atf(ws, p.o_sums2), u.masked ? lens : nullptr, dy, dy2,
+                                   u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, se_scale,
+                                   se_grad, atf(ws, p.o_sums), atf(ws, p.o_sums2), u.masked ? lens : nullptr, dy, dy2,
                                    grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
                                    u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, stream));
     // main 1x1: dW[co][ci] = dy^T gin
@@ -370,6 +449,29 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                          nullptr, 0, nullptr, 1, scratch, sb, stream));
     }
     cur ^= 1;
+    if (u.ctx_before) {
+      // g[cur] holds d(cat) [N][336].  Back through the BiLSTM, then
+      // d(block23 out) = d(cat)[:, :256] + dG_f W_ih_f + dG_r W_ih_r  -> g[cur^1]
+      const void* x23 = at(ws, m->units[ui - 1].o_out);
+      LASR_TRY(lasr_bilstm_bwd(at(ws, p.o_g[cur]), dt, 336, 256, params + m->lstm.w_hh[0], params + m->lstm.w_hh[1], lens, B, T,
+                               atf(ws, p.o_lstm_saved), atf(ws, p.o_dg[0]), atf(ws, p.o_dg[1]), grads + m->lstm.w_hh[0],
+                               grads + m->lstm.w_hh[1], scratch, sb, stream));
+      LASR_TRY(lasr_copy_cols(at(ws, p.o_g[cur]), dt, 336, 0, at(ws, p.o_g[cur ^ 1]), dt, 256, 0, N, 256, 0, stream));
+      for (int d = 0; d < 2; ++d) {
+        const void* dg_ab = atf(ws, p.o_dg[d]);
+        if (dt == LASR_BF16) {
+          LASR_TRY(lasr_cast_f32_to_bf16(atf(ws, p.o_dg[d]), at(ws, p.o_d1), N * 160, stream));
+          dg_ab = at(ws, p.o_d1);
+        }
+        LASR_TRY(lasr_colsum_f32(atf(ws, p.o_dg[d]), grads + m->lstm.b_ih[d], N, 160, scratch, sb, stream));
+        LASR_TRY(lasr_colsum_f32(atf(ws, p.o_dg[d]), grads + m->lstm.b_hh[d], N, 160, scratch, sb, stream));
+        LASR_TRY(lasr_gemm(dg_ab, x23, grads + m->lstm.w_ih[d], dt, LASR_F32, 160, 256, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16,
+                           scratch, sb, stream));
+        LASR_TRY(lasr_gemm(dg_ab, wptr(m, params, ws, m->lstm.w_ih[d]), at(ws, p.o_g[cur ^ 1]), dt, dt, N, 256, 160, 0, 1, nullptr,
+                           at(ws, p.o_g[cur ^ 1]), nullptr, 0, nullptr, 1, scratch, sb, stream));
+      }
+      cur ^= 1;
+    }
   }
   return 0;
 }

@@ -119,3 +119,46 @@ def test_plain_bf16_mode_tracks_f32(dev):
     norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
     assert np.median(np.abs(norms / gold["grad_norms"] - 1)) < 5e-2
     assert torch.isfinite(m.grads).all()
+
+
+@pytest.mark.parametrize("variant", ["context", "context_se"])
+def test_context_variants_match_golden_f32(dev, variant):
+    """QuartNetContext (BiLSTM context branch, 336-ch block3, block6) and QuartNetContextSE (+SE) on the
+    native plan vs the fixtures captured from the reference, and full gradients vs the CPU oracle."""
+    from lightning_asr_amd import ops
+    gold = np.load("tests/golden/model_%s.npz" % variant)
+    x, tg, pct, tsz = golden_inputs()
+    m = _native(variant, 28, dev)
+    assert [(t.name, t.shape) for t in m.tensors] == [(k, tuple(s)) for k, s in R.state_shapes(variant, 28)]
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    lp_e, _ = m.forward(feats, pct.to(dev), training=False)
+    assert np.abs(lp_e.cpu().numpy() - gold["eval_logprobs"]).max() < 3e-4
+    m2 = _native(variant, 28, dev)
+    loss, nll, lp, am = m2.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert np.abs(lp.cpu().numpy() - gold["logprobs"]).max() < 3e-3       # oracle itself is 2.4e-3 from the reference here
+    assert np.abs(nll.cpu().numpy() - gold["nll"]).max() / np.abs(gold["nll"]).max() < 1e-4
+    assert (am.cpu().numpy().astype(np.int16) == gold["argmax"]).mean() > 0.995
+    ctx = m2.tap("ctx_in")[:, :, 256:].contiguous().cpu()            # the reference module returns (B, T, 80)
+    assert np.abs(checksum(ctx) - gold["tap_context_rnn"]).max() < 1e-5
+    norms = np.array([m2.view(t, m2.grads).norm().item() for t in m2.param_infos()])
+    assert np.abs(norms / gold["grad_norms"] - 1).max() < 2e-2
+    o = R.OracleModel(variant, 28, mask=True, state=R.formula_state(variant, 28))
+    st = R.NovogradState(len(o.parameters()))
+    _, grads = R.train_step(o, st, x, tg, pct, tsz, 1e-2, 1e-3)
+    rels = {t.name: rel_l2(m2.view(t, m2.grads), g) for t, g in zip(m2.param_infos(), grads)}
+    worst = max(rels.values())
+    assert worst < 1e-2, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+
+
+@pytest.mark.parametrize("variant", ["context", "context_se"])
+def test_context_variants_bf16_mode_runs(dev, variant):
+    from lightning_asr_amd import ops
+    gold = np.load("tests/golden/model_%s.npz" % variant)
+    x, tg, pct, tsz = golden_inputs()
+    m = _native(variant, 28, dev, torch.bfloat16)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev), torch.bfloat16)
+    loss, nll, lp, am = m.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert abs(loss.item() - gold["losses"][0]) / gold["losses"][0] < 3e-2
+    assert torch.isfinite(m.grads).all()
+    norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
+    assert np.median(np.abs(norms / gold["grad_norms"] - 1)) < 8e-2
