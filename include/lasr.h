@@ -277,6 +277,21 @@ int lasr_model_loss_backward(lasr_model_t* m, const float* params, float* buffer
                              int32_t* argmax_out, float* grads, void* workspace, size_t workspace_bytes,
                              void* stream);
 
+/* Backward in stages, so the host can start the RCCL all-reduce of a gradient bucket while the units
+ * below it are still being differentiated (Lightning DDP's bucketed overlap, conf/conf.yaml:30).
+ * Units are numbered in forward order (lasr_model_unit_info gives their names).  _partial runs forward,
+ * loss, the decoder and units [unit_stop, n); each _continue call runs units [unit_stop, previous stop).
+ * Gradients of a unit's parameters are final once the call that covers the unit has been enqueued.      */
+int64_t lasr_model_num_units(const lasr_model_t* m);
+int lasr_model_unit_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap);
+int lasr_model_loss_backward_partial(lasr_model_t* m, const float* params, float* buffers, const void* feats,
+                                     const float* pct, const int64_t* targets, const int32_t* tgt_lens, int64_t B,
+                                     int64_t T_in, int64_t S_max, float* logp_out, float* loss_out, float* nll_out,
+                                     int32_t* argmax_out, float* grads, void* workspace, size_t workspace_bytes,
+                                     int64_t unit_stop, void* stream);
+int lasr_model_backward_continue(lasr_model_t* m, const float* params, const void* feats, int64_t B, int64_t T_in,
+                                 float* grads, void* workspace, size_t workspace_bytes, int64_t unit_stop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,10 @@ SIGNATURES = {
     "lasr_model_forward": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     "lasr_model_backward": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _sz, _p]),
     "lasr_model_loss_backward": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "lasr_model_num_units": (_i64, [_p]),
+    "lasr_model_unit_info": (_i32, [_p, _i64, C.c_char_p, _sz]),
+    "lasr_model_loss_backward_partial": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _i64, _p]),
+    "lasr_model_backward_continue": (_i32, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _i64, _p]),
 }
 
 _lib = None

@@ -60,16 +60,14 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 // is a ~500-step dependent chain per utterance, so transcendental LATENCY is the kernel's run time
 // (libm expf/logf: ~0.5 ms per step of the bench; these: ~10x less).  Arguments are in [-90, 0] and
 // [1, 3]; the relative error per step (~1e-6) stays far inside the 1e-4 loss tolerance.
-__device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  if (m == kNegInf) return kNegInf;
-  return m + __logf(__expf(a - m) + __expf(b - m));
-}
+// Branch-free: with every input -inf the shifted sum is exp(-inf)*3 = 0 and log(0) = -inf, so no
+// per-lane early exit is needed (divergent exits cost an exec-mask branch per state per step).
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(fmaxf(a, b), c);
-  if (m == kNegInf) return kNegInf;
-  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+  const float mm = (m == kNegInf) ? 0.f : m;
+  return mm + __logf(__expf(a - mm) + __expf(b - mm) + __expf(c - mm));
 }
+__device__ __forceinline__ float lse2(float a, float b) { return lse3(a, b, kNegInf); }
 
 // Workspace layout per utterance: alpha [T][SP], beta [T][SP] (SP = 64*NS), then next_same [S_max] int32.
 // grid: B blocks of 128 threads.
@@ -134,47 +132,59 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
     a[i] = (start && s >= 0 && s < SS) ? em[i] : kNegInf;
     out[(int64_t)t_first * SP + s] = a[i];
   }
-  // emissions of the next step are fetched one step ahead of their use
-  float em_next[NS];
+  // Emissions are fetched kPre steps ahead into a register ring.  On CDNA4 s_waitcnt vmcnt counts
+  // stores as well as loads, in issue order: with a one-step prefetch every step would also wait for
+  // the previous step's lattice stores to retire (~0.7 us).  Eight steps of slack hide both.
+  constexpr int kPre = 8;
+  float ring[kPre][NS];
 #pragma unroll
-  for (int i = 0; i < NS; ++i)
-    em_next[i] = (Tb > 1 && lane * NS + i < SS) ? lp[(int64_t)(t_first + dt) * C + cls[i]] : kNegInf;
-  for (int step = 1; step < Tb; ++step) {
-    const int t = t_first + dt * step;
+  for (int u = 0; u < kPre; ++u)
 #pragma unroll
-    for (int i = 0; i < NS; ++i) em[i] = em_next[i];
-    if (step + 1 < Tb) {
+    for (int i = 0; i < NS; ++i)
+      ring[u][i] = (1 + u < Tb && lane * NS + i < SS) ? lp[(int64_t)(t_first + dt * (1 + u)) * C + cls[i]] : kNegInf;
+  for (int step0 = 1; step0 < Tb; step0 += kPre) {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) em_next[i] = (lane * NS + i < SS) ? lp[(int64_t)(t + dt) * C + cls[i]] : kNegInf;
-    }
-    float n[NS];
-    if (!is_beta) {
-      float p1 = __shfl_up(a[NS - 1], 1, 64);
-      float p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1, 64) : 0.f;
-      if (lane == 0) { p1 = kNegInf; p2 = kNegInf; }
+    for (int u = 0; u < kPre; ++u) {
+      const int step = step0 + u;
+      if (step < Tb) {  // wave-uniform
+        const int t = t_first + dt * step;
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        // i==0: s-1 is the previous lane's last state, s-2 its second to last; i==1: s-2 is the previous lane's last
-        const float s1 = i >= 1 ? a[i - 1] : p1;
-        const float s2v = (i == 0) ? p2 : (i == 1 ? p1 : a[i - 2]);
-        n[i] = (skip_ok[i] ? lse3(a[i], s1, s2v) : lse2(a[i], s1)) + em[i];
+        for (int i = 0; i < NS; ++i) em[i] = ring[u][i];
+        if (step + kPre < Tb) {
+#pragma unroll
+          for (int i = 0; i < NS; ++i)
+            ring[u][i] = (lane * NS + i < SS) ? lp[(int64_t)(t + dt * kPre) * C + cls[i]] : kNegInf;
+        }
+        float n[NS];
+        if (!is_beta) {
+          float p1 = __shfl_up(a[NS - 1], 1, 64);
+          float p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1, 64) : 0.f;
+          if (lane == 0) { p1 = kNegInf; p2 = kNegInf; }
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            // i==0: s-1 is the previous lane's last state, s-2 its second to last; i==1: s-2 is the previous lane's last
+            const float s1 = i >= 1 ? a[i - 1] : p1;
+            const float s2v = (i == 0) ? p2 : (i == 1 ? p1 : a[i - 2]);
+            n[i] = lse3(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
+          }
+        } else {
+          float q1 = __shfl_down(a[0], 1, 64);
+          float q2 = NS >= 2 ? __shfl_down(a[1], 1, 64) : 0.f;
+          if (lane == 63) { q1 = kNegInf; q2 = kNegInf; }
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            const float s1 = i + 1 < NS ? a[i + 1] : q1;
+            const float s2v = (i + 2 < NS) ? a[i + 2] : (i + 2 == NS ? q1 : q2);
+            n[i] = lse3(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const int s = lane * NS + i;
+          a[i] = (s < SS) ? n[i] : kNegInf;
+          out[(int64_t)t * SP + s] = a[i];
+        }
       }
-    } else {
-      float q1 = __shfl_down(a[0], 1, 64);
-      float q2 = NS >= 2 ? __shfl_down(a[1], 1, 64) : 0.f;
-      if (lane == 63) { q1 = kNegInf; q2 = kNegInf; }
-#pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const float s1 = i + 1 < NS ? a[i + 1] : q1;
-        const float s2v = (i + 2 < NS) ? a[i + 2] : (i + 2 == NS ? q1 : q2);
-        n[i] = (skip_ok[i] ? lse3(a[i], s1, s2v) : lse2(a[i], s1)) + em[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      const int s = lane * NS + i;
-      a[i] = (s < SS) ? n[i] : kNegInf;
-      out[(int64_t)t * SP + s] = a[i];
     }
   }
   if (!is_beta) {

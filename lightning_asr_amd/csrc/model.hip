@@ -86,6 +86,8 @@ struct lasr_model {
   LstmRef lstm;
   Plan plan;
   bool planned = false;
+  int bwd_cur = 0;       // ping-pong index of the gradient buffers between partial backward calls
+  int bwd_next = -1;     // next unit a lasr_model_backward_continue call would process (-1: nothing pending)
 
   int64_t add_tensor(const std::string& name, std::initializer_list<int64_t> shape, int kind) {
     TensorInfo t;
@@ -376,8 +378,10 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
 }
 
 // backward from d(loss)/d(logits) already in the workspace (o_glogits)
+// unit_stop: the unit loop runs from the last unit down to `unit_stop` (0 = the whole model); a later
+// lasr_model_backward_continue call picks up at unit_stop-1.  with_head: run the decoder part first.
 static int backward_from_glogits(lasr_model* m, const float* params, const void* feats, int64_t B, int64_t T_in, float* grads,
-                                 void* ws, void* stream) {
+                                 void* ws, void* stream, bool with_head = true, int unit_hi = -1, int unit_stop = 0) {
   const Plan& p = m->plan;
   const int dt = m->cfg.dtype;
   const int64_t T = p.T, N = B * T, C = m->cfg.n_class;
@@ -386,6 +390,9 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   const int32_t* lens = reinterpret_cast<const int32_t*>(at(ws, p.o_lens));
   float* gl = atf(ws, p.o_glogits);
   const Unit& last = m->units.back();
+  int cur = m->bwd_cur;
+  if (with_head) {
+  cur = 0;
   // decoder (models/QuartNet.py:275): dW = gl^T h, db = colsum(gl), dh = gl W
   const void* gl_ab = gl;
   if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient
@@ -395,10 +402,11 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   LASR_TRY(lasr_gemm(gl_ab, at(ws, last.o_out), grads + m->w_dec, dt, LASR_F32, C, 1024, N, 1, 1, nullptr, nullptr, nullptr, 0,
                      nullptr, 16, scratch, sb, stream));
   LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
-  int cur = 0;
   LASR_TRY(lasr_gemm(gl_ab, wptr(m, params, ws, m->w_dec), at(ws, p.o_g[cur]), dt, dt, N, 1024, C, 0, 1, nullptr, nullptr, nullptr,
                      0, nullptr, 1, scratch, sb, stream));
-  for (int ui = (int)m->units.size() - 1; ui >= 0; --ui) {
+  }
+  if (unit_hi < 0) unit_hi = (int)m->units.size() - 1;
+  for (int ui = unit_hi; ui >= unit_stop; --ui) {
     const Unit& u = m->units[ui];
     const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
     if (u.ctx_before) x_in = at(ws, p.o_cat);
@@ -473,6 +481,8 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       cur ^= 1;
     }
   }
+  m->bwd_cur = cur;
+  m->bwd_next = unit_stop - 1;
   return 0;
 }
 
@@ -503,4 +513,39 @@ extern "C" int lasr_model_loss_backward(lasr_model_t* m, const float* params, fl
                          nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
   LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
   return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream);
+}
+
+extern "C" int64_t lasr_model_num_units(const lasr_model_t* m) { return m ? (int64_t)m->units.size() : -1; }
+
+extern "C" int lasr_model_unit_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap) {
+  LASR_CHECK_ARG(m && i >= 0 && i < (int64_t)m->units.size() && name && name_cap > 0, "lasr_model_unit_info: bad argument");
+  strncpy(name, m->units[i].tap.c_str(), name_cap - 1);
+  name[name_cap - 1] = 0;
+  return 0;
+}
+
+extern "C" int lasr_model_loss_backward_partial(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
+                                                const int64_t* targets, const int32_t* tgt_lens, int64_t B, int64_t T_in, int64_t S_max,
+                                                float* logp_out, float* loss_out, float* nll_out, int32_t* argmax_out, float* grads,
+                                                void* ws, size_t ws_bytes, int64_t unit_stop, void* stream) {
+  LASR_CHECK_ARG(m && targets && tgt_lens && logp_out && loss_out && nll_out && grads, "lasr_model_loss_backward_partial: null pointer");
+  LASR_CHECK_ARG(unit_stop >= 0 && unit_stop < (int64_t)m->units.size(), "lasr_model_loss_backward_partial: unit_stop");
+  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
+  const Plan& p = m->plan;
+  if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "lasr_model_loss_backward_partial: workspace %zu < %zu", ws_bytes, p.total);
+  LASR_TRY(lasr_model_forward(m, params, buffers, feats, pct, B, T_in, 1, logp_out, argmax_out, ws, ws_bytes, stream));
+  const int C = m->cfg.n_class;
+  LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
+                         nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
+  LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
+  return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream, true, -1, (int)unit_stop);
+}
+
+extern "C" int lasr_model_backward_continue(lasr_model_t* m, const float* params, const void* feats, int64_t B, int64_t T_in, float* grads,
+                                            void* ws, size_t ws_bytes, int64_t unit_stop, void* stream) {
+  LASR_CHECK_ARG(m && params && feats && grads && ws, "lasr_model_backward_continue: null pointer");
+  LASR_CHECK_ARG(m->planned && m->plan.B == B && m->plan.T_in == T_in && m->bwd_next >= 0, "lasr_model_backward_continue: nothing pending");
+  LASR_CHECK_ARG(unit_stop >= 0 && unit_stop <= m->bwd_next, "lasr_model_backward_continue: unit_stop");
+  if (ws_bytes < m->plan.total) return fail(LASR_E_WORKSPACE, "lasr_model_backward_continue: workspace");
+  return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream, false, m->bwd_next, (int)unit_stop);
 }

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
-      for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
+  #pragma unroll 4
+    for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
         float dv[V], yv[V], rv[V];
         Vec<T>::load(dout + r * C + c, dv);
         Vec<T>::load(y + r * C + c, yv);

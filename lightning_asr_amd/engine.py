@@ -211,6 +211,53 @@ class NativeModel:
              _p(grad_logp.contiguous()), B, T_in, _p(self.grads), _p(ws), ws.numel(), _stream())
         return self.grads
 
+    def unit_names(self) -> List[str]:
+        n = self._lib.lasr_model_num_units(self._h)
+        buf = C.create_string_buffer(128)
+        out = []
+        for i in range(n):
+            _lib.check(self._lib.lasr_model_unit_info(self._h, i, buf, 128), "lasr_model_unit_info")
+            out.append(buf.value.decode())
+        return out
+
+    def bucket_schedule(self):
+        """[(unit_stop, lo, hi)] from the LAST bucket to the first: once the backward stage ending at
+        ``unit_stop`` is enqueued, grads[lo:hi] are final and their all-reduce may start.  Only for the plain
+        variant: the context LSTM's parameters sit at the tail of the flat buffer but are differentiated mid-way."""
+        if self.variant != "plain":
+            return [(0, 0, self.n_param)]
+        names = self.unit_names()
+        bounds = self.bucket_bounds()                      # [0, |first_cnn|, |256 blocks|, |512 blocks|, n]
+        first512 = next(i for i, n in enumerate(names) if n == "block3")
+        last = len(names) - 1                              # last_cnn2 (+ decoder head)
+        stops = [last, first512, 1, 0]
+        return [(stops[k], bounds[3 - k], bounds[4 - k]) for k in range(4)]
+
+    def loss_backward_staged(self, feats_btc, pct, targets, tgt_lens, on_bucket, want_argmax: bool = True):
+        """loss_backward in stages; ``on_bucket(lo, hi)`` is called right after the stage that finalises
+        grads[lo:hi] has been enqueued (the data-parallel host starts that bucket's all-reduce there)."""
+        B, T_in, _ = feats_btc.shape
+        S = targets.shape[1]
+        ws = self.workspace(B, T_in, S)
+        T = self.out_frames(T_in)
+        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        am = torch.empty(B, T, dtype=torch.int32, device=self.device) if want_argmax else None
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        nll = torch.empty(B, dtype=torch.float32, device=self.device)
+        sched = self.bucket_schedule()
+        stop0, lo0, hi0 = sched[0]
+        call("lasr_model_loss_backward_partial", self._h, _p(self.params), _p(self.buffers), _p(feats_btc), _p(pct), _p(targets),
+             _p(tgt_lens), B, T_in, S, _p(logp), _p(loss), _p(nll), _p(am), _p(self.grads), _p(ws), ws.numel(), stop0, _stream())
+        on_bucket(lo0, hi0)
+        for stop, lo, hi in sched[1:]:
+            call("lasr_model_backward_continue", self._h, _p(self.params), _p(feats_btc), B, T_in, _p(self.grads), _p(ws), ws.numel(),
+                 stop, _stream())
+            on_bucket(lo, hi)
+        for k in self.counters:
+            self.counters[k] += 1
+        self._last_feats, self._last_logp = feats_btc, logp
+        return loss, nll, logp, am
+
     def loss_backward(self, feats_btc, pct, targets, tgt_lens, want_argmax: bool = True):
         """forward + mean CTC + backward.  Returns (loss (1), nll (B), logp, argmax)."""
         B, T_in, _ = feats_btc.shape

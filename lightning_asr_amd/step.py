@@ -34,6 +34,10 @@ class TrainStep:
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
         self.global_step = 0
+        self.overlap = True        # overlap the gradient all-reduce with backward (world > 1)
+        self._reduced = False
+        # exercise the staged + async all-reduce path on a 1-rank group too (validation on one GPU)
+        self.force_staged = bool(int(__import__("os").environ.get("LASR_FORCE_OVERLAP", "0"))) and torch.distributed.is_initialized()
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP wrap-time broadcast of parameters and buffers from rank 0."""
@@ -48,9 +52,10 @@ class TrainStep:
 
     def optimizer_step(self) -> None:
         m = self.model
-        if self.world > 1:
+        if self.world > 1 and not getattr(self, "_reduced", False):
             # one flat 20 MB SUM all-reduce; the 1/world average is folded into the optimiser's grad scale
             torch.distributed.all_reduce(m.grads, group=self.pg)
+        self._reduced = False
         ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
                           self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         if self.schedule is not None:
@@ -59,7 +64,21 @@ class TrainStep:
         self.global_step += 1
 
     def step_features(self, feats, pct, targets, tgt_lens):
-        loss, nll, logp, am = self.model.loss_backward(feats, pct, targets, tgt_lens)
+        m = self.model
+        if self.overlap and (self.world > 1 or self.force_staged):
+            # bucketed SUM all-reduce, launched bucket by bucket in reverse layer order while the units below
+            # are still being differentiated: RCCL runs on its own stream and waits (event) only for the
+            # kernels enqueued so far; the optimiser waits for all buckets.
+            works = []
+            loss, nll, logp, am = m.loss_backward_staged(
+                feats, pct, targets, tgt_lens,
+                lambda lo, hi: works.append(torch.distributed.all_reduce(m.grads[lo:hi], group=self.pg, async_op=True)))
+            for w in works:
+                w.wait()
+            self._reduced = True
+        else:
+            loss, nll, logp, am = m.loss_backward(feats, pct, targets, tgt_lens)
+            self._reduced = False
         self.optimizer_step()
         return loss, nll, logp, am
 
