@@ -191,48 +191,78 @@ __device__ __forceinline__ void lds_copy4<bf16_t>(bf16_t* dst, const bf16_t* src
 // slides an 8-frame register window over the taps: per tap one new frame and one tap vector are
 // read from LDS for 32 FMAs (the generic kernel above reads 9 vectors for the same work).
 // The taps are zero-padded to kpad = 8*ceil(k/8) so the window rotation unrolls with static indices.
+// Tile staging: every thread first issues ALL its 16-byte global loads (7 in flight for bf16), then
+// writes LDS; tile rows are padded (kTileLd) so the 16 time-lanes of a half-wave hit disjoint banks;
+// in bf16 mode the taps are kept as bf16 in LDS too, which fits 4 workgroups per CU (one full round
+// of the 1024-workgroup grid).
+template <typename T>
+struct S1 {
+  static constexpr int kVec = 16 / sizeof(T);                    // elements per 16-byte global load
+  static constexpr int kLanesPerRow = kCB / kVec;                // 8 (bf16) / 16 (f32)
+  static constexpr int kRowsPerPass = 256 / kLanesPerRow;        // 32 / 16
+  static constexpr int kTileLd = kCB + (sizeof(T) == 2 ? 8 : 0); // elements per LDS row: 144 B (bf16), 256 B (f32)
+  static constexpr int kMaxRows = kTT + kMaxK + 8;
+  static constexpr int kPasses = (kMaxRows + kRowsPerPass - 1) / kRowsPerPass;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_s1_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                         const T* __restrict__ addend, T* __restrict__ y, int64_t Tlen, int64_t C,
                                                         int k, int flip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  using P = S1<T>;
   const int pad = k / 2;
   const int kpad = (k + 7) & ~7;
   const int in_rows = kTT + kpad + 8;
-  float* s_w = reinterpret_cast<float*>(smem_raw);                                  // [kpad][kCB]
-  T* s_x = reinterpret_cast<T*>(smem_raw + (size_t)kpad * kCB * sizeof(float));     // [in_rows][kCB]
+  T* s_w = reinterpret_cast<T*>(smem_raw);                                          // [kpad][kCB] taps in T
+  T* s_x = reinterpret_cast<T*>(smem_raw + (size_t)kpad * kCB * sizeof(T));          // [in_rows][kTileLd]
   const int b = blockIdx.z;
-  const int64_t c0 = (int64_t)blockIdx.y * kCB;
-  const int64_t t0 = (int64_t)blockIdx.x * kTT;
-  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
-  const int64_t c = c0 + cl * 4;
-  const bool c_ok = c < C;
+  const int c0 = blockIdx.y * kCB;
+  const int t0 = blockIdx.x * kTT;
   const T* xb = x + (int64_t)b * Tlen * C;
-  for (int i = threadIdx.x; i < kpad * kCB; i += 256) {
-    const int ch = i / kpad, j = i - ch * kpad;
-    float v = 0.f;
-    if (j < k && c0 + ch < C) v = w[(c0 + ch) * k + (flip ? (k - 1 - j) : j)];
-    s_w[j * kCB + ch] = v;
+  // ---- stage the input tile: all loads first, then the LDS writes
+  {
+    const int lr = threadIdx.x / P::kLanesPerRow, lc = (threadIdx.x % P::kLanesPerRow) * P::kVec;
+    const bool c_in = c0 + lc < C;   // C % kVec == 0 is checked on the host
+    uint4 v[P::kPasses];
+#pragma unroll
+    for (int p = 0; p < P::kPasses; ++p) {
+      const int r = lr + p * P::kRowsPerPass;
+      const int64_t ti = (int64_t)t0 - pad + r;
+      v[p] = make_uint4(0u, 0u, 0u, 0u);
+      if (r < in_rows && c_in && ti >= 0 && ti < Tlen) v[p] = *reinterpret_cast<const uint4*>(xb + ti * C + c0 + lc);
+    }
+#pragma unroll
+    for (int p = 0; p < P::kPasses; ++p) {
+      const int r = lr + p * P::kRowsPerPass;
+      if (r < in_rows) *reinterpret_cast<uint4*>(s_x + (size_t)r * P::kTileLd + lc) = v[p];
+    }
   }
-  const int64_t in0 = t0 - pad;
-  for (int r = tl; r < in_rows; r += 16) {
-    const int64_t ti = in0 + r;
-    lds_copy4<T>(s_x + (size_t)r * kCB + cl * 4, xb + ti * C + c, c_ok && ti >= 0 && ti < Tlen);
+  // taps -> LDS [j][channel]: consecutive lanes take consecutive channels, so the LDS stores are
+  // conflict-free (lanes along j would all hit one bank); the strided global reads stay in L1, each
+  // 128-byte line of w serving 32 consecutive taps of its channel.
+  for (int i = threadIdx.x; i < kpad * kCB; i += 256) {
+    const int j = i >> 6, ch = i & (kCB - 1);
+    float v = 0.f;
+    if (j < k && c0 + ch < C) v = w[(int64_t)(c0 + ch) * k + (flip ? (k - 1 - j) : j)];
+    Elem<T>::st(s_w + j * kCB + ch, v);
   }
   __syncthreads();
 
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int c = c0 + cl * 4;
   float4 acc[kR], win[8];
 #pragma unroll
   for (int r = 0; r < kR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const T* xs = s_x + (size_t)(tl * kR) * kCB + cl * 4;
-  const float* ws = s_w + cl * 4;
+  const T* xs = s_x + (size_t)(tl * kR) * P::kTileLd + cl * 4;
+  const T* ws = s_w + cl * 4;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) win[i] = lds_ld4<T>(xs + (size_t)i * kCB);
+  for (int i = 0; i < 7; ++i) win[i] = lds_ld4<T>(xs + (size_t)i * P::kTileLd);
   for (int j0 = 0; j0 < kpad; j0 += 8) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-      win[(jj + 7) & 7] = lds_ld4<T>(xs + (size_t)(j0 + jj + 7) * kCB);
-      const float4 wv = *reinterpret_cast<const float4*>(ws + (j0 + jj) * kCB);
+      win[(jj + 7) & 7] = lds_ld4<T>(xs + (size_t)(j0 + jj + 7) * P::kTileLd);
+      const float4 wv = lds_ld4<T>(ws + (j0 + jj) * kCB);
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const float4 xv = win[(jj + r) & 7];
@@ -243,10 +273,10 @@ __global__ __launch_bounds__(256) void dwconv_s1_kernel(const T* __restrict__ x,
       }
     }
   }
-  if (!c_ok) return;
+  if (c >= C) return;
 #pragma unroll
   for (int r = 0; r < kR; ++r) {
-    const int64_t t = t0 + tl * kR + r;
+    const int64_t t = (int64_t)t0 + tl * kR + r;
     if (t < Tlen) {
       const int64_t off = ((int64_t)b * Tlen + t) * C + c;
       float o[4] = {acc[r].x, acc[r].y, acc[r].z, acc[r].w};
@@ -360,6 +390,8 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
   LASR_CHECK_SHAPE(k >= 1 && k <= kMaxK && (k & 1) && (stride == 1 || stride == 2) && C % 4 == 0 && B > 0 && B < 65536 && Tin > 0,
                    "lasr_dwconv_fwd: k=%d stride=%d C=%lld", k, stride, (long long)C);
   LASR_CHECK_SHAPE(!(flip && stride != 1), "lasr_dwconv_fwd: flip needs stride 1");
+  LASR_CHECK_SHAPE(stride != 1 || (C % (int64_t)(16 / dtype_size(dtype)) == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0),
+                   "lasr_dwconv_fwd: the stride-1 kernel loads 16-byte channel vectors (C=%lld)", (long long)C);
   const int64_t Tout = conv_out_len(Tin, k, stride);
   const int in_rows = (kTT - 1) * stride + k;
   const size_t shmem = ((size_t)in_rows + k) * kCB * sizeof(float);
@@ -368,7 +400,8 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
                              (double)B * (Tin + Tout * (addend ? 2 : 1)) * C * dtype_size(dtype));
   if (stride == 1) {
     const int kpad = (k + 7) & ~7;
-    const size_t sh1 = (size_t)kpad * kCB * sizeof(float) + (size_t)(kTT + kpad + 8) * kCB * dtype_size(dtype);
+    const size_t esz1 = dtype_size(dtype);
+    const size_t sh1 = (size_t)kpad * kCB * esz1 + (size_t)(kTT + kpad + 8) * (kCB + (esz1 == 2 ? 8 : 0)) * esz1;
     if (dtype == LASR_F32) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(dwconv_s1_kernel<float>, grid, dim3(256), sh1, as_stream(stream), (const float*)x, w, (const float*)addend,

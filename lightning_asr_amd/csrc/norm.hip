@@ -127,7 +127,7 @@ __device__ __forceinline__ float act_grad(float p, int act) {
 
 struct ColGeom { int cv, col_threads, row_lanes, cl, rl; };
 template <int V>
-__device__ __forceinline__ ColGeom col_geom(int64_t C) {
+__device__ __forceinline__ ColGeom col_geom(int C) {
   ColGeom g;
   g.cv = (int)(C / V);
   g.col_threads = g.cv < 256 ? g.cv : 256;
@@ -141,39 +141,44 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                          const T* __restrict__ y2, const float* __restrict__ coef2,
                                                          const float* __restrict__ se, T* __restrict__ out,
-                                                         int64_t rows, int64_t Tt, int64_t C, int act) {
+                                                         int rows, int Tt, int C, int act) {
   constexpr int V = Vec<T>::kN;
   const ColGeom g = col_geom<V>(C);
   if (g.rl >= g.row_lanes) return;
-  const int64_t r0 = (int64_t)blockIdx.x * kFwdRows;
-  const int64_t r1 = r0 + kFwdRows < rows ? r0 + kFwdRows : rows;
+  const int r0 = blockIdx.x * kFwdRows;
+  const int r1 = min(r0 + kFwdRows, rows);
   for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
-    const int64_t c = (int64_t)cvi * V;
+    const int c = cvi * V;
     float a[V], b[V], a2[V], b2[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       a[j] = coef[c + j]; b[j] = coef[C + c + j];
       a2[j] = y2 ? coef2[c + j] : 0.f; b2[j] = y2 ? coef2[C + c + j] : 0.f;
     }
-    for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
+    // 32-bit element offsets (host checks rows*C < 2^31); the utterance index is stepped, never divided
+    int ub = (r0 + g.rl) / Tt, ut = (r0 + g.rl) - ub * Tt;
+    for (int r = r0 + g.rl; r < r1; r += g.row_lanes) {
+      const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
       float v[V], o[V];
-      Vec<T>::load(y + r * C + c, v);
+      Vec<T>::load(y + off, v);
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = fmaf(v[j], a[j], b[j]);
       if (se) {
-        const float* sp = se + (r / Tt) * C + c;
+        const float* sp = se + (uint32_t)ub * (uint32_t)C + (uint32_t)c;
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] *= sp[j];
       }
       if (y2) {
         float w[V];
-        Vec<T>::load(y2 + r * C + c, w);
+        Vec<T>::load(y2 + off, w);
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] += fmaf(w[j], a2[j], b2[j]);
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = act_fwd(o[j], act);
-      Vec<T>::store(out + r * C + c, o);
+      Vec<T>::store(out + off, o);
+      ut += g.row_lanes;
+      while (ut >= Tt) { ut -= Tt; ++ub; }
     }
   }
 }
@@ -185,16 +190,16 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
                                                            const T* __restrict__ y2, const float* __restrict__ coef2,
                                                            const float* __restrict__ saved2, const float* __restrict__ se,
                                                            const float* __restrict__ seg, float* __restrict__ partials,
-                                                           int64_t rows, int64_t Tt, int64_t C, int act) {
+                                                           int rows, int Tt, int C, int act) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [row_lanes][4][C]
   constexpr int V = Vec<T>::kN;
   const ColGeom g = col_geom<V>(C);
-  const int64_t r0 = (int64_t)blockIdx.x * kRowsPerBlock;
-  const int64_t r1 = r0 + kRowsPerBlock < rows ? r0 + kRowsPerBlock : rows;
+  const int r0 = blockIdx.x * kRowsPerBlock;
+  const int r1 = min(r0 + kRowsPerBlock, rows);
   const bool has2 = y2 != nullptr;
   if (g.rl < g.row_lanes) {
     for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
-      const int64_t c = (int64_t)cvi * V;
+      const int c = cvi * V;
       float a1[V], b1[V], m1[V], q1[V], a2[V], b2[V], m2[V], q2[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -207,14 +212,17 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
-  #pragma unroll 4
-    for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
+      int ub = (r0 + g.rl) / Tt, ut = (r0 + g.rl) - ub * Tt;
+      for (int r = r0 + g.rl; r < r1; r += g.row_lanes) {
+        const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
         float dv[V], yv[V], rv[V];
-        Vec<T>::load(dout + r * C + c, dv);
-        Vec<T>::load(y + r * C + c, yv);
-        if (has2) Vec<T>::load(y2 + r * C + c, rv);
-        const float* sp = se ? se + (r / Tt) * C + c : nullptr;
-        const float* gp = (se && seg) ? seg + (r / Tt) * C + c : nullptr;
+        Vec<T>::load(dout + off, dv);
+        Vec<T>::load(y + off, yv);
+        if (has2) Vec<T>::load(y2 + off, rv);
+        const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+        const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+        ut += g.row_lanes;
+        while (ut >= Tt) { ut -= Tt; ++ub; }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
           const float sej = sp ? sp[j] : 1.f;
@@ -232,14 +240,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int j = 0; j < V; ++j) s_part[((int64_t)g.rl * 4 + k) * C + c + j] = acc[k][j];
+        for (int j = 0; j < V; ++j) s_part[(g.rl * 4 + k) * C + c + j] = acc[k][j];
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 4 * C; i += 256) {
     float s = 0.f;
-    for (int l = 0; l < g.row_lanes; ++l) s += s_part[(int64_t)l * 4 * C + i];
-    partials[(int64_t)blockIdx.x * 4 * C + i] = s;
+    for (int l = 0; l < g.row_lanes; ++l) s += s_part[l * 4 * C + i];
+    partials[(size_t)blockIdx.x * 4 * C + i] = s;
   }
 }
 
@@ -254,16 +262,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sums2, const int32_t* __restrict__ row_lens,
                                                            T* __restrict__ dy, T* __restrict__ dy2, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, float* __restrict__ dgamma2,
-                                                           float* __restrict__ dbeta2, int64_t rows, int64_t Tt, int64_t C, int act) {
+                                                           float* __restrict__ dbeta2, int rows, int Tt, int C, int act) {
   constexpr int V = Vec<T>::kN;
   const ColGeom g = col_geom<V>(C);
   if (g.rl >= g.row_lanes) return;
-  const int64_t r0 = (int64_t)blockIdx.x * kFwdRows;
-  const int64_t r1 = r0 + kFwdRows < rows ? r0 + kFwdRows : rows;
+  const int r0 = blockIdx.x * kFwdRows;
+  const int r1 = min(r0 + kFwdRows, rows);
   const float inv_n = 1.0f / (float)rows;
   const bool has2 = y2 != nullptr;
   for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
-    const int64_t c = (int64_t)cvi * V;
+    const int c = cvi * V;
     float a1[V], b1[V], m1[V], q1[V], g1[V], u1[V], w1[V], a2[V], b2[V], m2[V], q2[V], g2[V], u2[V], w2[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -282,15 +290,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         if (has2 && dgamma2) dgamma2[c + j] = sums2[C + c + j];
       }
     }
-    for (int64_t r = r0 + g.rl; r < r1; r += g.row_lanes) {
-      const int64_t b = r / Tt;
-      const bool masked = row_lens && (r - b * Tt) >= row_lens[b];
+    int ub = (r0 + g.rl) / Tt, ut = (r0 + g.rl) - ub * Tt;
+    for (int r = r0 + g.rl; r < r1; r += g.row_lanes) {
+      const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
+      const bool masked = row_lens && ut >= row_lens[ub];
       float dv[V], yv[V], rv[V], o1[V], o2[V];
-      Vec<T>::load(dout + r * C + c, dv);
-      Vec<T>::load(y + r * C + c, yv);
-      if (has2) Vec<T>::load(y2 + r * C + c, rv);
-      const float* sp = se ? se + b * C + c : nullptr;
-      const float* gp = (se && seg) ? seg + b * C + c : nullptr;
+      Vec<T>::load(dout + off, dv);
+      Vec<T>::load(y + off, yv);
+      if (has2) Vec<T>::load(y2 + off, rv);
+      const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+      const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+      ut += g.row_lanes;
+      while (ut >= Tt) { ut -= Tt; ++ub; }
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         const float sej = sp ? sp[j] : 1.f;
@@ -300,8 +311,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         o1[j] = masked ? 0.f : g1[j] * (d1 - u1[j] - (yv[j] - m1[j]) * q1[j] * w1[j]);
         o2[j] = g2[j] * (d - u2[j] - (rv[j] - m2[j]) * q2[j] * w2[j]);
       }
-      Vec<T>::store(dy + r * C + c, o1);
-      if (has2) Vec<T>::store(dy2 + r * C + c, o2);
+      Vec<T>::store(dy + off, o1);
+      if (has2) Vec<T>::store(dy2 + off, o2);
     }
   }
 }
@@ -354,6 +365,7 @@ static int check_bn_shape(const char* who, int dtype, int64_t B, int64_t T_, int
   const int v = dtype == LASR_F32 ? 4 : 8;
   LASR_CHECK_SHAPE(C % v == 0 && C <= 4096 && B > 0 && T_ > 0, "%s: C=%lld must be a multiple of %d (16-byte channel vectors)", who,
                    (long long)C, v);
+  LASR_CHECK_SHAPE(B * T_ * C < ((int64_t)1 << 31), "%s: tensor exceeds the kernels' 32-bit element offsets", who);
   return 0;
 }
 
@@ -363,7 +375,7 @@ extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2,
   LASR_TRY(check_bn_shape("lasr_bn_act_fwd", dtype, B, T_, C));
   const int64_t rows = B * T_;
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)cdiv(rows, kFwdRows)), dim3(256), 0, as_stream(stream),
-                                           (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, rows, T_, C, act));
+                                           (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows, (int)T_, (int)C, act));
   LASR_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
 }
@@ -390,7 +402,7 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
   float* partials = reinterpret_cast<float*>(workspace);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nblk), dim3(256), shmem, as_stream(stream), (const T*)dout,
                                            (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad, partials,
-                                           rows, T_, C, act));
+                                           (int)rows, (int)T_, (int)C, act));
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
   return launch_reduce_partials(partials, nblk, 4 * C, sums, 2 * C, sums2, as_stream(stream));
 }
@@ -408,7 +420,7 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)cdiv(rows, kFwdRows)), dim3(256), 0, as_stream(stream),
                                            (const T*)dout, (const T*)y, coef, saved, gamma, (const T*)y2, coef2, saved2, gamma2,
                                            se_scale, se_grad, sums, sums2, row_lens, (T*)dy, (T*)dy2, dgamma, dbeta, dgamma2, dbeta2,
-                                           rows, T_, C, act));
+                                           (int)rows, (int)T_, (int)C, act));
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;
 }
