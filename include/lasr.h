@@ -97,6 +97,18 @@ int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, 
               const int32_t* row_lens, int64_t rows_per_seq, float* stats, int split_k, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* One or two independent GEMMs of the same kind (dtypes, transposition, split_k) in ONE launch: a unit's
+ * main + residual 1x1 convolution (models/QuartNet.py:31 and :63), their two data gradients or their two
+ * weight gradients.  Same semantics per problem as lasr_gemm (no addend).                              */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int64_t M, N, K;
+  const float* bias; const int32_t* row_lens; int64_t rows_per_seq; float* stats;
+} lasr_gemm_problem;
+size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs, int n_probs, int split_k);
+int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
+                    int split_k, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Training-mode BatchNorm1d(eps) statistics -> affine coefficients (models/QuartNet.py:24,35):
  * mean = s/n, var = q/n - mean^2 (biased); coef[c] = gamma*rstd, coef[C+c] = beta - mean*gamma*rstd;
  * saved[c] = mean, saved[C+c] = rstd; running_mean/var updated with momentum (unbiased var) when

@@ -301,3 +301,81 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
   }
   return 0;
 }
+
+// ---- two independent problems in one launch (bf16 operands); anything else runs them one by one ----
+extern "C" size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs, int n_probs, int split_k) {
+  size_t b = 0;
+  for (int i = 0; i < n_probs; ++i) b += lasr_gemm_workspace_bytes(probs[i].M, probs[i].N, split_k, probs[i].stats != nullptr);
+  return b;
+}
+
+extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
+                               int split_k, void* workspace, size_t workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(probs && n_probs >= 1 && n_probs <= 2, "lasr_gemm_batch: 1 or 2 problems");
+  const size_t need = lasr_gemm_batch_workspace_bytes(probs, n_probs, split_k);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return fail(LASR_E_WORKSPACE, "lasr_gemm_batch: workspace %zu < %zu", workspace_bytes, need);
+  char* wsp = reinterpret_cast<char*>(workspace);
+  if (dtype_ab != LASR_BF16 || n_probs == 1 || getenv("LASR_NO_GEMM_BATCH")) {
+    for (int i = 0; i < n_probs; ++i) {
+      const lasr_gemm_problem& q = probs[i];
+      const size_t nb = lasr_gemm_workspace_bytes(q.M, q.N, split_k, q.stats != nullptr);
+      LASR_TRY(lasr_gemm(q.A, q.B, q.C, dtype_ab, dtype_c, q.M, q.N, q.K, transA, transB, q.bias, nullptr, q.row_lens, q.rows_per_seq,
+                         q.stats, split_k, wsp, nb, stream));
+      wsp += nb;
+    }
+    return 0;
+  }
+  LASR_CHECK_ARG(dtype_c == LASR_F32 || dtype_c == LASR_BF16, "lasr_gemm_batch: bad dtype");
+  GemmArgs g[2];
+  dim3 grids[2];
+  int splits[2];
+  for (int i = 0; i < 2; ++i) {
+    const lasr_gemm_problem& q = probs[i];
+    LASR_CHECK_ARG(q.A && q.B && q.C, "lasr_gemm_batch: null pointer");
+    LASR_CHECK_SHAPE(q.M > 0 && q.N > 0 && q.K > 0 && split_k >= 1 && split_k <= 1024, "lasr_gemm_batch: shape");
+    LASR_CHECK_ARG(!(q.row_lens && q.rows_per_seq <= 0) && !(split_k > 1 && (q.row_lens || q.stats)), "lasr_gemm_batch: epilogue options");
+    GemmArgs& a = g[i];
+    a.A = q.A; a.B = q.B; a.C = q.C; a.M = q.M; a.N = q.N; a.K = q.K;
+    a.lda = transA ? q.M : q.K; a.ldb = transB ? q.N : q.K; a.ldc = q.N;
+    a.bias = q.bias; a.addend = nullptr; a.row_lens = q.row_lens; a.rows_per_seq = q.rows_per_seq;
+    a.stat_partials = nullptr; a.split_ws = nullptr;
+    a.vecA = (a.lda % 8 == 0) && (reinterpret_cast<uintptr_t>(q.A) % 16 == 0);
+    a.vecB = (a.ldb % 8 == 0) && (reinterpret_cast<uintptr_t>(q.B) % 16 == 0);
+    int sk = split_k;
+    if (split_k > 1) {
+      a.split_ws = reinterpret_cast<float*>(wsp);
+      wsp += align_up((size_t)split_k * q.M * q.N * sizeof(float), 256);
+      const int64_t per = cdiv(cdiv(q.K, split_k), 64) * 64;
+      a.k_per_split = per;
+      sk = (int)cdiv(q.K, per);
+    } else {
+      a.k_per_split = q.K;
+    }
+    if (q.stats) { a.stat_partials = reinterpret_cast<float*>(wsp); wsp += align_up((size_t)cdiv(q.M, BM) * 2 * q.N * sizeof(float), 256); }
+    splits[i] = sk;
+    grids[i] = dim3((unsigned)cdiv(q.N, BN), (unsigned)cdiv(q.M, BM), (unsigned)sk);
+  }
+  hipStream_t st = as_stream(stream);
+  double fl = 0, by = 0;
+  for (int i = 0; i < 2; ++i) {
+    fl += 2.0 * (double)probs[i].M * probs[i].N * probs[i].K;
+    by += (double)(probs[i].M * probs[i].K + probs[i].N * probs[i].K) * 2 + (double)probs[i].M * probs[i].N * dtype_size(dtype_c);
+  }
+  const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
+  const int rc = launch_gemm_bf16_batch(g, grids, 2, dtype_c, transA, transB, st);
+  prof_end(tok, st);
+  if (rc) return rc;
+  for (int i = 0; i < 2; ++i) {
+    const lasr_gemm_problem& q = probs[i];
+    if (g[i].split_ws) {
+      const int64_t mn = q.M * q.N;
+      if (dtype_c == LASR_F32)
+        hipLaunchKernelGGL(gemm_split_reduce_kernel<float>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const float*)nullptr, (float*)q.C);
+      else
+        hipLaunchKernelGGL(gemm_split_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const bf16_t*)nullptr, (bf16_t*)q.C);
+      LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
+    }
+    if (q.stats) LASR_TRY(launch_reduce_partials(g[i].stat_partials, (int)cdiv(q.M, BM), 2 * q.N, q.stats, 2 * q.N, nullptr, st));
+  }
+  return 0;
+}

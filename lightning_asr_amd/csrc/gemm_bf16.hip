@@ -36,6 +36,10 @@ struct Bf16Args {
   int gm, gn, gz;      // tile grid
   int vecA, vecB, vecC;
 };
+// Up to two independent problems of the same kind in ONE launch (a unit's main + residual 1x1 conv, or
+// their two weight gradients): twice the workgroups per launch keeps two per CU resident for the
+// split-K weight gradients (256 tiles each) and lets one problem's store tail overlap the other's loads.
+struct Bf16Batch { Bf16Args p[2]; int tiles0, total; };
 
 // ---- global -> registers: 4 x 16 B per thread per operand tile ------------------------------------
 template <bool TRANS>
@@ -121,7 +125,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 }
 
 template <typename TC, bool TRANS_A, bool TRANS_B>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args g) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
   __shared__ __attribute__((aligned(16))) char smem[2 * OPER_BYTES];
   __shared__ float s_stat[2][2][TN];
   __shared__ float s_keep[TM];
@@ -129,7 +133,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args g) {
   char* sB = smem + OPER_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int lid = xcd_remap(blockIdx.x, g.gm * g.gn * g.gz);
+  const int lid_all = xcd_remap(blockIdx.x, gb.total);
+  const bool second = lid_all >= gb.tiles0;              // workgroup-uniform
+  const Bf16Args& g = second ? gb.p[1] : gb.p[0];
+  const int lid = second ? lid_all - gb.tiles0 : lid_all;
   const int tn = lid % g.gn, tm = (lid / g.gn) % g.gm, tz = lid / (g.gn * g.gm);
   const int m0 = tm * TM, n0 = tn * TN;
   const int kbeg = tz * g.k_per_split;
@@ -277,12 +284,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Args g) {
   }
 }
 
-int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim3 grid, hipStream_t st) {
+static int fill_args(Bf16Args& a, const GemmArgs& g, dim3 grid) {
   const int64_t lim = (int64_t)1 << 31;
   if (g.M * g.lda >= lim || g.K * g.lda >= lim || g.N * g.ldb >= lim || g.K * g.ldb >= lim || g.M * g.ldc >= lim ||
-      (int64_t)grid.x * grid.y * grid.z >= lim)
+      (int64_t)grid.x * grid.y * grid.z >= lim / 2)
     return fail(LASR_E_SHAPE, "lasr_gemm(bf16): matrix exceeds the kernel's 32-bit element offsets");
-  Bf16Args a;
   a.A = reinterpret_cast<const bf16_t*>(g.A); a.B = reinterpret_cast<const bf16_t*>(g.B); a.C = g.C;
   a.bias = g.bias; a.row_lens = g.row_lens; a.stat_partials = g.stat_partials; a.split_ws = g.split_ws;
   a.M = (int)g.M; a.N = (int)g.N; a.K = (int)g.K; a.lda = (int)g.lda; a.ldb = (int)g.ldb; a.ldc = (int)g.ldc;
@@ -290,8 +296,20 @@ int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim
   a.gn = (int)grid.x; a.gm = (int)grid.y; a.gz = (int)grid.z;
   a.vecA = g.vecA; a.vecB = g.vecB;
   a.vecC = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0);
-  const dim3 grid1((unsigned)(a.gn * a.gm * a.gz));
-#define LASR_BF16_CASE(TC_, TA_, TB_) hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_>), grid1, dim3(256), 0, st, a)
+  return 0;
+}
+
+// g[0..n): problems sharing dtype_c / transposition; grids[i] = (gn, gm, gz) of problem i
+int launch_gemm_bf16_batch(const GemmArgs* g, const dim3* grids, int n, int dtype_c, int transA, int transB, hipStream_t st) {
+  Bf16Batch b;
+  LASR_TRY(fill_args(b.p[0], g[0], grids[0]));
+  b.p[1] = b.p[0];
+  if (n > 1) LASR_TRY(fill_args(b.p[1], g[1], grids[1]));
+  b.tiles0 = b.p[0].gn * b.p[0].gm * b.p[0].gz;
+  b.total = b.tiles0 + (n > 1 ? b.p[1].gn * b.p[1].gm * b.p[1].gz : 0);
+  const dim3 grid1((unsigned)b.total);
+  const bool f32_out = dtype_c == LASR_F32 || g[0].split_ws != nullptr;   // split-K slabs are f32
+#define LASR_BF16_CASE(TC_, TA_, TB_) hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_>), grid1, dim3(256), 0, st, b)
 #define LASR_BF16_TC(TC_)                                         \
   do {                                                            \
     if (!transA && !transB) LASR_BF16_CASE(TC_, false, false);    \
@@ -299,11 +317,15 @@ int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim
     else if (transA && !transB) LASR_BF16_CASE(TC_, true, false); \
     else LASR_BF16_CASE(TC_, true, true);                         \
   } while (0)
-  if (dtype_c == LASR_F32 || g.split_ws) LASR_BF16_TC(float); else LASR_BF16_TC(bf16_t);   // split-K slabs are f32
+  if (f32_out) LASR_BF16_TC(float); else LASR_BF16_TC(bf16_t);
 #undef LASR_BF16_TC
 #undef LASR_BF16_CASE
   LASR_LAUNCH_CHECK("gemm_bf16_kernel");
   return 0;
+}
+
+int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim3 grid, hipStream_t st) {
+  return launch_gemm_bf16_batch(&g, &grid, 1, dtype_c, transA, transB, st);
 }
 
 }  // namespace lasr

@@ -211,9 +211,9 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
       scratch = std::max(scratch, lasr_se_bwd_workspace_bytes(B, u.co));
     }
     cmax = std::max<int64_t>(cmax, std::max(u.ci, u.co));
-    scratch = std::max(scratch, lasr_gemm_workspace_bytes(N, u.co, 1, 1));
+    scratch = std::max(scratch, 2 * lasr_gemm_workspace_bytes(N, u.co, 1, 1));
     scratch = std::max(scratch, lasr_bn_bwd_workspace_bytes(B, p.T, u.co));
-    scratch = std::max(scratch, lasr_gemm_workspace_bytes(u.co, u.ci, 16, 0));
+    scratch = std::max(scratch, 2 * lasr_gemm_workspace_bytes(u.co, u.ci, 16, 0));
     if (u.has_dw) scratch = std::max(scratch, lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k));
   }
   const int64_t C = m->cfg.n_class;
@@ -346,18 +346,19 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
       gin = at(ws, u.o_u);
     }
     float* stats = training ? atf(ws, u.o_stats) : nullptr;
-    LASR_TRY(lasr_gemm(gin, wptr(m, params, ws, u.w_pw), at(ws, u.o_y), dt, dt, N, u.co, u.ci, 0, 0, nullptr, nullptr,
-                       u.masked ? lens : nullptr, T, stats, 1, scratch, p.scratch_bytes, stream));
+    float* stats2 = (training && u.has_res) ? atf(ws, u.o_stats2) : nullptr;
+    {  // main 1x1 (masked, BN sums) and, for residual blocks, the residual 1x1 (never masked) in one launch
+      lasr_gemm_problem pr[2];
+      pr[0] = {gin, wptr(m, params, ws, u.w_pw), at(ws, u.o_y), N, u.co, u.ci, nullptr, u.masked ? lens : nullptr, T, stats};
+      if (u.has_res) pr[1] = {x, wptr(m, params, ws, u.w_res), at(ws, u.o_y2), N, u.co, u.ci, nullptr, nullptr, 0, stats2};
+      LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
+    }
     LASR_TRY(lasr_bn_finalize(stats, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
                               atf(ws, u.o_coef), atf(ws, u.o_saved), u.co, N, kBnEps, kBnMom, training, stream));
-    if (u.has_res) {
-      float* stats2 = training ? atf(ws, u.o_stats2) : nullptr;
-      LASR_TRY(lasr_gemm(x, wptr(m, params, ws, u.w_res), at(ws, u.o_y2), dt, dt, N, u.co, u.ci, 0, 0, nullptr, nullptr, nullptr, 0,
-                         stats2, 1, scratch, p.scratch_bytes, stream));
+    if (u.has_res)
       LASR_TRY(lasr_bn_finalize(stats2, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
                                 buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
                                 training, stream));
-    }
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
       LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
       LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
@@ -431,28 +432,32 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                                    se_grad, atf(ws, p.o_sums), atf(ws, p.o_sums2), u.masked ? lens : nullptr, dy, dy2,
                                    grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
                                    u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, stream));
-    // main 1x1: dW[co][ci] = dy^T gin
+    // weight gradients of the main and residual 1x1: dW[co][ci] = dy^T gin, dWr = dy2^T x  (one split-K launch)
     const void* gin = u.has_dw ? at(ws, u.o_u) : x_in;
-    LASR_TRY(lasr_gemm(dy, gin, grads + u.w_pw, dt, LASR_F32, u.co, u.ci, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16, scratch,
-                       sb, stream));
+    {
+      lasr_gemm_problem pr[2];
+      pr[0] = {dy, gin, grads + u.w_pw, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
+      if (u.has_res) pr[1] = {dy2, x_in, grads + u.w_res, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
+      LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, 16, scratch, sb, stream));
+    }
     const bool need_dx = ui > 0;
     void* dx = at(ws, p.o_g[cur ^ 1]);
-    if (u.has_res) {  // residual 1x1: dWr = dy2^T x ; dx_res = dy2 Wr
-      LASR_TRY(lasr_gemm(dy2, x_in, grads + u.w_res, dt, LASR_F32, u.co, u.ci, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16,
-                         scratch, sb, stream));
-      if (need_dx)
-        LASR_TRY(lasr_gemm(dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), dt, dt, N, u.ci, u.co, 0, 1, nullptr, nullptr, nullptr,
-                           0, nullptr, 1, scratch, sb, stream));
-    }
     if (u.has_dw) {
-      // d(dw output) = dy Wp ; depthwise dW from (x, du) ; dx = flipped depthwise conv of du (+ residual dx)
-      LASR_TRY(lasr_gemm(dy, wptr(m, params, ws, u.w_pw), at(ws, p.o_du), dt, dt, N, u.ci, u.co, 0, 1, nullptr, nullptr, nullptr, 0,
-                         nullptr, 1, scratch, sb, stream));
+      // data gradients: d(dw output) = dy Wp and, for residual blocks, dx_res = dy2 Wr (one launch)
+      lasr_gemm_problem pr[2];
+      pr[0] = {dy, wptr(m, params, ws, u.w_pw), at(ws, p.o_du), N, u.ci, u.co, nullptr, nullptr, 0, nullptr};
+      const bool with_res = u.has_res && need_dx;
+      if (with_res) pr[1] = {dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), N, u.ci, u.co, nullptr, nullptr, 0, nullptr};
+      LASR_TRY(lasr_gemm_batch(pr, with_res ? 2 : 1, dt, dt, 0, 1, 1, scratch, sb, stream));
+      // depthwise dW from (x, du); dx = flipped depthwise conv of du (+ residual dx)
       LASR_TRY(lasr_dwconv_wgrad(x_in, at(ws, p.o_du), grads + u.w_dw, dt, B, Tx, u.ci, u.k, u.stride, scratch, sb, stream));
       if (need_dx)
         LASR_TRY(lasr_dwconv_fwd(at(ws, p.o_du), params + u.w_dw, u.has_res ? at(ws, p.o_dxr) : nullptr, dx, dt, B, T, u.ci, u.k, 1,
                                  1, stream));
     } else if (need_dx) {
+      if (u.has_res)
+        LASR_TRY(lasr_gemm(dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), dt, dt, N, u.ci, u.co, 0, 1, nullptr, nullptr, nullptr,
+                           0, nullptr, 1, scratch, sb, stream));
       LASR_TRY(lasr_gemm(dy, wptr(m, params, ws, u.w_pw), dx, dt, dt, N, u.ci, u.co, 0, 1, nullptr, u.has_res ? at(ws, p.o_dxr) : nullptr,
                          nullptr, 0, nullptr, 1, scratch, sb, stream));
     }

@@ -134,13 +134,56 @@ class MyAudioDataset(Dataset):
         return len(self.datasets)
 
 
+class BucketBatchSampler(torch.utils.data.Sampler):
+    """Length-bucketed batches (BASELINE config 5; not in the reference, which pads to the batch's
+    longest clip, data_module.py:225-230): utterances are sorted by duration inside shuffled mega-chunks
+    of ``bucket_batches`` batches, so padding inside a batch stays small; batch order is reshuffled
+    every epoch.  Data-parallel ranks take disjoint batches (rank::world)."""
+
+    def __init__(self, durations, batch_size: int, bucket_batches: int = 50, shuffle: bool = True, drop_last: bool = True,
+                 seed: int = 0, rank: int = 0, world: int = 1):
+        self.durations = list(durations)
+        self.batch_size, self.bucket_batches = batch_size, bucket_batches
+        self.shuffle, self.drop_last, self.seed, self.rank, self.world = shuffle, drop_last, seed, rank, world
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def _batches(self):
+        n = len(self.durations)
+        rng = random.Random(self.seed + self.epoch)
+        idx = list(range(n))
+        if self.shuffle:
+            rng.shuffle(idx)
+        chunk = self.batch_size * self.bucket_batches
+        batches = []
+        for i in range(0, n, chunk):
+            part = sorted(idx[i:i + chunk], key=lambda j: self.durations[j])
+            for k in range(0, len(part), self.batch_size):
+                b = part[k:k + self.batch_size]
+                if len(b) == self.batch_size or not self.drop_last:
+                    batches.append(b)
+        if self.shuffle:
+            rng.shuffle(batches)
+        usable = len(batches) - len(batches) % self.world if self.world > 1 else len(batches)
+        return batches[:usable][self.rank::self.world]
+
+    def __iter__(self):
+        return iter(self._batches())
+
+    def __len__(self):
+        return len(self._batches())
+
+
 class WaveBatch(tuple):
     """(waves list, targets (B,Smax) int64, target_sizes (B) int32, paths, mask flag) from the workers."""
 
 
 class LibriDataModule(LightningDataModule):
     def __init__(self, train_manifest, dev_manifest, test_manifest, labels: list, train_bs=16, dev_bs=16, num_worker=0,
-                 train_max_duration=16.7, dev_max_duration=40, device="cuda", act_dtype=torch.float32):
+                 train_max_duration=16.7, dev_max_duration=40, device="cuda", act_dtype=torch.float32,
+                 bucket_by_length: bool = False):
         super().__init__()
         as_list = lambda m: list(m) if isinstance(m, (list, tuple)) else [m]  # noqa: E731
         self.train_manifest, self.dev_manifest, self.test_manifest = as_list(train_manifest), as_list(dev_manifest), as_list(test_manifest)
@@ -150,6 +193,7 @@ class LibriDataModule(LightningDataModule):
         self.train_max_duration, self.dev_max_duration = train_max_duration, dev_max_duration
         self.audio_parser = AudioParser(device=device)
         self.audio_parser.act_dtype = act_dtype
+        self.bucket_by_length = bucket_by_length
 
     def setup(self, stage=None):
         self.train_datasets = MyAudioDataset(self.train_manifest, self.labels, mask=True, max_duration=self.train_max_duration)
@@ -157,6 +201,10 @@ class LibriDataModule(LightningDataModule):
         self.test_datasets = MyAudioDataset(self.test_manifest, self.labels, max_duration=self.dev_max_duration)
 
     def _loader(self, ds, bs, train, distributed=None):
+        if train and getattr(self, "bucket_by_length", False):
+            world, rank = distributed if distributed is not None else (1, 0)
+            bs_ = BucketBatchSampler([d["duration"] for d in ds.datasets], bs, rank=rank, world=world)
+            return DataLoader(ds, batch_sampler=bs_, num_workers=self.num_worker, collate_fn=self._collate_train)
         sampler = None
         if distributed is not None:
             from torch.utils.data.distributed import DistributedSampler

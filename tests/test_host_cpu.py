@@ -146,3 +146,24 @@ def test_grad_sync_world_size_2_gloo():
     expect = (torch.arange(10, dtype=torch.float32) * 1.5).tolist()       # mean of x*1 and x*2
     for rank, vals, world in res:
         assert world == 2 and vals == pytest.approx(expect)
+
+
+def test_bucket_batch_sampler_padding_and_sharding():
+    from lightning_asr_amd.data_module import BucketBatchSampler
+    rng = np.random.default_rng(0)
+    dur = rng.uniform(2.0, 16.0, 1000).tolist()
+    s = BucketBatchSampler(dur, 32, bucket_batches=10, seed=1)
+    batches = list(s)
+    assert len(batches) == len(s) == 31 and all(len(b) == 32 for b in batches)
+    flat = [i for b in batches for i in b]
+    assert len(set(flat)) == len(flat)                               # no utterance twice in an epoch
+    waste = np.mean([1 - np.sum([dur[i] for i in b]) / (32 * max(dur[i] for i in b)) for b in batches])
+    assert waste < 0.10                                              # bucketed padding <= 10 % (BASELINE cfg5)
+    rand = [list(range(i, i + 32)) for i in range(0, 992, 32)]
+    assert waste < 0.3 * np.mean([1 - np.sum([dur[i] for i in b]) / (32 * max(dur[i] for i in b)) for b in rand])
+    s.set_epoch(1)
+    assert list(s) != batches                                        # reshuffled per epoch
+    a = BucketBatchSampler(dur, 32, bucket_batches=10, seed=1, rank=0, world=2)
+    b = BucketBatchSampler(dur, 32, bucket_batches=10, seed=1, rank=1, world=2)
+    la, lb = list(a), list(b)
+    assert len(la) == len(lb) == 15 and not ({i for x in la for i in x} & {i for x in lb for i in x})
