@@ -144,7 +144,8 @@ int lasr_bn_act_bwd_apply(const void* dout, const void* y, const float* coef,
                           const float* se_grad, const float* sums, const float* sums2,
                           const int32_t* row_lens, void* dy, void* dy2, float* dgamma, float* dbeta,
                           float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T, int64_t C, int act,
-                          void* stream);
+                          void* workspace, size_t workspace_bytes, void* stream);
+size_t lasr_bn_bwd_apply_workspace_bytes(int64_t C);   /* folded per-channel constants, 10*C f32 */
 
 /* ---------------------------------------------------------------- SE + BiLSTM context --------
  * models/QuartNetContextSE.py:8-23,55  SELayer(reduction=8, no bias): s = sigmoid(W2 relu(W1 mean_T(BN(y)))),

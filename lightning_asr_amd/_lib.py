@@ -41,7 +41,8 @@ SIGNATURES = {
     "lasr_bn_act_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i64, _i32, _p]),
     "lasr_bn_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lasr_bn_act_bwd_stats": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),
-    "lasr_bn_act_bwd_apply": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p]),
+    "lasr_bn_act_bwd_apply": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),
+    "lasr_bn_bwd_apply_workspace_bytes": (_sz, [_i64]),
     "lasr_seqsum": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p]),
     "lasr_se_fwd": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p]),
     "lasr_se_bwd_workspace_bytes": (_sz, [_i64, _i64]),

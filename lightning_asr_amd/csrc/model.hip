@@ -431,7 +431,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                                    u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, se_scale,
                                    se_grad, atf(ws, p.o_sums), atf(ws, p.o_sums2), u.masked ? lens : nullptr, dy, dy2,
                                    grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
-                                   u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, stream));
+                                   u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, scratch, sb, stream));
     // weight gradients of the main and residual 1x1: dW[co][ci] = dy^T gin, dWr = dy2^T x  (one split-K launch)
     const void* gin = u.has_dw ? at(ws, u.o_u) : x_in;
     {

@@ -112,8 +112,7 @@ int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, flo
 // ------------------------------------------------------------------ BN apply + add + act -----
 // Thread = one 16-byte column vector (4 f32 / 8 bf16 channels) walking a slab of rows, so the
 // per-channel coefficients are fetched once and every access is a full 16 B per lane.
-static constexpr int kFwdRows = 32;   // rows per workgroup, forward / backward-apply
-static constexpr int kRowsPerBlock = 64;  // rows per workgroup, backward statistics
+static constexpr int kRowsPerBlock = 32;  // rows per workgroup, backward statistics
 
 // d(act)/d(pre-activation)
 __device__ __forceinline__ float act_grad(float p, int act) {
@@ -137,49 +136,55 @@ __device__ __forceinline__ ColGeom col_geom(int C) {
   return g;
 }
 
+// Flat streaming form of the two element-wise BN kernels: a workgroup owns a slab of kSlabRows rows, keeps
+// the per-channel constants of the whole row in LDS (copied once with 16-byte loads) and its 256 threads
+// walk the slab's 16-byte vectors row-major, two vectors in flight per thread.  Registers stay small
+// (no per-thread coefficient arrays), so 6-8 waves per SIMD keep enough loads in flight.
+static constexpr int kSlabRows = 16;     // backward apply (40*C-byte table per slab)
+static constexpr int kFwdSlabRows = 8;   // forward (16*C-byte table per slab)
+
+__device__ __forceinline__ void lds_vec8(const float* p, float (&o)[8]) {
+  const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+}
+__device__ __forceinline__ void lds_vec8(const float* p, float (&o)[4]) {
+  const float4 lo = *reinterpret_cast<const float4*>(p);
+  o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
+}
+
+// out = act((a*y + b)*se + a2*y2 + b2);  s_tab = [a | b | a2 | b2][C]
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                          const T* __restrict__ y2, const float* __restrict__ coef2,
                                                          const float* __restrict__ se, T* __restrict__ out,
                                                          int rows, int Tt, int C, int act) {
+  extern __shared__ __attribute__((aligned(16))) float s_tab[];
   constexpr int V = Vec<T>::kN;
-  const ColGeom g = col_geom<V>(C);
-  if (g.rl >= g.row_lanes) return;
-  const int r0 = blockIdx.x * kFwdRows;
-  const int r1 = min(r0 + kFwdRows, rows);
-  for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
-    const int c = cvi * V;
-    float a[V], b[V], a2[V], b2[V];
+  for (int i = threadIdx.x * 4; i < 2 * C; i += 1024) {
+    *reinterpret_cast<float4*>(s_tab + i) = *reinterpret_cast<const float4*>(coef + i);
+    *reinterpret_cast<float4*>(s_tab + 2 * C + i) = y2 ? *reinterpret_cast<const float4*>(coef2 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int cv = C / V;
+  const int r0 = blockIdx.x * kFwdSlabRows;
+  const int n_items = (min(r0 + kFwdSlabRows, rows) - r0) * cv;
+  for (int it = threadIdx.x; it < n_items; it += 256) {
+    const int rl = it / cv, c = (it - rl * cv) * V, r = r0 + rl;
+    const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
+    float v[V], w[V], a[V], b[V], a2[V], b2[V], o[V];
+    Vec<T>::load(y + off, v);
+    if (y2) Vec<T>::load(y2 + off, w);
+    lds_vec8(s_tab + c, a); lds_vec8(s_tab + C + c, b);
+    lds_vec8(s_tab + 2 * C + c, a2); lds_vec8(s_tab + 3 * C + c, b2);
+    const float* sp = se ? se + (uint32_t)(r / Tt) * (uint32_t)C + (uint32_t)c : nullptr;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      a[j] = coef[c + j]; b[j] = coef[C + c + j];
-      a2[j] = y2 ? coef2[c + j] : 0.f; b2[j] = y2 ? coef2[C + c + j] : 0.f;
+      float z = fmaf(v[j], a[j], b[j]);
+      if (sp) z *= sp[j];
+      if (y2) z += fmaf(w[j], a2[j], b2[j]);
+      o[j] = act_fwd(z, act);
     }
-    // 32-bit element offsets (host checks rows*C < 2^31); the utterance index is stepped, never divided
-    int ub = (r0 + g.rl) / Tt, ut = (r0 + g.rl) - ub * Tt;
-    for (int r = r0 + g.rl; r < r1; r += g.row_lanes) {
-      const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
-      float v[V], o[V];
-      Vec<T>::load(y + off, v);
-#pragma unroll
-      for (int j = 0; j < V; ++j) o[j] = fmaf(v[j], a[j], b[j]);
-      if (se) {
-        const float* sp = se + (uint32_t)ub * (uint32_t)C + (uint32_t)c;
-#pragma unroll
-        for (int j = 0; j < V; ++j) o[j] *= sp[j];
-      }
-      if (y2) {
-        float w[V];
-        Vec<T>::load(y2 + off, w);
-#pragma unroll
-        for (int j = 0; j < V; ++j) o[j] += fmaf(w[j], a2[j], b2[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < V; ++j) o[j] = act_fwd(o[j], act);
-      Vec<T>::store(out + off, o);
-      ut += g.row_lanes;
-      while (ut >= Tt) { ut -= Tt; ++ub; }
-    }
+    Vec<T>::store(out + off, o);
   }
 }
 
@@ -201,11 +206,12 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
       const int c = cvi * V;
       float a1[V], b1[V], m1[V], q1[V], a2[V], b2[V], m2[V], q2[V];
+      lds_vec8(coef + c, a1); lds_vec8(coef + C + c, b1); lds_vec8(saved + c, m1); lds_vec8(saved + C + c, q1);
+      if (has2) {
+        lds_vec8(coef2 + c, a2); lds_vec8(coef2 + C + c, b2); lds_vec8(saved2 + c, m2); lds_vec8(saved2 + C + c, q2);
+      } else {
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        a1[j] = coef[c + j]; b1[j] = coef[C + c + j]; m1[j] = saved[c + j]; q1[j] = saved[C + c + j];
-        a2[j] = has2 ? coef2[c + j] : 0.f; b2[j] = has2 ? coef2[C + c + j] : 0.f;
-        m2[j] = has2 ? saved2[c + j] : 0.f; q2[j] = has2 ? saved2[C + c + j] : 0.f;
+        for (int j = 0; j < V; ++j) a2[j] = b2[j] = m2[j] = q2[j] = 0.f;
       }
       float acc[4][V];
 #pragma unroll
@@ -251,68 +257,87 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
   }
 }
 
-// pass 2: dy = gamma*rstd*(d1 - s1/n - yhat*s2/n), rows past the utterance length zeroed on branch 1
+// pass 2a: per-channel constants of the backward apply, folded once by C threads:
+//   dy = G*d1 + Bc*y + Cc   with G = gamma*rstd, Bc = -G*rstd*s2/n, Cc = G*(mean*rstd*s2/n - s1/n)
+// tab = [a1 | b1 | G1 | B1 | C1 | a2 | b2 | G2 | B2 | C2][C]; also emits dgamma = s2, dbeta = s1.
+__global__ __launch_bounds__(256) void bn_bwd_table_kernel(const float* __restrict__ coef, const float* __restrict__ saved,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           const float* __restrict__ coef2, const float* __restrict__ saved2,
+                                                           const float* __restrict__ gamma2, const float* __restrict__ sums2,
+                                                           float inv_n, int C, float* __restrict__ tab, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma2,
+                                                           float* __restrict__ dbeta2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  {
+    const float q = saved[C + c], w = sums[C + c] * inv_n, G = gamma[c] * q;
+    tab[c] = coef[c]; tab[C + c] = coef[C + c]; tab[2 * C + c] = G; tab[3 * C + c] = -G * q * w;
+    tab[4 * C + c] = G * (saved[c] * q * w - sums[c] * inv_n);
+    if (dbeta) dbeta[c] = sums[c];
+    if (dgamma) dgamma[c] = sums[C + c];
+  }
+  if (coef2) {
+    const float q = saved2[C + c], w = sums2[C + c] * inv_n, G = gamma2[c] * q;
+    tab[5 * C + c] = coef2[c]; tab[6 * C + c] = coef2[C + c]; tab[7 * C + c] = G; tab[8 * C + c] = -G * q * w;
+    tab[9 * C + c] = G * (saved2[c] * q * w - sums2[c] * inv_n);
+    if (dbeta2) dbeta2[c] = sums2[c];
+    if (dgamma2) dgamma2[c] = sums2[C + c];
+  } else {
+    for (int k = 5; k < 10; ++k) tab[k * C + c] = 0.f;
+  }
+}
+
+// pass 2b: dy = G1*d1 + B1*y + C1 (rows past the utterance length zeroed), dy2 = G2*d + B2*y2 + C2
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
-                                                           const float* __restrict__ coef, const float* __restrict__ saved,
-                                                           const float* __restrict__ gamma, const T* __restrict__ y2,
-                                                           const float* __restrict__ coef2, const float* __restrict__ saved2,
-                                                           const float* __restrict__ gamma2, const float* __restrict__ se,
-                                                           const float* __restrict__ seg, const float* __restrict__ sums,
-                                                           const float* __restrict__ sums2, const int32_t* __restrict__ row_lens,
-                                                           T* __restrict__ dy, T* __restrict__ dy2, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma2,
-                                                           float* __restrict__ dbeta2, int rows, int Tt, int C, int act) {
+                                                           const T* __restrict__ y2, const float* __restrict__ tab,
+                                                           const float* __restrict__ se, const float* __restrict__ seg,
+                                                           const int32_t* __restrict__ row_lens, T* __restrict__ dy,
+                                                           T* __restrict__ dy2, int rows, int Tt, int C, int act) {
+  extern __shared__ __attribute__((aligned(16))) float s_tab[];  // [10][C]
   constexpr int V = Vec<T>::kN;
-  const ColGeom g = col_geom<V>(C);
-  if (g.rl >= g.row_lanes) return;
-  const int r0 = blockIdx.x * kFwdRows;
-  const int r1 = min(r0 + kFwdRows, rows);
-  const float inv_n = 1.0f / (float)rows;
+  for (int i = threadIdx.x * 4; i < 10 * C; i += 1024) *reinterpret_cast<float4*>(s_tab + i) = *reinterpret_cast<const float4*>(tab + i);
+  __syncthreads();
   const bool has2 = y2 != nullptr;
-  for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
-    const int c = cvi * V;
-    float a1[V], b1[V], m1[V], q1[V], g1[V], u1[V], w1[V], a2[V], b2[V], m2[V], q2[V], g2[V], u2[V], w2[V];
+  const int cv = C / V;
+  const int r0 = blockIdx.x * kSlabRows;
+  const int n_items = (min(r0 + kSlabRows, rows) - r0) * cv;
+  for (int it = threadIdx.x; it < n_items; it += 256) {
+    const int rl = it / cv, c = (it - rl * cv) * V, r = r0 + rl;
+    const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
+    float dv[V], yv[V], rv[V], o1[V], o2[V];
+    Vec<T>::load(dout + off, dv);
+    Vec<T>::load(y + off, yv);
+    if (has2) Vec<T>::load(y2 + off, rv);
+    const int ub = r / Tt;
+    const bool masked = row_lens && (r - ub * Tt) >= row_lens[ub];
+    const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+    const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+    float a1[V], b1[V], G[V], Bc[V], Cc[V];
+    lds_vec8(s_tab + c, a1); lds_vec8(s_tab + C + c, b1);
+    float z[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (sp ? sp[j] : 1.f);
+    if (has2) {
+      lds_vec8(s_tab + 5 * C + c, a1); lds_vec8(s_tab + 6 * C + c, b1);
+#pragma unroll
+      for (int j = 0; j < V; ++j) z[j] += fmaf(rv[j], a1[j], b1[j]);
+    }
+    float d[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
+    lds_vec8(s_tab + 2 * C + c, G); lds_vec8(s_tab + 3 * C + c, Bc); lds_vec8(s_tab + 4 * C + c, Cc);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      a1[j] = coef[c + j]; b1[j] = coef[C + c + j]; m1[j] = saved[c + j]; q1[j] = saved[C + c + j];
-      g1[j] = gamma[c + j] * q1[j]; u1[j] = sums[c + j] * inv_n; w1[j] = sums[C + c + j] * inv_n;
-      a2[j] = has2 ? coef2[c + j] : 0.f; b2[j] = has2 ? coef2[C + c + j] : 0.f;
-      m2[j] = has2 ? saved2[c + j] : 0.f; q2[j] = has2 ? saved2[C + c + j] : 0.f;
-      g2[j] = has2 ? gamma2[c + j] * q2[j] : 0.f; u2[j] = has2 ? sums2[c + j] * inv_n : 0.f; w2[j] = has2 ? sums2[C + c + j] * inv_n : 0.f;
+      const float d1 = fmaf(d[j], sp ? sp[j] : 1.f, gp ? gp[j] : 0.f);
+      o1[j] = masked ? 0.f : fmaf(G[j], d1, fmaf(Bc[j], yv[j], Cc[j]));
     }
-    if (blockIdx.x == 0 && g.rl == 0) {  // BatchNorm parameter gradients: dbeta = s1, dgamma = s2
+    Vec<T>::store(dy + off, o1);
+    if (has2) {
+      lds_vec8(s_tab + 7 * C + c, G); lds_vec8(s_tab + 8 * C + c, Bc); lds_vec8(s_tab + 9 * C + c, Cc);
 #pragma unroll
-      for (int j = 0; j < V; ++j) {
-        if (dbeta) dbeta[c + j] = sums[c + j];
-        if (dgamma) dgamma[c + j] = sums[C + c + j];
-        if (has2 && dbeta2) dbeta2[c + j] = sums2[c + j];
-        if (has2 && dgamma2) dgamma2[c + j] = sums2[C + c + j];
-      }
-    }
-    int ub = (r0 + g.rl) / Tt, ut = (r0 + g.rl) - ub * Tt;
-    for (int r = r0 + g.rl; r < r1; r += g.row_lanes) {
-      const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
-      const bool masked = row_lens && ut >= row_lens[ub];
-      float dv[V], yv[V], rv[V], o1[V], o2[V];
-      Vec<T>::load(dout + off, dv);
-      Vec<T>::load(y + off, yv);
-      if (has2) Vec<T>::load(y2 + off, rv);
-      const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-      const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-      ut += g.row_lanes;
-      while (ut >= Tt) { ut -= Tt; ++ub; }
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float sej = sp ? sp[j] : 1.f;
-        const float z = fmaf(yv[j], a1[j], b1[j]) * sej + (has2 ? fmaf(rv[j], a2[j], b2[j]) : 0.f);
-        const float d = dv[j] * act_grad(z, act);
-        const float d1 = fmaf(d, sej, gp ? gp[j] : 0.f);
-        o1[j] = masked ? 0.f : g1[j] * (d1 - u1[j] - (yv[j] - m1[j]) * q1[j] * w1[j]);
-        o2[j] = g2[j] * (d - u2[j] - (rv[j] - m2[j]) * q2[j] * w2[j]);
-      }
-      Vec<T>::store(dy + off, o1);
-      if (has2) Vec<T>::store(dy2 + off, o2);
+      for (int j = 0; j < V; ++j) o2[j] = fmaf(G[j], d[j], fmaf(Bc[j], rv[j], Cc[j]));
+      Vec<T>::store(dy2 + off, o2);
     }
   }
 }
@@ -374,7 +399,8 @@ extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2,
   LASR_CHECK_ARG(y && coef && out && (!y2 || coef2), "lasr_bn_act_fwd: null pointer");
   LASR_TRY(check_bn_shape("lasr_bn_act_fwd", dtype, B, T_, C));
   const int64_t rows = B * T_;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)cdiv(rows, kFwdRows)), dim3(256), 0, as_stream(stream),
+  const size_t shmem = (size_t)4 * C * sizeof(float);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem, as_stream(stream),
                                            (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows, (int)T_, (int)C, act));
   LASR_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
@@ -407,19 +433,28 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
   return launch_reduce_partials(partials, nblk, 4 * C, sums, 2 * C, sums2, as_stream(stream));
 }
 
+extern "C" size_t lasr_bn_bwd_apply_workspace_bytes(int64_t C) { return (size_t)10 * C * sizeof(float); }
+
 extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const float* coef, const float* saved,
                                      const float* gamma, const void* y2, const float* coef2, const float* saved2,
                                      const float* gamma2, const float* se_scale, const float* se_grad, const float* sums,
                                      const float* sums2, const int32_t* row_lens, void* dy, void* dy2, float* dgamma,
                                      float* dbeta, float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T_, int64_t C,
-                                     int act, void* stream) {
-  LASR_CHECK_ARG(dout && y && coef && saved && gamma && sums && dy, "lasr_bn_act_bwd_apply: null pointer");
+                                     int act, void* workspace, size_t workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(dout && y && coef && saved && gamma && sums && dy && workspace, "lasr_bn_act_bwd_apply: null pointer");
   LASR_CHECK_ARG(!y2 || (coef2 && saved2 && gamma2 && sums2 && dy2), "lasr_bn_act_bwd_apply: branch-2 pointers");
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_apply", dtype, B, T_, C));
+  if (workspace_bytes < lasr_bn_bwd_apply_workspace_bytes(C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
   const int64_t rows = B * T_;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)cdiv(rows, kFwdRows)), dim3(256), 0, as_stream(stream),
-                                           (const T*)dout, (const T*)y, coef, saved, gamma, (const T*)y2, coef2, saved2, gamma2,
-                                           se_scale, se_grad, sums, sums2, row_lens, (T*)dy, (T*)dy2, dgamma, dbeta, dgamma2, dbeta2,
+  float* tab = reinterpret_cast<float*>(workspace);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_table_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, coef, saved, gamma, sums, y2 ? coef2 : nullptr,
+                     saved2, gamma2, sums2, 1.0f / (float)rows, (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
+  LASR_LAUNCH_CHECK("bn_bwd_table_kernel");
+  const size_t shmem = (size_t)10 * C * sizeof(float);
+  LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_apply: C too large for the LDS coefficient table");
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                           (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy, (T*)dy2,
                                            (int)rows, (int)T_, (int)C, act));
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;

@@ -145,7 +145,7 @@ def bn_act_bwd(dout, y, coef, saved, gamma, y2=None, coef2=None, saved2=None, ga
     dev = y.device
     sums = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
     sums2 = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
-    nb = _lib.load().lasr_bn_bwd_workspace_bytes(B, T, Cc)
+    nb = max(_lib.load().lasr_bn_bwd_workspace_bytes(B, T, Cc), _lib.load().lasr_bn_bwd_apply_workspace_bytes(Cc))
     ws = _ws(nb, dev)
     call("lasr_bn_act_bwd_stats", _p(dout), _p(y), _p(coef), _p(saved), _p(y2), _p(coef2), _p(saved2), _p(se_scale),
          _p(se_grad), _p(sums), _p(sums2), _dt(y), B, T, Cc, ACT[act], _p(ws), nb, _stream())
@@ -155,7 +155,7 @@ def bn_act_bwd(dout, y, coef, saved, gamma, y2=None, coef2=None, saved2=None, ga
     dg2, db2 = ((torch.empty(Cc, dtype=torch.float32, device=dev) for _ in range(2)) if y2 is not None else (None, None))
     call("lasr_bn_act_bwd_apply", _p(dout), _p(y), _p(coef), _p(saved), _p(gamma), _p(y2), _p(coef2), _p(saved2), _p(gamma2),
          _p(se_scale), _p(se_grad), _p(sums), _p(sums2), _p(row_lens), _p(dy), _p(dy2), _p(dg), _p(db), _p(dg2), _p(db2),
-         _dt(y), B, T, Cc, ACT[act], _stream())
+         _dt(y), B, T, Cc, ACT[act], _p(ws), ws.numel(), _stream())
     return dy, dy2, dg, db, dg2, db2
 
 

@@ -42,7 +42,7 @@ if which in ("bn", "all"):
     d1 = torch.empty_like(x); d2 = torch.empty_like(x); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
     t = timeit(lambda: lib.lasr_bn_act_bwd_apply(dy.data_ptr(), x.data_ptr(), coef.data_ptr(), saved.data_ptr(), gam.data_ptr(), y2.data_ptr(), coef.data_ptr(),
                                                  saved.data_ptr(), gam.data_ptr(), None, None, sums.data_ptr(), sums2.data_ptr(), lens.data_ptr(), d1.data_ptr(),
-                                                 d2.data_ptr(), dg.data_ptr(), db.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, B, T, C, 1, st()))
+                                                 d2.data_ptr(), dg.data_ptr(), db.data_ptr(), dg.data_ptr(), db.data_ptr(), 1, B, T, C, 1, ws2.data_ptr(), nb, st()))
     print("bn_bwd_apply        : %6.1f us  (%.2f TB/s)" % (t, mb(5 * N * C * 2, t)))
     z = torch.empty_like(x)
     t = timeit(lambda: z.copy_(x))
