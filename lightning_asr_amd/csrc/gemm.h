@@ -17,7 +17,10 @@ struct GemmArgs {
 
 // bf16-MFMA path (gemm_bf16.hip); returns LASR_E_SHAPE-free 0 on launch, or -100 when the
 // request needs the f32 path (f32 operands or an addend).
-int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim3 grid, hipStream_t st);
-int launch_gemm_bf16_batch(const GemmArgs* g, const dim3* grids, int n, int dtype_c, int transA, int transB, hipStream_t st);
+// gz = split-K slices; the launcher picks the tile (128x128 or 256x256) and reports through stat_tiles
+// how many row tiles wrote BN partial sums ([tile][2][N] in stat_partials).
+int launch_gemm_bf16(const GemmArgs& g, int gz, int dtype_c, int transA, int transB, hipStream_t st, int* stat_tiles);
+int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c, int transA, int transB, hipStream_t st,
+                           int* stat_tiles);
 
 }  // namespace lasr

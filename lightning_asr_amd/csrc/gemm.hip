@@ -276,14 +276,14 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
   } else {
     g.k_per_split = K;
   }
-  const int grid_m = (int)cdiv(M, BM);
+  int grid_m = (int)cdiv(M, BM);
   if (stats) g.stat_partials = reinterpret_cast<float*>(wsp);
   dim3 grid((unsigned)cdiv(N, BN), (unsigned)grid_m, (unsigned)split_k);
   hipStream_t st = as_stream(stream);
   const double gbytes = (double)(M * K + N * K) * esz + (double)M * N * dtype_size(dtype_c);
   const int tok = prof_begin(LASR_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K, gbytes);
   int rc;
-  if (use_bf16) rc = launch_gemm_bf16(g, dtype_c, transA, transB, grid, st);
+  if (use_bf16) rc = launch_gemm_bf16(g, split_k, dtype_c, transA, transB, st, &grid_m);
   else if (dtype_ab == LASR_F32) rc = dtype_c == LASR_F32 ? launch_f32<float, float>(g, transA, transB, grid, st) : launch_f32<float, bf16_t>(g, transA, transB, grid, st);
   else rc = dtype_c == LASR_F32 ? launch_f32<bf16_t, float>(g, transA, transB, grid, st) : launch_f32<bf16_t, bf16_t>(g, transA, transB, grid, st);
   prof_end(tok, st);
@@ -327,8 +327,7 @@ extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int 
   }
   LASR_CHECK_ARG(dtype_c == LASR_F32 || dtype_c == LASR_BF16, "lasr_gemm_batch: bad dtype");
   GemmArgs g[2];
-  dim3 grids[2];
-  int splits[2];
+  int splits[2], stat_tiles[2];
   for (int i = 0; i < 2; ++i) {
     const lasr_gemm_problem& q = probs[i];
     LASR_CHECK_ARG(q.A && q.B && q.C, "lasr_gemm_batch: null pointer");
@@ -353,7 +352,6 @@ extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int 
     }
     if (q.stats) { a.stat_partials = reinterpret_cast<float*>(wsp); wsp += align_up((size_t)cdiv(q.M, BM) * 2 * q.N * sizeof(float), 256); }
     splits[i] = sk;
-    grids[i] = dim3((unsigned)cdiv(q.N, BN), (unsigned)cdiv(q.M, BM), (unsigned)sk);
   }
   hipStream_t st = as_stream(stream);
   double fl = 0, by = 0;
@@ -362,7 +360,7 @@ extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int 
     by += (double)(probs[i].M * probs[i].K + probs[i].N * probs[i].K) * 2 + (double)probs[i].M * probs[i].N * dtype_size(dtype_c);
   }
   const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
-  const int rc = launch_gemm_bf16_batch(g, grids, 2, dtype_c, transA, transB, st);
+  const int rc = launch_gemm_bf16_batch(g, splits, 2, dtype_c, transA, transB, st, stat_tiles);
   prof_end(tok, st);
   if (rc) return rc;
   for (int i = 0; i < 2; ++i) {
@@ -375,7 +373,7 @@ extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int 
         hipLaunchKernelGGL(gemm_split_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const bf16_t*)nullptr, (bf16_t*)q.C);
       LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
     }
-    if (q.stats) LASR_TRY(launch_reduce_partials(g[i].stat_partials, (int)cdiv(q.M, BM), 2 * q.N, q.stats, 2 * q.N, nullptr, st));
+    if (q.stats) LASR_TRY(launch_reduce_partials(g[i].stat_partials, stat_tiles[i], 2 * q.N, q.stats, 2 * q.N, nullptr, st));
   }
   return 0;
 }

@@ -41,26 +41,69 @@ struct Bf16Args {
 // split-K weight gradients (256 tiles each) and lets one problem's store tail overlap the other's loads.
 struct Bf16Batch { Bf16Args p[2]; int tiles0, total; };
 
-// ---- global -> registers: 4 x 16 B per thread per operand tile ------------------------------------
+// ---- global -> registers -> LDS: 4 x 16 B per thread per operand tile --------------------------------
+// 16-byte chunk c = tid + NT*p of a [ROWS x 64] operand tile.  K-contiguous operand: row c>>3, k (c&7)*8;
+// row-contiguous ([k][row]) operand: k = c / (ROWS/8), row (c % (ROWS/8))*8.
+//
+// Aligned operands (pitch % 8 == 0, 16-byte base: every tensor of the model) take the BRANCH-FREE pair
+// below: four unconditional loads from clamped addresses, so nothing but their consumer waits on them
+// and a K step's loads stay in flight under the previous step's MFMAs; chunks past the K range are zeroed
+// when they are written to LDS (chunks past the M/N edge repeat the last row: those outputs are never
+// stored).  Per-lane bounds branches around the loads (the generic path, kept for unaligned shapes)
+// make the compiler drain vmcnt at every join.
+template <bool TRANS, int ROWS, int NT>
+__device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, uint4 (&reg)[4]) {
+  constexpr int RCH = ROWS / 8;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = tid + NT * p;
+    uint32_t off;
+    if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), kend - 8);
+    else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), R - 8);
+    reg[p] = *reinterpret_cast<const uint4*>(X + off);
+  }
+}
+
+template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_>
+__device__ __forceinline__ void store_vec(char* __restrict__ s, const uint4 (&reg)[4], int k0, int kend) {
+  constexpr int RCH = ROWS / 8;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = tid + NT * p;
+    const bool valid = !TRANS ? (k0 + ((c & 7) << 3) < kend) : (k0 + c / RCH < kend);
+    const int off = !TRANS ? (c >> 3) * LDK_ + ((c & 7) << 4) : (c / RCH) * LDR_ + ((c % RCH) << 4);
+    const uint32_t mk = valid ? 0xffffffffu : 0u;   // AND, not select: keeps the K loop free of exec-mask branches
+    *reinterpret_cast<uint4*>(s + off) = make_uint4(reg[p].x & mk, reg[p].y & mk, reg[p].z & mk, reg[p].w & mk);
+  }
+}
+
+// single-chunk forms (chunk p of the thread), for K loops that spread the staging between MFMA groups
+template <bool TRANS, int ROWS, int NT>
+__device__ __forceinline__ uint4 load_chunk(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, int p) {
+  constexpr int RCH = ROWS / 8;
+  const int c = threadIdx.x + NT * p;
+  uint32_t off;
+  if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), kend - 8);
+  else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), R - 8);
+  return *reinterpret_cast<const uint4*>(X + off);
+}
+template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_>
+__device__ __forceinline__ void store_chunk(char* __restrict__ s, const uint4& v, int k0, int kend, int p) {
+  constexpr int RCH = ROWS / 8;
+  const int c = threadIdx.x + NT * p;
+  const bool valid = !TRANS ? (k0 + ((c & 7) << 3) < kend) : (k0 + c / RCH < kend);
+  const int off = !TRANS ? (c >> 3) * LDK_ + ((c & 7) << 4) : (c / RCH) * LDR_ + ((c % RCH) << 4);
+  const uint32_t mk = valid ? 0xffffffffu : 0u;
+  *reinterpret_cast<uint4*>(s + off) = make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+}
+
+// generic path: any pitch/alignment, element-granular edges
 template <bool TRANS>
 __device__ __forceinline__ void load_oper(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, bool vec_ok,
                                           uint4 (&reg)[4]) {
   const int tid = threadIdx.x;
-  // Fast path, decided per TILE (wave-uniform, a scalar branch): four unconditional 16-byte loads in
-  // flight per lane.  Rows past the matrix edge are clamped to the last row: what they load is never
-  // stored (the epilogue masks m >= M / n >= N).  Per-lane bounds branches here serialise the loads.
-  const bool fast = vec_ok && (k0 + TK <= kend) && (TRANS ? (r0 + TM <= R) : true);
-  if (fast) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int c = tid + 256 * p;
-      uint32_t off;
-      if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)(k0 + ((c & 7) << 3));
-      else off = (uint32_t)(k0 + (c >> 4)) * (uint32_t)ld + (uint32_t)(r0 + ((c & 15) << 3));
-      reg[p] = *reinterpret_cast<const uint4*>(X + off);
-    }
-    return;
-  }
 #pragma unroll 1
   for (int p = 0; p < 4; ++p) {
     const int c = tid + 256 * p;
@@ -95,7 +138,7 @@ __device__ __forceinline__ void store_oper(char* __restrict__ s, const uint4 (&r
 }
 
 // ---- LDS -> MFMA fragment: 8 consecutive k of row (rb + lane&31), k = ks*16 + 8*(lane>>5) + j ----
-template <bool TRANS>
+template <bool TRANS, int LD_RC_ = LD_RC>
 __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ s, int rb, int ks, int lane) {
   Frag f;
   if (!TRANS) {
@@ -107,9 +150,9 @@ __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ s, int rb, 
     const int kbase = ks * 16 + 8 * (g >> 1) + q;
     const int col = rb + 16 * (g & 1) + 4 * p;
     typedef __attribute__((address_space(3))) s16x4 lds_s4;
-    const char* a0 = s + kbase * LD_RC + col * 2;
+    const char* a0 = s + kbase * LD_RC_ + col * 2;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a0 + 4 * LD_RC));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(a0 + 4 * LD_RC_));
     f.s = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
   return f.b;
@@ -124,7 +167,7 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
-template <typename TC, bool TRANS_A, bool TRANS_B>
+template <typename TC, bool TRANS_A, bool TRANS_B, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
   __shared__ __attribute__((aligned(16))) char smem[2 * OPER_BYTES];
   __shared__ float s_stat[2][2][TN];
@@ -166,20 +209,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
   // load has two full iterations to land (one CU holds 2 workgroups x 64 KB in flight).  With K of
   // only 256-1024 the kernel is a short dependent chain of load latencies, not a bandwidth stream.
   uint4 ra0[4], rb0[4], ra1[4], rb1[4];
-  load_oper<TRANS_A>(g.A, g.lda, g.M, m0, kbeg, kend, g.vecA, ra0);
-  load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, kbeg, kend, g.vecB, rb0);
-  load_oper<TRANS_A>(g.A, g.lda, g.M, m0, kbeg + TK, kend, g.vecA, ra1);
-  load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, g.vecB, rb1);
-#define LASR_K_STEP(RA_, RB_, KNEXT_)                                                     \
-  {                                                                                      \
-    __syncthreads();                                                                     \
+#define LASR_LOAD(RA_, RB_, K0_)                                                          \
+  if constexpr (VEC) {                                                                   \
+    load_vec<TRANS_A, TM, 256>(g.A, g.lda, g.M, m0, (K0_), kend, RA_);                   \
+    load_vec<TRANS_B, TN, 256>(g.B, g.ldb, g.N, n0, (K0_), kend, RB_);                   \
+  } else {                                                                               \
+    load_oper<TRANS_A>(g.A, g.lda, g.M, m0, (K0_), kend, g.vecA, RA_);                   \
+    load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, (K0_), kend, g.vecB, RB_);                   \
+  }
+#define LASR_STORE(RA_, RB_, K0_)                                                         \
+  if constexpr (VEC) {                                                                   \
+    store_vec<TRANS_A, TM, 256, LD_KC, LD_RC>(sA, RA_, (K0_), kend);                     \
+    store_vec<TRANS_B, TN, 256, LD_KC, LD_RC>(sB, RB_, (K0_), kend);                     \
+  } else {                                                                               \
     store_oper<TRANS_A>(sA, RA_);                                                        \
     store_oper<TRANS_B>(sB, RB_);                                                        \
+  }
+  LASR_LOAD(ra0, rb0, kbeg)
+  if (kbeg + TK < kend) { LASR_LOAD(ra1, rb1, kbeg + TK) }
+#define LASR_K_STEP(RA_, RB_, KCUR_, KNEXT_)                                              \
+  {                                                                                      \
     __syncthreads();                                                                     \
-    if ((KNEXT_) < kend) {                                                               \
-      load_oper<TRANS_A>(g.A, g.lda, g.M, m0, (KNEXT_), kend, g.vecA, RA_);               \
-      load_oper<TRANS_B>(g.B, g.ldb, g.N, n0, (KNEXT_), kend, g.vecB, RB_);               \
-    }                                                                                    \
+    LASR_STORE(RA_, RB_, KCUR_)                                                          \
+    __syncthreads();                                                                     \
+    if ((KNEXT_) < kend) { LASR_LOAD(RA_, RB_, KNEXT_) }                                  \
     _Pragma("unroll") for (int ks = 0; ks < TK / 16; ++ks) {                             \
       const bf16x8 a0 = load_frag<TRANS_A>(sA, wm * 64, ks, lane);                       \
       const bf16x8 a1 = load_frag<TRANS_A>(sA, wm * 64 + 32, ks, lane);                  \
@@ -192,9 +245,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
     }                                                                                    \
   }
   for (int k0 = kbeg; k0 < kend; k0 += 2 * TK) {
-    LASR_K_STEP(ra0, rb0, k0 + 2 * TK)
-    if (k0 + TK < kend) LASR_K_STEP(ra1, rb1, k0 + 3 * TK)
+    LASR_K_STEP(ra0, rb0, k0, k0 + 2 * TK)
+    if (k0 + TK < kend) LASR_K_STEP(ra1, rb1, k0 + TK, k0 + 3 * TK)
   }
+#undef LASR_LOAD
+#undef LASR_STORE
 #undef LASR_K_STEP
 
   const int half = lane >> 5, l31 = lane & 31;
@@ -284,32 +339,265 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
   }
 }
 
-static int fill_args(Bf16Args& a, const GemmArgs& g, dim3 grid) {
+// =====================================================================================================
+// 256x256x64 tile, 512 threads (8 waves as 2 x 4, each 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator
+// VGPRs), ONE workgroup per CU, operand images double-buffered in LDS (2 x 72 KB) with one barrier per
+// K step.  Against the 128x128 tile it halves the operand bytes pulled from L2 and written to LDS per
+// FLOP and reads 0.75 instead of 1 fragment per MFMA; a unit's main + residual problem (63 x 2 tiles
+// each at N=512) fill 252 of the 256 CUs in a single round.  bf16 results only.
+namespace big {
+static constexpr int BTM = 256, BTN = 256, NT = 512;
+static constexpr int LDR = 576;               // [k][256 rows] image: 512 B + 64 B pad (bank residue 16 dwords, as LD_RC)
+static constexpr int OPER = 36864;            // 256*144 == 64*576
+static constexpr int BUF = 2 * OPER;          // A + B image of one K step
+}  // namespace big
+
+// One K step of the 256x256 tile: 4 groups of (6 fragment reads, 8 MFMAs); after group ks the thread moves
+// its chunk ks of the NEXT step from registers into the other LDS image and (re)issues the global load of
+// the step after that into the same registers, so LDS writes and VMEM issue ride in the MFMA shadows
+// instead of forming a separate all-waves staging phase in front of them.
+template <bool TRANS_A, bool TRANS_B, bool STORE, bool LOAD>
+__device__ __forceinline__ void big_step(const char* __restrict__ sA, const char* __restrict__ sB, char* __restrict__ dA,
+                                         char* __restrict__ dB, f32x16 (&acc)[4][2], uint4 (&ra)[4], uint4 (&rb)[4],
+                                         const Bf16Args& g, int m0, int n0, int k_store, int k_load, int kend, int wm, int wn,
+                                         int lane) {
+  using namespace big;
+#pragma unroll
+  for (int ks = 0; ks < TK / 16; ++ks) {
+    bf16x8 a[4], b[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) b[ni] = load_frag<TRANS_B, LDR>(sB, wn * 64 + ni * 32, ks, lane);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a[mi] = load_frag<TRANS_A, LDR>(sA, wm * 128 + mi * 32, ks, lane);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    if constexpr (STORE) {
+      store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
+      store_chunk<TRANS_B, BTN, NT, LD_KC, LDR>(dB, rb[ks], k_store, kend, ks);
+    }
+    if constexpr (LOAD) {
+      ra[ks] = load_chunk<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, k_load, kend, ks);
+      rb[ks] = load_chunk<TRANS_B, BTN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
+    }
+  }
+}
+
+#ifdef LASR_GEMM_STAMPS
+// Debug builds only (never in liblasr.so): per-workgroup wall-clock stamps, 8 x u64 per workgroup, for the
+// first 4096 workgroups of a launch.  The buffer is set by lasr_debug_set_gemm_stamps (tools/gemm_stamps.py).
+__device__ unsigned long long* g_stamps = nullptr;
+#define LASR_STAMP(i_) do { if (stamps && threadIdx.x == 0 && blockIdx.x < 4096) stamps[blockIdx.x * 8 + (i_)] = wall_clock64(); } while (0)
+#else
+#define LASR_STAMP(i_) do {} while (0)
+#endif
+
+template <bool TRANS_A, bool TRANS_B>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
+#ifdef LASR_GEMM_STAMPS
+  unsigned long long* stamps = g_stamps;
+#endif
+  LASR_STAMP(0);
+  using big::BTM; using big::BTN; using big::NT; using big::LDR; using big::OPER; using big::BUF;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ float s_stat[2][2][BTN];
+  __shared__ float s_keep[BTM];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int lid_all = xcd_remap(blockIdx.x, gb.total);
+  const bool second = lid_all >= gb.tiles0;
+  const Bf16Args& g = second ? gb.p[1] : gb.p[0];
+  const int lid = second ? lid_all - gb.tiles0 : lid_all;
+  const int tn = lid % g.gn, tm = (lid / g.gn) % g.gm, tz = lid / (g.gn * g.gm);
+  const int m0 = tm * BTM, n0 = tn * BTN;
+  const int kbeg = tz * g.k_per_split;
+  const int kend = min(kbeg + g.k_per_split, g.K);
+  const int nk = (kend - kbeg + TK - 1) / TK;
+
+  if (tid < BTM) {
+    const int m = m0 + tid;
+    bool keep = m < g.M;
+    if (keep && g.row_lens) {
+      const int b = m / g.rows_per_seq;
+      keep = (m - b * g.rows_per_seq) < g.row_lens[b];
+    }
+    s_keep[tid] = keep ? 1.f : 0.f;
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
+  load_vec<TRANS_B, BTN, NT>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
+  store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
+  store_vec<TRANS_B, BTN, NT, LD_KC, LDR>(smem + OPER, rb, kbeg, kend);
+  if (nk > 1) {
+    load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
+    load_vec<TRANS_B, BTN, NT>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
+  }
+  __syncthreads();
+  LASR_STAMP(1);
+  {
+    // steady state: compute step it, stage step it+1 (registers -> other image), fetch step it+2
+    int it = 0;
+    for (; it + 2 < nk; ++it) {
+      const char* sA = smem + (it & 1) * BUF;
+      char* dA = smem + ((it + 1) & 1) * BUF;
+      big_step<TRANS_A, TRANS_B, true, true>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
+                                             kbeg + (it + 2) * TK, kend, wm, wn, lane);
+      __syncthreads();
+    }
+    if (it + 1 < nk) {
+      const char* sA = smem + (it & 1) * BUF;
+      char* dA = smem + ((it + 1) & 1) * BUF;
+      big_step<TRANS_A, TRANS_B, true, false>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
+                                              wm, wn, lane);
+      __syncthreads();
+      ++it;
+    }
+    const char* sA = smem + (it & 1) * BUF;
+    big_step<TRANS_A, TRANS_B, false, false>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane);
+    __syncthreads();
+  }
+  LASR_STAMP(2);
+  // ---- epilogue: bias, row mask, bf16 rounding, BN column sums.  The whole 256x256 bf16 tile is laid out
+  //      in LDS (528-byte rows: 132 KB of the operand images, free after the last barrier), then every
+  //      wave stores 32 complete tile rows: one instruction = 2 rows x 512 contiguous bytes, and the waves
+  //      of the chip walk the rows in the same order, so the stores in flight form long runs (measured:
+  //      8 rows x 128 B per instruction with per-wave images 7.5 us for a wave's first 8 stores, a per-wave
+  //      rotated row order 13 us).
+  constexpr int EPB = 528;
+  const int half = lane >> 5, l31 = lane & 31;
+  bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
+  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+  const int nb = n0 + wn * 64;
+  const float bv0 = (g.bias && nb + l31 < g.N) ? g.bias[nb + l31] : 0.f;
+  const float bv1 = (g.bias && nb + 32 + l31 < g.N) ? g.bias[nb + 32 + l31] : 0.f;
+  {
+    char* img = smem + (wn * 64 + l31) * 2;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float kf = s_keep[lr];
+        const bf16_t q0 = f32_to_bf16((acc[mi][0][r] + bv0) * kf);
+        const bf16_t q1 = f32_to_bf16((acc[mi][1][r] + bv1) * kf);
+        const float v0 = bf16_to_f32(q0), v1 = bf16_to_f32(q1);   // statistics of the values as stored
+        csum[0] += v0; csq[0] = fmaf(v0, v0, csq[0]);
+        csum[1] += v1; csq[1] = fmaf(v1, v1, csq[1]);
+        *reinterpret_cast<bf16_t*>(img + lr * EPB) = q0;
+        *reinterpret_cast<bf16_t*>(img + lr * EPB + 64) = q1;
+      }
+    }
+  }
+  if (g.stat_partials) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      csum[ni] += __shfl_xor(csum[ni], 32, 64);
+      csq[ni] += __shfl_xor(csq[ni], 32, 64);
+      if (half == 0) {
+        s_stat[wm][0][wn * 64 + ni * 32 + l31] = csum[ni];
+        s_stat[wm][1][wn * 64 + ni * 32 + l31] = csq[ni];
+      }
+    }
+  }
+  __syncthreads();
+  LASR_STAMP(5);
+  {
+    const int nst = n0 + l31 * 8;
+    const bool full_n = g.vecC && nst + 7 < g.N;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int lr = wid * 32 + it * 2 + half;
+      const int m = m0 + lr;
+      if (m < g.M && nst < g.N) {
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + l31 * 16);
+        bf16_t* dst = C + (uint32_t)m * (uint32_t)g.ldc + (uint32_t)nst;
+        if (full_n) {
+          *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+          for (int i = 0; i < 8 && nst + i < g.N; ++i) dst[i] = e[i];
+        }
+      }
+    }
+  }
+  LASR_STAMP(3);
+  if (g.stat_partials && tid < BTN) {
+    const int n = n0 + tid;
+    if (n < g.N) {
+      float* P = g.stat_partials + (size_t)tm * 2 * g.N;
+      P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
+      P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+    }
+  }
+#ifdef LASR_GEMM_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);   // the stores of this wave have been accepted
+  LASR_STAMP(4);
+#endif
+}
+
+static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
   const int64_t lim = (int64_t)1 << 31;
+  const int64_t gn = cdiv(g.N, tn), gm = cdiv(g.M, tm);
   if (g.M * g.lda >= lim || g.K * g.lda >= lim || g.N * g.ldb >= lim || g.K * g.ldb >= lim || g.M * g.ldc >= lim ||
-      (int64_t)grid.x * grid.y * grid.z >= lim / 2)
+      gn * gm * gz >= lim / 2)
     return fail(LASR_E_SHAPE, "lasr_gemm(bf16): matrix exceeds the kernel's 32-bit element offsets");
   a.A = reinterpret_cast<const bf16_t*>(g.A); a.B = reinterpret_cast<const bf16_t*>(g.B); a.C = g.C;
   a.bias = g.bias; a.row_lens = g.row_lens; a.stat_partials = g.stat_partials; a.split_ws = g.split_ws;
   a.M = (int)g.M; a.N = (int)g.N; a.K = (int)g.K; a.lda = (int)g.lda; a.ldb = (int)g.ldb; a.ldc = (int)g.ldc;
   a.rows_per_seq = (int)(g.rows_per_seq > 0 ? g.rows_per_seq : 1); a.k_per_split = (int)g.k_per_split;
-  a.gn = (int)grid.x; a.gm = (int)grid.y; a.gz = (int)grid.z;
+  a.gn = (int)gn; a.gm = (int)gm; a.gz = gz;
   a.vecA = g.vecA; a.vecB = g.vecB;
   a.vecC = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0);
   return 0;
 }
 
-// g[0..n): problems sharing dtype_c / transposition; grids[i] = (gn, gm, gz) of problem i
-int launch_gemm_bf16_batch(const GemmArgs* g, const dim3* grids, int n, int dtype_c, int transA, int transB, hipStream_t st) {
+// g[0..n): problems sharing dtype_c / transposition; gz[i] = split-K slices of problem i.
+// stat_tiles[i] receives the number of row tiles problem i writes BN partial sums for.
+int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c, int transA, int transB, hipStream_t st,
+                           int* stat_tiles) {
+  const bool f32_out = dtype_c == LASR_F32 || g[0].split_ws != nullptr;   // split-K slabs are f32
+  // The 256x256 tile pays when its (one per CU) workgroups cover most of the chip.
+  static const int big_min = getenv("LASR_GEMM_BIG_MIN_TILES") ? atoi(getenv("LASR_GEMM_BIG_MIN_TILES")) : 120;
+  int64_t big_tiles = 0;
+  for (int i = 0; i < n; ++i) big_tiles += cdiv(g[i].M, big::BTM) * cdiv(g[i].N, big::BTN) * gz[i];
+  bool vec = true;   // every operand aligned for 16-byte chunks (pitch % 8, base % 16): true for all model tensors
+  for (int i = 0; i < n; ++i) vec = vec && g[i].vecA && g[i].vecB;
+  const bool use_big = !f32_out && vec && big_tiles >= big_min;
+  const int tm = use_big ? big::BTM : TM, tn = use_big ? big::BTN : TN;
   Bf16Batch b;
-  LASR_TRY(fill_args(b.p[0], g[0], grids[0]));
+  LASR_TRY(fill_args(b.p[0], g[0], tm, tn, gz[0]));
   b.p[1] = b.p[0];
-  if (n > 1) LASR_TRY(fill_args(b.p[1], g[1], grids[1]));
+  if (n > 1) LASR_TRY(fill_args(b.p[1], g[1], tm, tn, gz[1]));
   b.tiles0 = b.p[0].gn * b.p[0].gm * b.p[0].gz;
   b.total = b.tiles0 + (n > 1 ? b.p[1].gn * b.p[1].gm * b.p[1].gz : 0);
+  if (stat_tiles)
+    for (int i = 0; i < n; ++i) stat_tiles[i] = b.p[i].gm;
   const dim3 grid1((unsigned)b.total);
-  const bool f32_out = dtype_c == LASR_F32 || g[0].split_ws != nullptr;   // split-K slabs are f32
-#define LASR_BF16_CASE(TC_, TA_, TB_) hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_>), grid1, dim3(256), 0, st, b)
+  if (use_big) {
+#define LASR_BIG_CASE(TA_, TB_) hipLaunchKernelGGL((gemm_bf16_big_kernel<TA_, TB_>), grid1, dim3(big::NT), 0, st, b)
+    if (!transA && !transB) LASR_BIG_CASE(false, false);
+    else if (!transA && transB) LASR_BIG_CASE(false, true);
+    else if (transA && !transB) LASR_BIG_CASE(true, false);
+    else LASR_BIG_CASE(true, true);
+#undef LASR_BIG_CASE
+    LASR_LAUNCH_CHECK("gemm_bf16_big_kernel");
+    return 0;
+  }
+#define LASR_BF16_CASE(TC_, TA_, TB_)                                                                    \
+  do {                                                                                                  \
+    if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_, true>), grid1, dim3(256), 0, st, b);    \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TC_, TA_, TB_, false>), grid1, dim3(256), 0, st, b);       \
+  } while (0)
 #define LASR_BF16_TC(TC_)                                         \
   do {                                                            \
     if (!transA && !transB) LASR_BF16_CASE(TC_, false, false);    \
@@ -324,8 +612,15 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const dim3* grids, int n, int dtyp
   return 0;
 }
 
-int launch_gemm_bf16(const GemmArgs& g, int dtype_c, int transA, int transB, dim3 grid, hipStream_t st) {
-  return launch_gemm_bf16_batch(&g, &grid, 1, dtype_c, transA, transB, st);
+int launch_gemm_bf16(const GemmArgs& g, int gz, int dtype_c, int transA, int transB, hipStream_t st, int* stat_tiles) {
+  return launch_gemm_bf16_batch(&g, &gz, 1, dtype_c, transA, transB, st, stat_tiles);
 }
 
 }  // namespace lasr
+
+#ifdef LASR_GEMM_STAMPS
+extern "C" int lasr_debug_set_gemm_stamps(void* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lasr::g_stamps), &p, sizeof(p));
+}
+#endif

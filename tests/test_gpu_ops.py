@@ -380,3 +380,42 @@ def test_gemm_bf16_mfma_epilogue(dev):
     assert max_rel(stats[:N], gf.sum(0)) < 1e-5           # statistics of the values as stored
     assert max_rel(stats[N:], (gf * gf).sum(0)) < 1e-5
     assert torch.all(got[T + 40:] == 0)
+
+
+# ----------------------------------------------------------------------------------------- 256x256-tile bf16 GEMM
+@pytest.mark.parametrize("M,N,K,tA,tB", [(16032, 512, 512, False, False), (16032, 512, 512, False, True),
+                                         (8100, 768, 320, False, False), (8100, 776, 200, False, True),
+                                         (8192, 1024, 256, True, False), (7000, 520, 136, True, True)])
+def test_gemm_bf16_big_tile_exact_integers(dev, M, N, K, tA, tB):
+    """Shapes large enough for the 256x256x64 one-workgroup-per-CU kernel (>= 120 tiles), with ragged M/N/K
+    edges.  Small-integer operands make bf16 x bf16 -> f32 exact, and the bf16 result is exact while
+    |value| <= 256, so the comparison is bit for bit."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randint(-2, 3, (K, M) if tA else (M, K), generator=g).float()
+    Bm = (torch.rand((K, N) if tB else (N, K), generator=g) < 0.05).float()
+    ref = (A.t() if tA else A) @ (Bm if tB else Bm.t())
+    assert ref.abs().max() <= 256
+    got, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, tA, tB)
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got.cpu().float(), ref)
+
+
+def test_gemm_bf16_big_tile_epilogue(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(33)
+    B, T, K, N = 32, 501, 512, 512
+    M = B * T
+    A = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / 16).bfloat16()
+    bias = torch.randn(N, generator=g)
+    lens = torch.randint(0, T + 1, (B,), generator=g).to(torch.int32)
+    lens[0], lens[1] = T, 0
+    keep = (torch.arange(T).view(1, T) < lens.view(B, 1)).view(M, 1)
+    ref = ((A.double() @ W.double().t() + bias.double()) * keep).float()
+    got, stats = ops.gemm(A.to(dev), W.to(dev), M, N, K, bias=bias.to(dev), row_lens=lens.to(dev), rows_per_seq=T, want_stats=True)
+    assert max_rel(got.float(), ref) < 4e-3
+    gf = got.float().cpu().double()
+    assert max_rel(stats[:N], gf.sum(0)) < 1e-5
+    assert max_rel(stats[N:], (gf * gf).sum(0)) < 1e-5
+    assert torch.all(got.view(B, T, N)[1] == 0)
