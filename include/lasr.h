@@ -109,6 +109,14 @@ size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs, int n_pro
 int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
                     int split_k, void* workspace, size_t workspace_bytes, void* stream);
 
+/* lasr_gemm_batch that leaves each problem's BN partial sums UNREDUCED in the workspace (no split-K):
+ * for every problem with stats != NULL, stat_partials[i] points at [stat_tiles[i]][2][N] f32 inside
+ * `workspace` (valid until the workspace is reused) and problem.stats itself is not written.
+ * lasr_bn_finalize_partials consumes them: 1 launch instead of 2 reductions + 2 finalizes per unit. */
+int lasr_gemm_batch_partials(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA,
+                             int transB, void* workspace, size_t workspace_bytes, const float** stat_partials,
+                             int* stat_tiles, void* stream);
+
 /* Training-mode BatchNorm1d(eps) statistics -> affine coefficients (models/QuartNet.py:24,35):
  * mean = s/n, var = q/n - mean^2 (biased); coef[c] = gamma*rstd, coef[C+c] = beta - mean*gamma*rstd;
  * saved[c] = mean, saved[C+c] = rstd; running_mean/var updated with momentum (unbiased var) when
@@ -116,6 +124,17 @@ int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, i
 int lasr_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float* coef, float* saved, int64_t C, int64_t n_rows, float eps,
                      float momentum, int training, void* stream);
+
+/* Training-mode lasr_bn_finalize for one or two BN layers of the same width (a unit's main and residual
+ * branch) straight from GEMM partial sums: fixed-order f64 column reduction + the same arithmetic, one
+ * launch.  stats (optional) receives the reduced [sum | sumsq] (2C f32).   (models/QuartNet.py:24,35) */
+typedef struct {
+  const float* partials; int n_partials;          /* [n_partials][2][C] */
+  const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* coef; float* saved; float* stats;
+} lasr_bn_branch;
+int lasr_bn_finalize_partials(const lasr_bn_branch* branches, int n_branches, int64_t C, int64_t n_rows, float eps,
+                              float momentum, void* stream);
 
 /* out = act( (y*coef_a + coef_b) * se_scale[b][c] + (y2*coef2_a + coef2_b) )
  * y2/coef2 (residual branch) and se_scale ([B][C] f32) may be NULL.
@@ -131,7 +150,10 @@ int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2, const floa
  *                 branch 1 only (the residual branch is never masked, models/QuartNet.py:75).
  * The pre-activation is rebuilt from y/y2 and the coefficients, so the forward output is not read.
  * dgamma = s2, dbeta = s1 are written by pass 2 (f32, may be NULL).
- * se_grad ([B][C] f32, may be NULL): extra per-(b,c) gradient added to d*se (SE pooled path).  */
+ * se_grad ([B][C] f32, may be NULL): extra per-(b,c) gradient added to d*se (SE pooled path).
+ * Fused hand-over: call stats with sums = sums2 = NULL and apply with sums = sums2 = NULL and the SAME
+ * workspace (lasr_bn_bwd_workspace_bytes): the per-block partial sums stay in the workspace and pass 2
+ * reduces them while folding its per-channel constants (one launch less, no f32 round trip).   */
 size_t lasr_bn_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
 int lasr_bn_act_bwd_stats(const void* dout, const void* y, const float* coef,
                           const float* saved, const void* y2, const float* coef2, const float* saved2,

@@ -218,6 +218,20 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
   Elem<TC>::st(C + m * ldc + n, s);
 }
 
+// two split-K problems (a unit's main and residual weight gradient) reduced by one launch
+struct SplitReduce2 { const float* ws[2]; float* C[2]; const float* bias[2]; int split[2]; int64_t M[2], N[2]; };
+__global__ __launch_bounds__(256) void gemm_split_reduce2_kernel(SplitReduce2 a) {
+  const int q = blockIdx.y;
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t mn = a.M[q] * a.N[q];
+  if (i >= mn) return;
+  const float* ws = a.ws[q];
+  float s = 0.f;
+  for (int p = 0; p < a.split[q]; ++p) s += ws[(int64_t)p * mn + i];
+  if (a.bias[q]) s += a.bias[q][i % a.N[q]];
+  a.C[q][i] = s;
+}
+
 template <typename TAB, typename TC>
 static int launch_f32(const GemmArgs& g, int transA, int transB, dim3 grid, hipStream_t st) {
 #define LASR_GEMM_CASE(TA_, TB_)                                                                              \
@@ -242,10 +256,12 @@ extern "C" size_t lasr_gemm_workspace_bytes(int64_t M, int64_t N, int split_k, i
   return b;
 }
 
-extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,
-                         int transA, int transB, const float* bias, const void* addend, const int32_t* row_lens,
-                         int64_t rows_per_seq, float* stats, int split_k, void* workspace, size_t workspace_bytes,
-                         void* stream) {
+// stat_out != null: the BN partial sums stay unreduced in the workspace; *stat_out = {pointer, row tiles}
+struct StatOut { const float* partials; int tiles; };
+static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,
+                     int transA, int transB, const float* bias, const void* addend, const int32_t* row_lens,
+                     int64_t rows_per_seq, float* stats, int split_k, void* workspace, size_t workspace_bytes,
+                     void* stream, StatOut* stat_out) {
   LASR_CHECK_ARG(A && B && C, "lasr_gemm: null pointer");
   LASR_CHECK_ARG((dtype_ab == LASR_F32 || dtype_ab == LASR_BF16) && (dtype_c == LASR_F32 || dtype_c == LASR_BF16), "lasr_gemm: bad dtype");
   LASR_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && split_k >= 1 && split_k <= 1024, "lasr_gemm: M=%lld N=%lld K=%lld split=%d",
@@ -296,10 +312,20 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
       hipLaunchKernelGGL(gemm_split_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g.split_ws, split_k, M, N, g.ldc, bias, (const bf16_t*)addend, (bf16_t*)C);
     LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
   }
-  if (stats) {
+  if (stats && stat_out) {
+    stat_out->partials = g.stat_partials; stat_out->tiles = grid_m;
+  } else if (stats) {
     LASR_TRY(launch_reduce_partials(g.stat_partials, grid_m, 2 * N, stats, 2 * N, nullptr, st));
   }
   return 0;
+}
+
+extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,
+                         int transA, int transB, const float* bias, const void* addend, const int32_t* row_lens,
+                         int64_t rows_per_seq, float* stats, int split_k, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  return gemm_impl(A, B, C, dtype_ab, dtype_c, M, N, K, transA, transB, bias, addend, row_lens, rows_per_seq, stats, split_k,
+                   workspace, workspace_bytes, stream, nullptr);
 }
 
 // ---- two independent problems in one launch (bf16 operands); anything else runs them one by one ----
@@ -309,8 +335,8 @@ extern "C" size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs
   return b;
 }
 
-extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
-                               int split_k, void* workspace, size_t workspace_bytes, void* stream) {
+static int gemm_batch_impl(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
+                           int split_k, void* workspace, size_t workspace_bytes, void* stream, StatOut* stat_out) {
   LASR_CHECK_ARG(probs && n_probs >= 1 && n_probs <= 2, "lasr_gemm_batch: 1 or 2 problems");
   const size_t need = lasr_gemm_batch_workspace_bytes(probs, n_probs, split_k);
   if (need > 0 && (!workspace || workspace_bytes < need)) return fail(LASR_E_WORKSPACE, "lasr_gemm_batch: workspace %zu < %zu", workspace_bytes, need);
@@ -319,8 +345,8 @@ extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int 
     for (int i = 0; i < n_probs; ++i) {
       const lasr_gemm_problem& q = probs[i];
       const size_t nb = lasr_gemm_workspace_bytes(q.M, q.N, split_k, q.stats != nullptr);
-      LASR_TRY(lasr_gemm(q.A, q.B, q.C, dtype_ab, dtype_c, q.M, q.N, q.K, transA, transB, q.bias, nullptr, q.row_lens, q.rows_per_seq,
-                         q.stats, split_k, wsp, nb, stream));
+      LASR_TRY(gemm_impl(q.A, q.B, q.C, dtype_ab, dtype_c, q.M, q.N, q.K, transA, transB, q.bias, nullptr, q.row_lens, q.rows_per_seq,
+                         q.stats, split_k, wsp, nb, stream, stat_out ? stat_out + i : nullptr));
       wsp += nb;
     }
     return 0;
@@ -363,17 +389,51 @@ extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int 
   const int rc = launch_gemm_bf16_batch(g, splits, 2, dtype_c, transA, transB, st, stat_tiles);
   prof_end(tok, st);
   if (rc) return rc;
+  if (g[0].split_ws && g[1].split_ws && dtype_c == LASR_F32) {
+    SplitReduce2 a;
+    int64_t mx = 0;
+    for (int i = 0; i < 2; ++i) {
+      a.ws[i] = g[i].split_ws; a.C[i] = reinterpret_cast<float*>(probs[i].C); a.bias[i] = probs[i].bias; a.split[i] = splits[i];
+      a.M[i] = probs[i].M; a.N[i] = probs[i].N;
+      mx = std::max(mx, probs[i].M * probs[i].N);
+    }
+    hipLaunchKernelGGL(gemm_split_reduce2_kernel, dim3((unsigned)cdiv(mx, 256), 2), dim3(256), 0, st, a);
+    LASR_LAUNCH_CHECK("gemm_split_reduce2_kernel");
+  } else {
+    for (int i = 0; i < 2; ++i) {
+      const lasr_gemm_problem& q = probs[i];
+      if (g[i].split_ws) {
+        const int64_t mn = q.M * q.N;
+        if (dtype_c == LASR_F32)
+          hipLaunchKernelGGL(gemm_split_reduce_kernel<float>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const float*)nullptr, (float*)q.C);
+        else
+          hipLaunchKernelGGL(gemm_split_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const bf16_t*)nullptr, (bf16_t*)q.C);
+        LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
+      }
+    }
+  }
   for (int i = 0; i < 2; ++i) {
     const lasr_gemm_problem& q = probs[i];
-    if (g[i].split_ws) {
-      const int64_t mn = q.M * q.N;
-      if (dtype_c == LASR_F32)
-        hipLaunchKernelGGL(gemm_split_reduce_kernel<float>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const float*)nullptr, (float*)q.C);
-      else
-        hipLaunchKernelGGL(gemm_split_reduce_kernel<bf16_t>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g[i].split_ws, splits[i], q.M, q.N, q.N, q.bias, (const bf16_t*)nullptr, (bf16_t*)q.C);
-      LASR_LAUNCH_CHECK("gemm_split_reduce_kernel");
+    if (q.stats && stat_out) {
+      stat_out[i].partials = g[i].stat_partials; stat_out[i].tiles = stat_tiles[i];
+    } else if (q.stats) {
+      LASR_TRY(launch_reduce_partials(g[i].stat_partials, stat_tiles[i], 2 * q.N, q.stats, 2 * q.N, nullptr, st));
     }
-    if (q.stats) LASR_TRY(launch_reduce_partials(g[i].stat_partials, stat_tiles[i], 2 * q.N, q.stats, 2 * q.N, nullptr, st));
   }
+  return 0;
+}
+
+extern "C" int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
+                               int split_k, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_batch_impl(probs, n_probs, dtype_ab, dtype_c, transA, transB, split_k, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int lasr_gemm_batch_partials(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
+                                        void* workspace, size_t workspace_bytes, const float** stat_partials, int* stat_tiles,
+                                        void* stream) {
+  LASR_CHECK_ARG(stat_partials && stat_tiles, "lasr_gemm_batch_partials: null output");
+  StatOut so[2] = {{nullptr, 0}, {nullptr, 0}};
+  LASR_TRY(gemm_batch_impl(probs, n_probs, dtype_ab, dtype_c, transA, transB, 1, workspace, workspace_bytes, stream, so));
+  for (int i = 0; i < n_probs; ++i) { stat_partials[i] = so[i].partials; stat_tiles[i] = so[i].tiles; }
   return 0;
 }

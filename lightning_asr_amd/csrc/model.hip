@@ -49,6 +49,8 @@ struct TensorInfo {
 
 struct BnRef { int64_t gamma = -1, beta = -1, rmean = -1, rvar = -1; };
 
+static bool no_fuse() { static const bool v = getenv("LASR_NO_FUSE") != nullptr; return v; }
+
 // One "unit": [depthwise conv] -> 1x1 GEMM (+mask) -> BN  [+ residual 1x1 GEMM -> BN] -> activation
 struct Unit {
   std::string tap;
@@ -351,14 +353,29 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
       lasr_gemm_problem pr[2];
       pr[0] = {gin, wptr(m, params, ws, u.w_pw), at(ws, u.o_y), N, u.co, u.ci, nullptr, u.masked ? lens : nullptr, T, stats};
       if (u.has_res) pr[1] = {x, wptr(m, params, ws, u.w_res), at(ws, u.o_y2), N, u.co, u.ci, nullptr, nullptr, 0, stats2};
-      LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
+      const int np = u.has_res ? 2 : 1;
+      if (training && !no_fuse()) {
+        // the epilogue's per-tile BN sums go straight to ONE reduce+finalize launch for both branches
+        const float* parts[2] = {nullptr, nullptr};
+        int tiles[2] = {0, 0};
+        LASR_TRY(lasr_gemm_batch_partials(pr, np, dt, dt, 0, 0, scratch, p.scratch_bytes, parts, tiles, stream));
+        lasr_bn_branch br[2];
+        br[0] = {parts[0], tiles[0], params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
+                 atf(ws, u.o_coef), atf(ws, u.o_saved), stats};
+        if (u.has_res)
+          br[1] = {parts[1], tiles[1], params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
+                   buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), stats2};
+        LASR_TRY(lasr_bn_finalize_partials(br, np, u.co, N, kBnEps, kBnMom, stream));
+      } else {
+        LASR_TRY(lasr_gemm_batch(pr, np, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
+        LASR_TRY(lasr_bn_finalize(stats, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
+                                  atf(ws, u.o_coef), atf(ws, u.o_saved), u.co, N, kBnEps, kBnMom, training, stream));
+        if (u.has_res)
+          LASR_TRY(lasr_bn_finalize(stats2, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
+                                    buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
+                                    training, stream));
+      }
     }
-    LASR_TRY(lasr_bn_finalize(stats, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
-                              atf(ws, u.o_coef), atf(ws, u.o_saved), u.co, N, kBnEps, kBnMom, training, stream));
-    if (u.has_res)
-      LASR_TRY(lasr_bn_finalize(stats2, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
-                                buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
-                                training, stream));
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
       LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
       LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
@@ -423,13 +440,16 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                            u.has_res ? atf(ws, u.o_coef2) : nullptr, se_scale, atf(ws, u.o_se_hid), atf(ws, u.o_se_pool), params + u.w_se1,
                            params + u.w_se2, dt, B, T, u.co, act, atf(ws, u.o_se_grad), grads + u.w_se1, grads + u.w_se2, scratch, sb,
                            stream));
+    // fused hand-over: pass 2 reduces pass 1's partial sums (LASR_NO_FUSE=1 keeps the separate reductions, for A/B runs)
+    float* fsum = no_fuse() ? atf(ws, p.o_sums) : nullptr;
+    float* fsum2 = no_fuse() ? atf(ws, p.o_sums2) : nullptr;
     LASR_TRY(lasr_bn_act_bwd_stats(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), u.has_res ? at(ws, u.o_y2) : nullptr,
                                    u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_res ? atf(ws, u.o_saved2) : nullptr, se_scale,
-                                   se_grad, atf(ws, p.o_sums), atf(ws, p.o_sums2), dt, B, T, u.co, act, scratch, sb, stream));
+                                   se_grad, fsum, fsum2, dt, B, T, u.co, act, scratch, sb, stream));
     LASR_TRY(lasr_bn_act_bwd_apply(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma,
                                    u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
                                    u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, se_scale,
-                                   se_grad, atf(ws, p.o_sums), atf(ws, p.o_sums2), u.masked ? lens : nullptr, dy, dy2,
+                                   se_grad, fsum, fsum2, u.masked ? lens : nullptr, dy, dy2,
                                    grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
                                    u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, scratch, sb, stream));
     // weight gradients of the main and residual 1x1: dW[co][ci] = dy^T gin, dWr = dy2^T x  (one split-K launch)

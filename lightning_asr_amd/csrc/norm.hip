@@ -40,17 +40,15 @@ __global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, fl
 }
 
 // ------------------------------------------------------------------ BN finalize --------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                   float* __restrict__ coef, float* __restrict__ saved, int64_t C, float n, float eps,
-                                   float momentum, int training) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__device__ __forceinline__ void bn_finalize_channel(float s, float q, int64_t c, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ rmean,
+                                                    float* __restrict__ rvar, float* __restrict__ coef, float* __restrict__ saved,
+                                                    int64_t C, float n, float eps, float momentum, int training) {
   float mean, var;
   if (training) {
     // sums arrive in f32; the subtraction is done in double to keep E[x^2]-E[x]^2 benign
-    const double m = (double)stats[c] / n;
-    double v = (double)stats[C + c] / n - m * m;
+    const double m = (double)s / n;
+    double v = (double)q / n - m * m;
     if (v < 0) v = 0;
     mean = (float)m;
     var = (float)v;
@@ -70,28 +68,41 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
   if (saved) { saved[c] = mean; saved[C + c] = rstd; }
 }
 
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ coef, float* __restrict__ saved, int64_t C, float n, float eps,
+                                   float momentum, int training) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  bn_finalize_channel(training ? stats[c] : 0.f, training ? stats[C + c] : 0.f, c, gamma, beta, rmean, rvar, coef, saved, C, n, eps,
+                      momentum, training);
+}
+
 // ------------------------------------------------------------------ fixed-order partial sums ----
 // block = 32 columns x 8 partial lanes; each lane strides the partial rows with 4 independent sums.
 // Accumulation is f64: these sums are BatchNorm statistics and gradient reductions, and the
 // network's backward map amplifies relative noise in them by ~1e2-1e3 (measured), so f32 sums
 // of a few hundred partials cost visible gradient parity.
+// one partial lane's share of column c: rows pl, pl+8, ... with 4 independent f64 sums (fixed order)
+__device__ __forceinline__ double partial_lane_sum(const float* __restrict__ partials, int n_part, int64_t ncols, int64_t c, int pl) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int p = pl;
+  for (; p + 24 < n_part; p += 32) {
+    a0 += (double)partials[(int64_t)p * ncols + c];
+    a1 += (double)partials[(int64_t)(p + 8) * ncols + c];
+    a2 += (double)partials[(int64_t)(p + 16) * ncols + c];
+    a3 += (double)partials[(int64_t)(p + 24) * ncols + c];
+  }
+  for (; p < n_part; p += 8) a0 += (double)partials[(int64_t)p * ncols + c];
+  return (a0 + a1) + (a2 + a3);
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int n_part, int64_t ncols,
                                                               float* __restrict__ out0, int64_t split, float* __restrict__ out1) {
   __shared__ double s_acc[8][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + cl;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  if (c < ncols) {
-    int p = pl;
-    for (; p + 24 < n_part; p += 32) {
-      a0 += (double)partials[(int64_t)p * ncols + c];
-      a1 += (double)partials[(int64_t)(p + 8) * ncols + c];
-      a2 += (double)partials[(int64_t)(p + 16) * ncols + c];
-      a3 += (double)partials[(int64_t)(p + 24) * ncols + c];
-    }
-    for (; p < n_part; p += 8) a0 += (double)partials[(int64_t)p * ncols + c];
-  }
-  s_acc[pl][cl] = (a0 + a1) + (a2 + a3);
+  s_acc[pl][cl] = c < ncols ? partial_lane_sum(partials, n_part, ncols, c, pl) : 0.0;
   __syncthreads();
   if (pl == 0 && c < ncols) {
     double s = 0.0;
@@ -99,6 +110,33 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     for (int i = 0; i < 8; ++i) s += s_acc[i][cl];
     if (c < split) out0[c] = (float)s;
     else if (out1) out1[c - split] = (float)s;
+  }
+}
+
+// GEMM-epilogue BN partial sums ([tile][sum | sumsq][C]) -> training-mode BN coefficients, for the main
+// and the residual branch of a unit in ONE launch (blockIdx.y = branch): the fixed-order f64 column
+// reduction of reduce_partials_kernel and the arithmetic of bn_finalize_kernel, without the f32 round
+// trip of the statistics through HBM and without three of the four launches.
+struct BnBranch {
+  const float* partials; int n_part;
+  const float* gamma; const float* beta; float* rmean; float* rvar; float* coef; float* saved; float* stats;
+};
+struct BnBranch2 { BnBranch b[2]; };
+
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(BnBranch2 br, int64_t C, float n, float eps, float momentum) {
+  // block = 16 channels x {sum, sumsq} = 32 columns x 8 partial lanes (the parallelism of reduce_partials_kernel)
+  __shared__ double s_acc[8][33];
+  const BnBranch& b = blockIdx.y ? br.b[1] : br.b[0];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 16 + (cl & 15);
+  s_acc[pl][cl] = c < C ? partial_lane_sum(b.partials, b.n_part, 2 * C, (int64_t)(cl >> 4) * C + c, pl) : 0.0;
+  __syncthreads();
+  if (pl == 0 && cl < 16 && c < C) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s += s_acc[i][cl]; q += s_acc[i][16 + cl]; }
+    if (b.stats) { b.stats[c] = (float)s; b.stats[C + c] = (float)q; }
+    bn_finalize_channel((float)s, (float)q, c, b.gamma, b.beta, b.rmean, b.rvar, b.coef, b.saved, C, n, eps, momentum, 1);
   }
 }
 
@@ -260,6 +298,30 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
 // pass 2a: per-channel constants of the backward apply, folded once by C threads:
 //   dy = G*d1 + Bc*y + Cc   with G = gamma*rstd, Bc = -G*rstd*s2/n, Cc = G*(mean*rstd*s2/n - s1/n)
 // tab = [a1 | b1 | G1 | B1 | C1 | a2 | b2 | G2 | B2 | C2][C]; also emits dgamma = s2, dbeta = s1.
+__device__ __forceinline__ void bn_bwd_table_channel(int c, int C, float s1, float s2, float s1b, float s2b, bool has2,
+                                                     const float* __restrict__ coef, const float* __restrict__ saved,
+                                                     const float* __restrict__ gamma, const float* __restrict__ coef2,
+                                                     const float* __restrict__ saved2, const float* __restrict__ gamma2, float inv_n,
+                                                     float* __restrict__ tab, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
+  {
+    const float q = saved[C + c], w = s2 * inv_n, G = gamma[c] * q;
+    tab[c] = coef[c]; tab[C + c] = coef[C + c]; tab[2 * C + c] = G; tab[3 * C + c] = -G * q * w;
+    tab[4 * C + c] = G * (saved[c] * q * w - s1 * inv_n);
+    if (dbeta) dbeta[c] = s1;
+    if (dgamma) dgamma[c] = s2;
+  }
+  if (has2) {
+    const float q = saved2[C + c], w = s2b * inv_n, G = gamma2[c] * q;
+    tab[5 * C + c] = coef2[c]; tab[6 * C + c] = coef2[C + c]; tab[7 * C + c] = G; tab[8 * C + c] = -G * q * w;
+    tab[9 * C + c] = G * (saved2[c] * q * w - s1b * inv_n);
+    if (dbeta2) dbeta2[c] = s1b;
+    if (dgamma2) dgamma2[c] = s2b;
+  } else {
+    for (int k = 5; k < 10; ++k) tab[k * C + c] = 0.f;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_table_kernel(const float* __restrict__ coef, const float* __restrict__ saved,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            const float* __restrict__ coef2, const float* __restrict__ saved2,
@@ -269,21 +331,35 @@ __global__ __launch_bounds__(256) void bn_bwd_table_kernel(const float* __restri
                                                            float* __restrict__ dbeta2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  {
-    const float q = saved[C + c], w = sums[C + c] * inv_n, G = gamma[c] * q;
-    tab[c] = coef[c]; tab[C + c] = coef[C + c]; tab[2 * C + c] = G; tab[3 * C + c] = -G * q * w;
-    tab[4 * C + c] = G * (saved[c] * q * w - sums[c] * inv_n);
-    if (dbeta) dbeta[c] = sums[c];
-    if (dgamma) dgamma[c] = sums[C + c];
-  }
-  if (coef2) {
-    const float q = saved2[C + c], w = sums2[C + c] * inv_n, G = gamma2[c] * q;
-    tab[5 * C + c] = coef2[c]; tab[6 * C + c] = coef2[C + c]; tab[7 * C + c] = G; tab[8 * C + c] = -G * q * w;
-    tab[9 * C + c] = G * (saved2[c] * q * w - sums2[c] * inv_n);
-    if (dbeta2) dbeta2[c] = sums2[c];
-    if (dgamma2) dgamma2[c] = sums2[C + c];
-  } else {
-    for (int k = 5; k < 10; ++k) tab[k * C + c] = 0.f;
+  const bool has2 = coef2 != nullptr;
+  bn_bwd_table_channel(c, C, sums[c], sums[C + c], has2 ? sums2[c] : 0.f, has2 ? sums2[C + c] : 0.f, has2, coef, saved, gamma, coef2,
+                       saved2, gamma2, inv_n, tab, dgamma, dbeta, dgamma2, dbeta2);
+}
+
+// the same table straight from the unreduced pass-1 partials ([blk][s1 | s2 | s1' | s2'][C]): four f64
+// column sums per channel, then the fold (one launch instead of two)
+__global__ __launch_bounds__(256) void bn_bwd_table_partials_kernel(const float* __restrict__ partials, int n_part,
+                                                                    const float* __restrict__ coef, const float* __restrict__ saved,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ coef2,
+                                                                    const float* __restrict__ saved2, const float* __restrict__ gamma2,
+                                                                    float inv_n, int C, float* __restrict__ tab,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
+  // block = 8 channels x 4 sums = 32 columns x 8 partial lanes
+  __shared__ double s_acc[8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 8 + (cl & 7), k = cl >> 3;
+  const bool has2 = coef2 != nullptr;
+  s_acc[pl][cl] = (c < C && (k < 2 || has2)) ? partial_lane_sum(partials, n_part, 4 * (int64_t)C, (int64_t)k * C + c, pl) : 0.0;
+  __syncthreads();
+  if (pl == 0 && cl < 8 && c < C) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[q] += s_acc[i][q * 8 + cl];
+    bn_bwd_table_channel(c, C, (float)t[0], (float)t[1], (float)t[2], (float)t[3], has2, coef, saved, gamma, coef2, saved2, gamma2,
+                         inv_n, tab, dgamma, dbeta, dgamma2, dbeta2);
   }
 }
 
@@ -385,6 +461,21 @@ extern "C" int lasr_bn_finalize(const float* stats, const float* gamma, const fl
   return 0;
 }
 
+extern "C" int lasr_bn_finalize_partials(const lasr_bn_branch* branches, int n_branches, int64_t C, int64_t n_rows, float eps,
+                                         float momentum, void* stream) {
+  LASR_CHECK_ARG(branches && (n_branches == 1 || n_branches == 2) && C > 0 && n_rows > 0, "lasr_bn_finalize_partials: bad argument");
+  BnBranch2 br;
+  for (int i = 0; i < 2; ++i) {
+    const lasr_bn_branch& q = branches[i < n_branches ? i : 0];
+    LASR_CHECK_ARG(q.partials && q.n_partials > 0 && q.gamma && q.beta && q.coef, "lasr_bn_finalize_partials: null pointer");
+    br.b[i] = {q.partials, q.n_partials, q.gamma, q.beta, q.running_mean, q.running_var, q.coef, q.saved, q.stats};
+  }
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3((unsigned)cdiv(C, 16), (unsigned)n_branches), dim3(256), 0, as_stream(stream), br, C,
+                     (float)n_rows, eps, momentum);
+  LASR_LAUNCH_CHECK("bn_finalize_partials_kernel");
+  return 0;
+}
+
 static int check_bn_shape(const char* who, int dtype, int64_t B, int64_t T_, int64_t C) {
   LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "%s: bad dtype", who);
   const int v = dtype == LASR_F32 ? 4 : 8;
@@ -407,15 +498,16 @@ extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2,
 }
 
 extern "C" size_t lasr_bn_bwd_workspace_bytes(int64_t B, int64_t T_, int64_t C) {
-  return (size_t)cdiv(B * T_, kRowsPerBlock) * 4 * C * sizeof(float);
+  // pass-1 partials [blk][4][C], then the folded constants [10][C] of pass 2
+  return (size_t)cdiv(B * T_, kRowsPerBlock) * 4 * C * sizeof(float) + (size_t)10 * C * sizeof(float);
 }
 
 extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const float* coef, const float* saved, const void* y2,
                                      const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
                                      float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
                                      void* workspace, size_t workspace_bytes, void* stream) {
-  LASR_CHECK_ARG(dout && y && coef && saved && sums && workspace, "lasr_bn_act_bwd_stats: null pointer");
-  LASR_CHECK_ARG(!y2 || (coef2 && saved2 && sums2), "lasr_bn_act_bwd_stats: branch-2 pointers");
+  LASR_CHECK_ARG(dout && y && coef && saved && workspace, "lasr_bn_act_bwd_stats: null pointer");
+  LASR_CHECK_ARG(!y2 || (coef2 && saved2 && (sums2 || !sums)), "lasr_bn_act_bwd_stats: branch-2 pointers");
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_stats", dtype, B, T_, C));
   const int64_t rows = B * T_;
   const int nblk = (int)cdiv(rows, kRowsPerBlock);
@@ -430,6 +522,7 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
                                            (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad, partials,
                                            (int)rows, (int)T_, (int)C, act));
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
+  if (!sums) return 0;   // partials stay in the workspace for lasr_bn_act_bwd_apply(sums = NULL)
   return launch_reduce_partials(partials, nblk, 4 * C, sums, 2 * C, sums2, as_stream(stream));
 }
 
@@ -441,16 +534,28 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
                                      const float* sums2, const int32_t* row_lens, void* dy, void* dy2, float* dgamma,
                                      float* dbeta, float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T_, int64_t C,
                                      int act, void* workspace, size_t workspace_bytes, void* stream) {
-  LASR_CHECK_ARG(dout && y && coef && saved && gamma && sums && dy && workspace, "lasr_bn_act_bwd_apply: null pointer");
-  LASR_CHECK_ARG(!y2 || (coef2 && saved2 && gamma2 && sums2 && dy2), "lasr_bn_act_bwd_apply: branch-2 pointers");
+  LASR_CHECK_ARG(dout && y && coef && saved && gamma && dy && workspace, "lasr_bn_act_bwd_apply: null pointer");
+  LASR_CHECK_ARG(!y2 || (coef2 && saved2 && gamma2 && (sums2 || !sums) && dy2), "lasr_bn_act_bwd_apply: branch-2 pointers");
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_apply", dtype, B, T_, C));
-  if (workspace_bytes < lasr_bn_bwd_apply_workspace_bytes(C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
   const int64_t rows = B * T_;
-  float* tab = reinterpret_cast<float*>(workspace);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_table_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, coef, saved, gamma, sums, y2 ? coef2 : nullptr,
-                     saved2, gamma2, sums2, 1.0f / (float)rows, (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
-  LASR_LAUNCH_CHECK("bn_bwd_table_kernel");
+  float* tab;
+  if (sums) {
+    if (workspace_bytes < lasr_bn_bwd_apply_workspace_bytes(C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
+    tab = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(bn_bwd_table_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, coef, saved, gamma, sums, y2 ? coef2 : nullptr,
+                       saved2, gamma2, sums2, 1.0f / (float)rows, (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
+    LASR_LAUNCH_CHECK("bn_bwd_table_kernel");
+  } else {
+    // the workspace of the preceding lasr_bn_act_bwd_stats(sums = NULL): unreduced partials, then room for the table
+    if (workspace_bytes < lasr_bn_bwd_workspace_bytes(B, T_, C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
+    const int nblk = (int)cdiv(rows, kRowsPerBlock);
+    const float* partials = reinterpret_cast<const float*>(workspace);
+    tab = reinterpret_cast<float*>(workspace) + (size_t)nblk * 4 * C;
+    hipLaunchKernelGGL(bn_bwd_table_partials_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, st, partials, nblk, coef, saved, gamma,
+                       y2 ? coef2 : nullptr, saved2, gamma2, 1.0f / (float)rows, (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
+    LASR_LAUNCH_CHECK("bn_bwd_table_partials_kernel");
+  }
   const size_t shmem = (size_t)10 * C * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_apply: C too large for the LDS coefficient table");
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,

@@ -131,6 +131,57 @@ def bn_finalize(stats, gamma, beta, running_mean, running_var, n_rows: int, eps:
     return coef, saved
 
 
+class _GemmProblem(_lib.C.Structure):
+    _fields_ = [("A", _lib.C.c_void_p), ("B", _lib.C.c_void_p), ("C", _lib.C.c_void_p), ("M", _lib.C.c_int64), ("N", _lib.C.c_int64),
+                ("K", _lib.C.c_int64), ("bias", _lib.C.c_void_p), ("row_lens", _lib.C.c_void_p), ("rows_per_seq", _lib.C.c_int64),
+                ("stats", _lib.C.c_void_p)]
+
+
+class _BnBranch(_lib.C.Structure):
+    _fields_ = [("partials", _lib.C.c_void_p), ("n_partials", _lib.C.c_int), ("gamma", _lib.C.c_void_p), ("beta", _lib.C.c_void_p),
+                ("running_mean", _lib.C.c_void_p), ("running_var", _lib.C.c_void_p), ("coef", _lib.C.c_void_p),
+                ("saved", _lib.C.c_void_p), ("stats", _lib.C.c_void_p)]
+
+
+def gemm_bn_fused(xs, ws_, bns, row_lens=None, rows_per_seq: int = 0, eps: float = 1e-3, momentum: float = 0.1):
+    """A unit's 1x1 convolutions (1 or 2 problems: y_i = x_i @ w_i^T, the first optionally row-masked) with
+    training-mode BN coefficients from the epilogue's partial sums in one reduce+finalize launch.
+    bns[i] = (gamma, beta, running_mean, running_var).  Returns ([y_i], [coef_i], [saved_i], [stats_i])."""
+    n = len(xs)
+    dev = xs[0].device
+    M = xs[0].shape[0]
+    probs = (_GemmProblem * 2)()
+    ys, coefs, saveds, stats = [], [], [], []
+    for i in range(n):
+        N, K = ws_[i].shape
+        y = torch.empty(M, N, dtype=xs[i].dtype, device=dev)
+        st = torch.empty(2 * N, dtype=torch.float32, device=dev)
+        probs[i].A, probs[i].B, probs[i].C = _p(xs[i]), _p(ws_[i]), _p(y)
+        probs[i].M, probs[i].N, probs[i].K = M, N, K
+        probs[i].bias = None
+        probs[i].row_lens = _p(row_lens) if (i == 0 and row_lens is not None) else None
+        probs[i].rows_per_seq = rows_per_seq if i == 0 else 0
+        probs[i].stats = _p(st)
+        ys.append(y); stats.append(st)
+    nb = sum(_lib.load().lasr_gemm_workspace_bytes(M, ws_[i].shape[0], 1, 1) for i in range(n))
+    wsb = _ws(nb, dev)
+    parts = (_lib.C.c_void_p * 2)()
+    tiles = (_lib.C.c_int * 2)()
+    call("lasr_gemm_batch_partials", probs, n, _dt(xs[0]), _dt(xs[0]), 0, 0, _p(wsb), wsb.numel(), parts, tiles, _stream())
+    brs = (_BnBranch * 2)()
+    for i in range(n):
+        N = ws_[i].shape[0]
+        g, b, rm, rv = bns[i]
+        coef = torch.empty(2 * N, dtype=torch.float32, device=dev)
+        saved = torch.empty(2 * N, dtype=torch.float32, device=dev)
+        brs[i].partials, brs[i].n_partials = parts[i], tiles[i]
+        brs[i].gamma, brs[i].beta, brs[i].running_mean, brs[i].running_var = _p(g), _p(b), _p(rm), _p(rv)
+        brs[i].coef, brs[i].saved, brs[i].stats = _p(coef), _p(saved), _p(stats[i])
+        coefs.append(coef); saveds.append(saved)
+    call("lasr_bn_finalize_partials", brs, n, ws_[0].shape[0], M, eps, momentum, _stream())
+    return ys, coefs, saveds, stats
+
+
 def bn_act(y, coef, y2=None, coef2=None, se_scale=None, act: str = "relu") -> torch.Tensor:
     B, T, Cc = y.shape
     out = torch.empty_like(y)
@@ -139,14 +190,16 @@ def bn_act(y, coef, y2=None, coef2=None, se_scale=None, act: str = "relu") -> to
 
 
 def bn_act_bwd(dout, y, coef, saved, gamma, y2=None, coef2=None, saved2=None, gamma2=None, se_scale=None, se_grad=None,
-               row_lens=None, act: str = "relu"):
-    """Returns (dy, dy2, dgamma, dbeta, dgamma2, dbeta2)."""
+               row_lens=None, act: str = "relu", fused: bool = False):
+    """Returns (dy, dy2, dgamma, dbeta, dgamma2, dbeta2).  fused: pass 2 reduces pass 1's partial sums itself."""
     B, T, Cc = y.shape
     dev = y.device
     sums = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
     sums2 = torch.empty(2 * Cc, dtype=torch.float32, device=dev)
     nb = max(_lib.load().lasr_bn_bwd_workspace_bytes(B, T, Cc), _lib.load().lasr_bn_bwd_apply_workspace_bytes(Cc))
     ws = _ws(nb, dev)
+    if fused:
+        sums = sums2 = None
     call("lasr_bn_act_bwd_stats", _p(dout), _p(y), _p(coef), _p(saved), _p(y2), _p(coef2), _p(saved2), _p(se_scale),
          _p(se_grad), _p(sums), _p(sums2), _dt(y), B, T, Cc, ACT[act], _p(ws), nb, _stream())
     dy = torch.empty_like(y)

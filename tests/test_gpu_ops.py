@@ -225,6 +225,11 @@ def test_bn_act_fwd_bwd(dev, C, has_res, act, masked):
     if has_res:
         assert max_rel(dy2.transpose(1, 2), y2.grad) < 2e-5
         assert max_rel(dg2, gam2.grad) < 2e-5 and max_rel(db2, bet2.grad) < 2e-5
+    # fused hand-over (pass 2 reduces pass 1's partial sums itself): bit-identical to the two-launch path
+    fz = ops.bn_act_bwd(cl(dout), yg, coef, saved, gam.detach().to(dev), y2g, coef2, saved2,
+                        gam2.detach().to(dev) if has_res else None, row_lens=lens.to(dev) if masked else None, act=act, fused=True)
+    for a_, b_ in zip(fz, (dy, dy2, dg, db, dg2, db2)):
+        assert (a_ is None and b_ is None) or torch.equal(a_, b_)
     # eval mode: coefficients from the running statistics
     coef_e, _ = ops.bn_finalize(None, gam.detach().to(dev), bet.detach().to(dev), grm, grv, N, training=False)
     ref_e = F.batch_norm(ym.detach(), grm.cpu(), grv.cpu(), gam.detach(), bet.detach(), False, 0.1, 1e-3)
@@ -419,3 +424,27 @@ def test_gemm_bf16_big_tile_epilogue(dev):
     assert max_rel(stats[:N], gf.sum(0)) < 1e-5
     assert max_rel(stats[N:], (gf * gf).sum(0)) < 1e-5
     assert torch.all(got.view(B, T, N)[1] == 0)
+
+
+@pytest.mark.parametrize("dtype,M,T", [(torch.bfloat16, 16032, 501), (torch.float32, 600, 200), (torch.bfloat16, 777, 259)])
+def test_gemm_bn_fused_matches_unfused(dev, dtype, M, T):
+    """lasr_gemm_batch_partials + lasr_bn_finalize_partials (one reduce+finalize launch for the main and the
+    residual branch) against lasr_gemm(stats) + lasr_bn_finalize per branch: same sums, same coefficients."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(M)
+    K, N, B = 256, 512, M // T
+    xs = [torch.randn(M, K, generator=g).to(dtype).to(dev) for _ in range(2)]
+    ws_ = [(torch.randn(N, K, generator=g) / 16).to(dtype).to(dev) for _ in range(2)]
+    lens = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32).to(dev)
+    mk = lambda: (torch.rand(N, generator=g).to(dev) + 0.5, torch.randn(N, generator=g).to(dev), torch.zeros(N, device=dev), torch.ones(N, device=dev))
+    bns, bns_ref = [mk(), mk()], None
+    bns_ref = [(a, b, torch.zeros(N, device=dev), torch.ones(N, device=dev)) for (a, b, _, _) in bns]
+    ys, coefs, saveds, stats = ops.gemm_bn_fused(xs, ws_, bns, row_lens=lens, rows_per_seq=T)
+    for i in range(2):
+        y_ref, st_ref = ops.gemm(xs[i], ws_[i], M, N, K, row_lens=lens if i == 0 else None, rows_per_seq=T if i == 0 else 0,
+                                 want_stats=True)
+        coef_ref, saved_ref = ops.bn_finalize(st_ref, bns_ref[i][0], bns_ref[i][1], bns_ref[i][2], bns_ref[i][3], M)
+        assert torch.equal(ys[i], y_ref)
+        assert torch.equal(stats[i], st_ref)
+        assert torch.equal(coefs[i], coef_ref) and torch.equal(saveds[i], saved_ref)
+        assert torch.equal(bns[i][2], bns_ref[i][2]) and torch.equal(bns[i][3], bns_ref[i][3])
