@@ -290,6 +290,126 @@ __global__ __launch_bounds__(256) void dwconv_s1_kernel(const T* __restrict__ x,
   }
 }
 
+// bf16 stride-1 depthwise conv on the packed dot unit: v_dot2c_f32_bf16 does two bf16 MACs into an f32
+// accumulator per lane per issue, so pairing taps (j, j+1) halves the VALU work that bounds the f32-FMA
+// form above (2*k FLOP per output element against 32 B of traffic: the kernel is VALU-, not HBM-bound).
+// Same tiling (64 channels x 128 frames per workgroup, lane = 4 channels x 8 outputs).  The operands are
+//   P[u][ch]  = (x[u][ch], x[u+1][ch])   built by one v_perm_b32 from two consecutive LDS rows,
+//   W2[jp][ch] = (w[2jp][ch], w[2jp+1][ch])  packed when the taps are staged,
+// and output r accumulates dot2(P[tb + r + 2jp], W2[jp]) over jp.  A ring of 8 P registers per channel
+// slides two frames per tap pair: 2 row reads (8 B), 1 tap read (16 B), 8 v_perm and 32 dot2 per lane
+// per 64 MACs.  Products of bf16 operands are exact in f32, as in the FMA form (whose taps are bf16 too).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+// (lo16 of a, lo16 of b) and (hi16 of a, hi16 of b)
+__device__ __forceinline__ uint32_t pair_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+__device__ __forceinline__ uint32_t pair_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__global__ __launch_bounds__(256) void dwconv_s1_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                             const bf16_t* __restrict__ addend, bf16_t* __restrict__ y, int64_t Tlen,
+                                                             int64_t C, int k, int flip) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  using P = S1<bf16_t>;
+  const int pad = k / 2;
+  const int kpad = (k + 7) & ~7;
+  const int in_rows = kTT + kpad + 8;
+  uint32_t* s_w2 = reinterpret_cast<uint32_t*>(smem_raw);                                    // [kpad/2][kCB] tap pairs
+  bf16_t* s_x = reinterpret_cast<bf16_t*>(smem_raw + (size_t)(kpad / 2) * kCB * sizeof(uint32_t));  // [in_rows][72]
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * kCB;
+  const int t0 = blockIdx.x * kTT;
+  const bf16_t* xb = x + (int64_t)b * Tlen * C;
+  {
+    const int lr = threadIdx.x / P::kLanesPerRow, lc = (threadIdx.x % P::kLanesPerRow) * P::kVec;
+    const bool c_in = c0 + lc < C;
+    uint4 v[P::kPasses];
+#pragma unroll
+    for (int p = 0; p < P::kPasses; ++p) {
+      const int r = lr + p * P::kRowsPerPass;
+      const int64_t ti = (int64_t)t0 - pad + r;
+      v[p] = make_uint4(0u, 0u, 0u, 0u);
+      if (r < in_rows && c_in && ti >= 0 && ti < Tlen) v[p] = *reinterpret_cast<const uint4*>(xb + ti * C + c0 + lc);
+    }
+#pragma unroll
+    for (int p = 0; p < P::kPasses; ++p) {
+      const int r = lr + p * P::kRowsPerPass;
+      if (r < in_rows) *reinterpret_cast<uint4*>(s_x + (size_t)r * P::kTileLd + lc) = v[p];
+    }
+  }
+  for (int i = threadIdx.x; i < (kpad / 2) * kCB; i += 256) {
+    const int jp = i >> 6, ch = i & (kCB - 1);
+    float v0 = 0.f, v1 = 0.f;
+    if (c0 + ch < C) {
+      const float* wc = w + (int64_t)(c0 + ch) * k;
+      const int j0 = 2 * jp, j1 = 2 * jp + 1;
+      if (j0 < k) v0 = wc[flip ? (k - 1 - j0) : j0];
+      if (j1 < k) v1 = wc[flip ? (k - 1 - j1) : j1];
+    }
+    s_w2[i] = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+  }
+  __syncthreads();
+
+  const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int c = c0 + cl * 4;
+  float acc[kR][4];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
+  const char* xs = reinterpret_cast<const char*>(s_x + (size_t)(tl * kR) * P::kTileLd + cl * 4);
+  constexpr int LD = P::kTileLd * 2;   // bytes per LDS row
+  const uint32_t* ws = s_w2 + cl * 4;
+  uint32_t pw[8][4];
+  uint2 prev = *reinterpret_cast<const uint2*>(xs);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const uint2 nx = *reinterpret_cast<const uint2*>(xs + (u + 1) * LD);
+    pw[u][0] = pair_lo(prev.x, nx.x); pw[u][1] = pair_hi(prev.x, nx.x);
+    pw[u][2] = pair_lo(prev.y, nx.y); pw[u][3] = pair_hi(prev.y, nx.y);
+    prev = nx;
+  }
+  // prev = row tb+8
+  const int npair = kpad / 2;
+  for (int jp0 = 0; jp0 < npair; jp0 += 4) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int jp = jp0 + q;
+      const uint4 wv = *reinterpret_cast<const uint4*>(ws + jp * kCB);
+      const uint2 ra = *reinterpret_cast<const uint2*>(xs + (2 * jp + 9) * LD);
+      const uint2 rb = *reinterpret_cast<const uint2*>(xs + (2 * jp + 10) * LD);
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int sl = (r + 2 * q) & 7;
+        acc[r][0] = dot2_bf16(pw[sl][0], wv.x, acc[r][0]);
+        acc[r][1] = dot2_bf16(pw[sl][1], wv.y, acc[r][1]);
+        acc[r][2] = dot2_bf16(pw[sl][2], wv.z, acc[r][2]);
+        acc[r][3] = dot2_bf16(pw[sl][3], wv.w, acc[r][3]);
+      }
+      const int s0 = (2 * q) & 7, s1 = (2 * q + 1) & 7;
+      pw[s0][0] = pair_lo(prev.x, ra.x); pw[s0][1] = pair_hi(prev.x, ra.x);
+      pw[s0][2] = pair_lo(prev.y, ra.y); pw[s0][3] = pair_hi(prev.y, ra.y);
+      pw[s1][0] = pair_lo(ra.x, rb.x); pw[s1][1] = pair_hi(ra.x, rb.x);
+      pw[s1][2] = pair_lo(ra.y, rb.y); pw[s1][3] = pair_hi(ra.y, rb.y);
+      prev = rb;
+    }
+  }
+  if (c >= C) return;
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int64_t t = (int64_t)t0 + tl * kR + r;
+    if (t < Tlen) {
+      const int64_t off = ((int64_t)b * Tlen + t) * C + c;
+      float o[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+      if (addend) {
+        float a[4];
+        Elem<bf16_t>::ld4(addend + off, a);
+        o[0] += a[0]; o[1] += a[1]; o[2] += a[2]; o[3] += a[3];
+      }
+      Elem<bf16_t>::st4(y + off, o);
+    }
+  }
+}
+
 // Weight gradient, stride 1.  Lane = 4 channels x 8 consecutive taps (group jg) x one time split;
 // the 8 frames x[t+j0 .. t+j0+7] slide through a register window as t advances, so a frame costs
 // two LDS vector reads (new x row, dy row) for 32 FMAs.  16 lane groups per workgroup are dealt as
@@ -407,9 +527,16 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
       hipLaunchKernelGGL(dwconv_s1_kernel<float>, grid, dim3(256), sh1, as_stream(stream), (const float*)x, w, (const float*)addend,
                          (float*)y, Tin, C, k, flip);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(dwconv_s1_kernel<bf16_t>, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, w,
-                         (const bf16_t*)addend, (bf16_t*)y, Tin, C, k, flip);
+      static const bool fma_form = getenv("LASR_DWCONV_FMA") != nullptr;   // A/B switch: the f32-FMA form of the same kernel
+      if (fma_form) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(dwconv_s1_kernel<bf16_t>, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, w,
+                           (const bf16_t*)addend, (bf16_t*)y, Tin, C, k, flip);
+      } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(dwconv_s1_bf16_kernel, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, w, (const bf16_t*)addend,
+                           (bf16_t*)y, Tin, C, k, flip);
+      }
     }
   } else if (dtype == LASR_F32) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

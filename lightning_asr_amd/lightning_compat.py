@@ -289,8 +289,11 @@ class Trainer:
     def test(self, model, test_dataloaders=None, datamodule=None):
         model.trainer = self
         model.eval()
-        loader = test_dataloaders if test_dataloaders is not None else datamodule.test_dataloader()
         dm = datamodule or self.datamodule
+        if test_dataloaders is None and dm is not None and dm is not self.datamodule:
+            dm.trainer = self
+            dm.setup("test")                       # PL calls setup('test') on a datamodule handed to .test()
+        loader = test_dataloaders if test_dataloaders is not None else dm.test_dataloader()
         outs = [model.test_step(self._batch(batch, dm), i) for i, batch in enumerate(loader)]
         model.test_epoch_end(outs)
         return outs

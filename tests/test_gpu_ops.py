@@ -124,6 +124,28 @@ def test_dwconv_bf16(dev):
     assert max_rel(got.float().transpose(1, 2), ref) < 1e-2
 
 
+@pytest.mark.parametrize("C,k,T", [(256, 33, 501), (512, 75, 260), (336, 51, 77), (512, 87, 130), (64, 1, 40), (72, 5, 300)])
+def test_dwconv_bf16_dot2_exact_taps(dev, C, k, T):
+    """bf16 stride-1 kernel (tap pairs on v_dot2c_f32_bf16): activations and taps are bf16, products exact in
+    f32, so against an f64 convolution of the same bf16 operands only the f32 accumulation order and the
+    final bf16 rounding differ.  Forward, and the flipped form with an addend (data gradient)."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C * 3 + k)
+    B = 3
+    x = torch.randn(B, C, T, generator=g).bfloat16()
+    w = (torch.randn(C, 1, k, generator=g) / math.sqrt(k))
+    wq = w.bfloat16().double()
+    ref = F.conv1d(x.double(), wq, None, 1, k // 2, 1, C)
+    xg = x.transpose(1, 2).contiguous().to(dev)
+    got = ops.dwconv(xg, w.to(dev))
+    assert got.dtype == torch.bfloat16
+    assert max_rel(got.double().cpu().transpose(1, 2), ref) < 4e-3          # one bf16 rounding (2^-9) of the result
+    add = torch.randn(B, T, C, generator=g).bfloat16()
+    ref_f = F.conv1d(x.double(), wq.flip(2), None, 1, k // 2, 1, C) + add.double().transpose(1, 2)
+    got_f = ops.dwconv(xg, w.to(dev), 1, flip=True, addend=add.to(dev))
+    assert max_rel(got_f.double().cpu().transpose(1, 2), ref_f) < 4e-3
+
+
 # ----------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,tA,tB", [(300, 256, 64, 0, 0), (257, 130, 100, 0, 1), (96, 200, 515, 1, 1), (128, 28, 1024, 1, 0),
                                          (1000, 28, 1024, 0, 0), (70, 1024, 28, 0, 1), (33, 50, 4334, 0, 0), (200, 4334, 64, 0, 0)])
