@@ -109,6 +109,13 @@ size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs, int n_pro
 int lasr_gemm_batch(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
                     int split_k, void* workspace, size_t workspace_bytes, void* stream);
 
+/* lasr_gemm with explicit leading dimensions (elements; 0 = the packed default) and no masking / statistics:
+ * operands or results that are sub-blocks or row-padded copies of a larger matrix.  bf16 operands take the
+ * aligned 16-byte path when the pitch is a multiple of 8 and the base 16-byte aligned, whatever M, N, K. */
+int lasr_gemm_ld(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int dtype_ab, int dtype_c,
+                 int64_t M, int64_t N, int64_t K, int transA, int transB, const float* bias, int split_k, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
 /* lasr_gemm_batch that leaves each problem's BN partial sums UNREDUCED in the workspace (no split-K):
  * for every problem with stats != NULL, stat_partials[i] points at [stat_tiles[i]][2][N] f32 inside
  * `workspace` (valid until the workspace is reused) and problem.stats itself is not written.
@@ -259,6 +266,8 @@ int64_t lasr_edit_distance(const int32_t* a, int64_t na, const int32_t* b, int64
 
 /* small helpers used by the plan and by the host */
 int lasr_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* out[r][0..cols) = bf16(in[r][:]), out[r][cols..ld_out) = 0: row-padded bf16 copy (ld_out % 8 == 0 keeps rows 16-byte aligned) */
+int lasr_cast_pad_f32_to_bf16(const float* in, void* out, int64_t rows, int64_t cols, int64_t ld_out, void* stream);
 size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C);
 int lasr_colsum_f32(const float* x, float* out, int64_t rows, int64_t C, void* workspace, size_t workspace_bytes,
                     void* stream);                                   /* out[c] = sum_r x[r][c] (decoder bias grad) */

@@ -261,7 +261,7 @@ struct StatOut { const float* partials; int tiles; };
 static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,
                      int transA, int transB, const float* bias, const void* addend, const int32_t* row_lens,
                      int64_t rows_per_seq, float* stats, int split_k, void* workspace, size_t workspace_bytes,
-                     void* stream, StatOut* stat_out) {
+                     void* stream, StatOut* stat_out, int64_t lda = 0, int64_t ldb = 0, int64_t ldc = 0) {
   LASR_CHECK_ARG(A && B && C, "lasr_gemm: null pointer");
   LASR_CHECK_ARG((dtype_ab == LASR_F32 || dtype_ab == LASR_BF16) && (dtype_c == LASR_F32 || dtype_c == LASR_BF16), "lasr_gemm: bad dtype");
   LASR_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && split_k >= 1 && split_k <= 1024, "lasr_gemm: M=%lld N=%lld K=%lld split=%d",
@@ -272,7 +272,8 @@ static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dt
   if (need > 0 && (!workspace || workspace_bytes < need)) return fail(LASR_E_WORKSPACE, "lasr_gemm: workspace %zu < %zu", workspace_bytes, need);
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
-  g.lda = transA ? M : K; g.ldb = transB ? N : K; g.ldc = N;
+  g.lda = lda > 0 ? lda : (transA ? M : K); g.ldb = ldb > 0 ? ldb : (transB ? N : K); g.ldc = ldc > 0 ? ldc : N;
+  LASR_CHECK_SHAPE(g.lda >= (transA ? M : K) && g.ldb >= (transB ? N : K) && g.ldc >= N, "lasr_gemm: leading dimension smaller than the row");
   g.bias = bias; g.addend = addend; g.row_lens = row_lens; g.rows_per_seq = rows_per_seq;
   g.stat_partials = nullptr; g.split_ws = nullptr;
   const size_t esz = dtype_size(dtype_ab);
@@ -318,6 +319,13 @@ static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dt
     LASR_TRY(launch_reduce_partials(g.stat_partials, grid_m, 2 * N, stats, 2 * N, nullptr, st));
   }
   return 0;
+}
+
+extern "C" int lasr_gemm_ld(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int dtype_ab, int dtype_c,
+                            int64_t M, int64_t N, int64_t K, int transA, int transB, const float* bias, int split_k, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  return gemm_impl(A, B, C, dtype_ab, dtype_c, M, N, K, transA, transB, bias, nullptr, nullptr, 0, nullptr, split_k, workspace,
+                   workspace_bytes, stream, nullptr, lda, ldb, ldc);
 }
 
 extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,

@@ -51,6 +51,14 @@ struct Bf16Batch { Bf16Args p[2]; int tiles0, total; };
 // when they are written to LDS (chunks past the M/N edge repeat the last row: those outputs are never
 // stored).  Per-lane bounds branches around the loads (the generic path, kept for unaligned shapes)
 // make the compiler drain vmcnt at every join.
+// 16-byte chunk of 8 bf16 of which the first `nvalid` (any integer; <= 0 none, >= 8 all) are inside the K range
+__device__ __forceinline__ uint4 mask_chunk(const uint4& v, int nvalid) {
+  const int n = max(0, min(nvalid, 8));
+  if (n == 8) return v;                                  // wave-uniform in every aligned-K problem
+  auto dm = [n](int i) -> uint32_t { return n >= 2 * i + 2 ? 0xffffffffu : (n == 2 * i + 1 ? 0x0000ffffu : 0u); };
+  return make_uint4(v.x & dm(0), v.y & dm(1), v.z & dm(2), v.w & dm(3));
+}
+
 template <bool TRANS, int ROWS, int NT>
 __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, uint4 (&reg)[4]) {
   constexpr int RCH = ROWS / 8;
@@ -59,8 +67,8 @@ __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, i
   for (int p = 0; p < 4; ++p) {
     const int c = tid + NT * p;
     uint32_t off;
-    if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), kend - 8);
-    else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), R - 8);
+    if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), ((kend + 7) & ~7) - 8);
+    else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), ((R + 7) & ~7) - 8);
     reg[p] = *reinterpret_cast<const uint4*>(X + off);
   }
 }
@@ -72,10 +80,11 @@ __device__ __forceinline__ void store_vec(char* __restrict__ s, const uint4 (&re
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int c = tid + NT * p;
-    const bool valid = !TRANS ? (k0 + ((c & 7) << 3) < kend) : (k0 + c / RCH < kend);
+    // elements past the K range become zero: whole k-rows of a row-contiguous operand, the tail elements of a
+    // K-contiguous chunk (K need not be a multiple of 8; the pitch is, so the chunk itself is in bounds)
+    const int nvalid = !TRANS ? kend - (k0 + ((c & 7) << 3)) : (k0 + c / RCH < kend ? 8 : 0);
     const int off = !TRANS ? (c >> 3) * LDK_ + ((c & 7) << 4) : (c / RCH) * LDR_ + ((c % RCH) << 4);
-    const uint32_t mk = valid ? 0xffffffffu : 0u;   // AND, not select: keeps the K loop free of exec-mask branches
-    *reinterpret_cast<uint4*>(s + off) = make_uint4(reg[p].x & mk, reg[p].y & mk, reg[p].z & mk, reg[p].w & mk);
+    *reinterpret_cast<uint4*>(s + off) = mask_chunk(reg[p], nvalid);
   }
 }
 
@@ -85,18 +94,17 @@ __device__ __forceinline__ uint4 load_chunk(const bf16_t* __restrict__ X, int ld
   constexpr int RCH = ROWS / 8;
   const int c = threadIdx.x + NT * p;
   uint32_t off;
-  if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), kend - 8);
-  else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), R - 8);
+  if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), ((kend + 7) & ~7) - 8);
+  else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), ((R + 7) & ~7) - 8);
   return *reinterpret_cast<const uint4*>(X + off);
 }
 template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_>
 __device__ __forceinline__ void store_chunk(char* __restrict__ s, const uint4& v, int k0, int kend, int p) {
   constexpr int RCH = ROWS / 8;
   const int c = threadIdx.x + NT * p;
-  const bool valid = !TRANS ? (k0 + ((c & 7) << 3) < kend) : (k0 + c / RCH < kend);
+  const int nvalid = !TRANS ? kend - (k0 + ((c & 7) << 3)) : (k0 + c / RCH < kend ? 8 : 0);
   const int off = !TRANS ? (c >> 3) * LDK_ + ((c & 7) << 4) : (c / RCH) * LDR_ + ((c % RCH) << 4);
-  const uint32_t mk = valid ? 0xffffffffu : 0u;
-  *reinterpret_cast<uint4*>(s + off) = make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+  *reinterpret_cast<uint4*>(s + off) = mask_chunk(v, nvalid);
 }
 
 // generic path: any pitch/alignment, element-granular edges

@@ -236,7 +236,7 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   p.o_scratch = take(cur, scratch);
   p.o_g[0] = take(cur, (size_t)N * cmax * es);
   p.o_g[1] = take(cur, (size_t)N * cmax * es);
-  p.o_d1 = take(cur, (size_t)N * std::max<int64_t>(cmax, C) * es);
+  p.o_d1 = take(cur, (size_t)N * std::max<int64_t>(cmax, (C + 7) / 8 * 8) * es);   // dy, or the row-padded bf16 logit gradient
   p.o_d2 = take(cur, (size_t)N * cmax * es);
   p.o_du = take(cur, (size_t)N * cmax * es);
   p.o_dxr = take(cur, (size_t)N * cmax * es);
@@ -413,15 +413,17 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   cur = 0;
   // decoder (models/QuartNet.py:275): dW = gl^T h, db = colsum(gl), dh = gl W
   const void* gl_ab = gl;
-  if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient
-    LASR_TRY(lasr_cast_f32_to_bf16(gl, at(ws, p.o_d1), N * C, stream));
+  int64_t ld_gl = C;
+  if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient, rows padded to 16-byte multiples
+    ld_gl = (C + 7) / 8 * 8;
+    LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
     gl_ab = at(ws, p.o_d1);
   }
-  LASR_TRY(lasr_gemm(gl_ab, at(ws, last.o_out), grads + m->w_dec, dt, LASR_F32, C, 1024, N, 1, 1, nullptr, nullptr, nullptr, 0,
-                     nullptr, 16, scratch, sb, stream));
+  LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr, 16,
+                        scratch, sb, stream));
   LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
-  LASR_TRY(lasr_gemm(gl_ab, wptr(m, params, ws, m->w_dec), at(ws, p.o_g[cur]), dt, dt, N, 1024, C, 0, 1, nullptr, nullptr, nullptr,
-                     0, nullptr, 1, scratch, sb, stream));
+  LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, wptr(m, params, ws, m->w_dec), 1024, at(ws, p.o_g[cur]), 1024, dt, dt, N, 1024, C, 0, 1, nullptr,
+                        1, scratch, sb, stream));
   }
   if (unit_hi < 0) unit_hi = (int)m->units.size() - 1;
   for (int ui = unit_hi; ui >= unit_stop; --ui) {

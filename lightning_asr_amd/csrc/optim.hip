@@ -76,6 +76,18 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     out[e] = f32_to_bf16(in[e]);
 }
 
+// out[r][c] = bf16(in[r][c]) for c < cols, 0 for cols <= c < ld_out: a bf16 copy whose rows start on 16-byte
+// boundaries (ld_out % 8 == 0) so that GEMMs over a narrow matrix (the 28-class logit gradient) take the
+// aligned operand path.
+__global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t rows,
+                                                            int64_t cols, int64_t ld_out) {
+  const int64_t total = rows * ld_out;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / ld_out, c = i - r * ld_out;
+    out[i] = c < cols ? f32_to_bf16(in[r * cols + c]) : (bf16_t)0;
+  }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -107,6 +119,16 @@ extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_
   hipLaunchKernelGGL(novograd_update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, offsets, (int)n_tensors,
                      denom, lr, beta1, weight_decay, grad_scale, n_elems);
   LASR_LAUNCH_CHECK("novograd_update_kernel");
+  return 0;
+}
+
+extern "C" int lasr_cast_pad_f32_to_bf16(const float* in, void* out, int64_t rows, int64_t cols, int64_t ld_out, void* stream) {
+  LASR_CHECK_ARG(in && out && rows > 0 && cols > 0 && ld_out >= cols, "lasr_cast_pad_f32_to_bf16: bad argument");
+  int64_t blocks = cdiv(rows * ld_out, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in, reinterpret_cast<bf16_t*>(out), rows,
+                     cols, ld_out);
+  LASR_LAUNCH_CHECK("cast_pad_bf16_kernel");
   return 0;
 }
 

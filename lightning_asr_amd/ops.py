@@ -121,6 +121,17 @@ def gemm(A: torch.Tensor, Bm: torch.Tensor, M: int, N: int, K: int, transA: bool
     return Cm, stats
 
 
+def gemm_ld(A, lda, Bm, ldb, M, N, K, transA=False, transB=False, split_k: int = 1, out_dtype=None, ldc: int = 0):
+    """lasr_gemm_ld: operands given as flat/padded buffers with explicit pitches; returns C (M, ldc or N)."""
+    out_dtype = out_dtype or A.dtype
+    Cm = torch.empty(M, ldc or N, dtype=out_dtype, device=A.device)
+    nb = _lib.load().lasr_gemm_workspace_bytes(M, N, split_k, 0)
+    ws = _ws(nb, A.device)
+    call("lasr_gemm_ld", _p(A), lda, _p(Bm), ldb, _p(Cm), ldc, _dt(A), _dt(Cm), M, N, K, int(transA), int(transB), None, split_k,
+         _p(ws), nb, _stream())
+    return Cm
+
+
 def bn_finalize(stats, gamma, beta, running_mean, running_var, n_rows: int, eps: float = 1e-3, momentum: float = 0.1,
                 training: bool = True):
     Cc = gamma.numel()

@@ -470,3 +470,24 @@ def test_gemm_bn_fused_matches_unfused(dev, dtype, M, T):
         assert torch.equal(stats[i], st_ref)
         assert torch.equal(coefs[i], coef_ref) and torch.equal(saveds[i], saved_ref)
         assert torch.equal(bns[i][2], bns_ref[i][2]) and torch.equal(bns[i][3], bns_ref[i][3])
+
+
+def test_gemm_ld_padded_narrow_operand(dev):
+    """The decoder's backward GEMMs: a 28-column matrix kept in a 32-pitch bf16 buffer whose pad columns hold
+    NaN must give exact results (pad elements are masked / only feed rows that are never stored), on the
+    aligned 16-byte operand path, with K = 28 (not a multiple of 8) and M = 28."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(77)
+    rows, C, H = 16032, 28, 1024
+    gl = torch.randint(-2, 3, (rows, C), generator=g).float()
+    glp = torch.full((rows, 32), float("nan"))
+    glp[:, :C] = gl
+    W = (torch.rand(C, H, generator=g) < 0.1).float()
+    h = torch.randint(-1, 2, (rows, H), generator=g).float()
+    glp_d, W_d, h_d = glp.bfloat16().to(dev), W.bfloat16().to(dev), h.bfloat16().to(dev)
+    # dh = gl W : A K-contiguous with a ragged K and a NaN tail, B row-contiguous
+    dh = ops.gemm_ld(glp_d, 32, W_d, H, rows, H, C, transA=False, transB=True)
+    assert torch.equal(dh.float().cpu(), gl @ W)
+    # dW = gl^T h : A row-contiguous with 28 of 32 columns valid, split-K, f32 result
+    dW = ops.gemm_ld(glp_d, 32, h_d, H, C, H, rows, transA=True, transB=True, split_k=16, out_dtype=torch.float32)
+    assert torch.equal(dW.cpu(), gl.t() @ h)
