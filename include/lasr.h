@@ -259,6 +259,8 @@ int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float*
 enum { LASR_PROF_GEMM = 0, LASR_PROF_DWCONV = 1, LASR_PROF_BN = 2, LASR_PROF_OTHER = 3 };
 int lasr_prof_enable(int on);
 int lasr_prof_collect(double* ms, double* flops, double* bytes, int64_t* count);
+/* mean elapsed ms of n empty event pairs on `stream`: the bracketing overhead included in every ms[] entry */
+int lasr_prof_overhead_ms(void* stream, int n, double* ms_per_pair);
 
 /* Levenshtein distance between two token-id sequences, on the HOST (plain C++, no device work):
  * replaces editdistance.eval at utils/asr_metrics.py:54,220.  Returns -1 on bad arguments.       */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "lasr_edit_distance": (_i64, [_p, _i64, _p, _i64]),
     "lasr_prof_enable": (_i32, [_i32]),
     "lasr_prof_collect": (_i32, [_p, _p, _p, _p]),
+    "lasr_prof_overhead_ms": (_i32, [_p, _i32, _p]),
     "lasr_model_create": (_i32, [C.POINTER(ModelConfig), C.POINTER(_p)]),
     "lasr_model_destroy": (None, [_p]),
     "lasr_model_tensor_info": (_i64, [_p, _i64, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(C.c_int32),

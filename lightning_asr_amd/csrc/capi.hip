@@ -82,6 +82,30 @@ extern "C" int lasr_prof_collect(double* ms, double* flops, double* bytes, int64
   return 0;
 }
 
+// Mean elapsed time of n EMPTY event pairs on `stream` (ms): what the bracketing itself adds to every
+// instrumented launch (two event packets the command processor must retire in order).  bench.py subtracts
+// it, so that its per-launch kernel time lines up with rocprofv3's kernel-trace durations.
+extern "C" int lasr_prof_overhead_ms(void* stream, int n, double* ms_per_pair) {
+  using namespace lasr;
+  LASR_CHECK_ARG(n > 0 && n <= 4096 && ms_per_pair, "lasr_prof_overhead_ms: bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev((size_t)2 * n);
+  for (auto& e : ev) e = get_event();
+  for (int i = 0; i < n; ++i) { (void)hipEventRecord(ev[2 * i], st); (void)hipEventRecord(ev[2 * i + 1], st); }
+  hipError_t e = hipEventSynchronize(ev.back());
+  if (e != hipSuccess) return hip_fail(e, "lasr_prof_overhead_ms");
+  double tot = 0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+    if (e != hipSuccess) return hip_fail(e, "lasr_prof_overhead_ms");
+    tot += t;
+  }
+  for (auto& x : ev) g_pool.push_back(x);
+  *ms_per_pair = tot / n;
+  return 0;
+}
+
 // ---- host-side Levenshtein distance on token-id sequences (WER/CER: utils/asr_metrics.py:54,220
 // call editdistance.eval on word / character lists; the host maps words to ids first) -------------
 extern "C" int64_t lasr_edit_distance(const int32_t* a, int64_t na, const int32_t* b, int64_t nb) {
