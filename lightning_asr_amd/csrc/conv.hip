@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 // Weight gradient.  grid: (n_chunks, ceil(C/kCB), B); each workgroup walks `chunk` output frames in
 // steps of kWT and writes a partial [kCB][k] to partials[(b*n_chunks+chunk)][C][k].
 static constexpr int kWT = 64;       // frames per LDS step
-static constexpr int kWChunk = 256;  // frames per workgroup
+static constexpr int kWChunk = 256;  // frames per workgroup (stride-1 kernel)
+static constexpr int kWChunkG = 64;  // frames per workgroup of the generic kernel: the only stride-2 layer has 64 channels, so
+                                     // (chunks x B) must supply the parallelism: 8 x 32 workgroups at T' = 501
 static constexpr int kQ = kMaxK / 16;
 
 template <typename T>
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 #pragma unroll
   for (int q = 0; q < kQ; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
   const int nq = (k + 15) / 16;
-  const int64_t tbeg = (int64_t)blockIdx.x * kWChunk;
-  const int64_t tend = tbeg + kWChunk < Tout ? tbeg + kWChunk : Tout;
+  const int64_t tbeg = (int64_t)blockIdx.x * kWChunkG;
+  const int64_t tend = tbeg + kWChunkG < Tout ? tbeg + kWChunkG : Tout;
   for (int64_t t0 = tbeg; t0 < tend; t0 += kWT) {
     __syncthreads();
     const int64_t in0 = t0 * stride - pad;
@@ -553,7 +555,7 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
 }
 
 extern "C" size_t lasr_dwconv_wgrad_workspace_bytes(int64_t B, int64_t Tout, int64_t C, int k) {
-  return (size_t)B * cdiv(Tout, kWChunk) * C * k * sizeof(float);
+  return (size_t)B * cdiv(Tout, kWChunkG) * C * k * sizeof(float);   // the finer of the two chunkings
 }
 
 extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
@@ -564,7 +566,7 @@ extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int d
                    "lasr_dwconv_wgrad: k=%d stride=%d C=%lld", k, stride, (long long)C);
   const int64_t Tout = conv_out_len(Tin, k, stride);
   if (workspace_bytes < lasr_dwconv_wgrad_workspace_bytes(B, Tout, C, k)) return fail(LASR_E_WORKSPACE, "lasr_dwconv_wgrad: workspace");
-  const int n_chunks = (int)cdiv(Tout, kWChunk);
+  const int n_chunks = (int)cdiv(Tout, stride == 1 ? kWChunk : kWChunkG);
   const int in_rows = (kWT - 1) * stride + k;
   const size_t shmem = ((size_t)in_rows + kWT) * kCB * sizeof(float);
   dim3 grid((unsigned)n_chunks, (unsigned)cdiv(C, kCB), (unsigned)B);

@@ -62,6 +62,16 @@ __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(const float* __res
 // [1, 3]; the relative error per step (~1e-6) stays far inside the 1e-4 loss tolerance.
 // Branch-free: with every input -inf the shifted sum is exp(-inf)*3 = 0 and log(0) = -inf, so no
 // per-lane early exit is needed (divergent exits cost an exec-mask branch per state per step).
+// Neighbour exchange of the lattice recursion on the DPP path (gfx9 wave-wide shifts, one VALU op) instead of
+// ds_bpermute (an LDS round trip on the critical path of every one of the T' dependent steps):
+// wave_shr1: lane i receives lane i-1, lane 0 keeps `fill`; wave_shl1: lane i receives lane i+1, lane 63 `fill`.
+__device__ __forceinline__ float wave_shr1(float v, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v, float fill) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   const float m = fmaxf(fmaxf(a, b), c);
   const float mm = (m == kNegInf) ? 0.f : m;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
   for (int u = 0; u < kPre; ++u)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
-      ring[u][i] = (1 + u < Tb && lane * NS + i < SS) ? lp[(int64_t)(t_first + dt * (1 + u)) * C + cls[i]] : kNegInf;
+      ring[u][i] = (1 + u < Tb) ? lp[(int64_t)(t_first + dt * (1 + u)) * C + cls[i]] : kNegInf;   // states past SS read the blank column: in bounds, masked below
   for (int step0 = 1; step0 < Tb; step0 += kPre) {
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
@@ -153,13 +163,12 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
         if (step + kPre < Tb) {
 #pragma unroll
           for (int i = 0; i < NS; ++i)
-            ring[u][i] = (lane * NS + i < SS) ? lp[(int64_t)(t + dt * kPre) * C + cls[i]] : kNegInf;
+            ring[u][i] = lp[(int64_t)(t + dt * kPre) * C + cls[i]];   // unconditional: no exec-mask branch around the load
         }
         float n[NS];
         if (!is_beta) {
-          float p1 = __shfl_up(a[NS - 1], 1, 64);
-          float p2 = NS >= 2 ? __shfl_up(a[NS - 2], 1, 64) : 0.f;
-          if (lane == 0) { p1 = kNegInf; p2 = kNegInf; }
+          const float p1 = wave_shr1(a[NS - 1], kNegInf);
+          const float p2 = NS >= 2 ? wave_shr1(a[NS - 2], kNegInf) : kNegInf;
 #pragma unroll
           for (int i = 0; i < NS; ++i) {
             // i==0: s-1 is the previous lane's last state, s-2 its second to last; i==1: s-2 is the previous lane's last
@@ -168,9 +177,8 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
             n[i] = lse3(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
           }
         } else {
-          float q1 = __shfl_down(a[0], 1, 64);
-          float q2 = NS >= 2 ? __shfl_down(a[1], 1, 64) : 0.f;
-          if (lane == 63) { q1 = kNegInf; q2 = kNegInf; }
+          const float q1 = wave_shl1(a[0], kNegInf);
+          const float q2 = NS >= 2 ? wave_shl1(a[1], kNegInf) : kNegInf;
 #pragma unroll
           for (int i = 0; i < NS; ++i) {
             const float s1 = i + 1 < NS ? a[i + 1] : q1;

@@ -568,24 +568,31 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
 // ------------------------------------------------------------------ small reductions ----------
 namespace lasr {
 static constexpr int kColsumRows = 256;
-// partials[blk][c] = sum over a 256-row slab; block = 256 threads walking columns
+// partials[blk][c] = sum over a 256-row slab.  Narrow matrices (the 28-class logit gradient) would leave most
+// of a column-per-thread block idle, so the 256 threads are dealt as col_threads x row_lanes: a lane sums
+// every row_lanes-th row of the slab, the lanes are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int64_t C,
                                                              float* __restrict__ partials) {
+  __shared__ float s_p[256];
+  const int col_threads = C < 256 ? (int)C : 256;
+  const int row_lanes = 256 / col_threads;
+  const int cl = threadIdx.x % col_threads, rl = threadIdx.x / col_threads;
   const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
   const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
-  for (int64_t c = threadIdx.x; c < C; c += 256) {
+  for (int64_t c0 = 0; c0 < C; c0 += col_threads) {
+    const int64_t c = c0 + cl;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
-    partials[(int64_t)blockIdx.x * C + c] = s;
+    if (rl < row_lanes && c < C)
+      for (int64_t r = r0 + rl; r < r1; r += row_lanes) s += x[r * C + c];
+    s_p[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      float t = 0.f;
+      for (int l = 0; l < row_lanes; ++l) t += s_p[l * col_threads + cl];
+      partials[(int64_t)blockIdx.x * C + c] = t;
+    }
+    __syncthreads();
   }
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partials, int nblk, int64_t C,
-                                                           float* __restrict__ out) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partials[(int64_t)b * C + c];
-  out[c] = (float)s;
 }
 // out[0] = scale * sum(x[0..n)), one wave, fixed order (n is the batch size)
 __global__ __launch_bounds__(64) void scale_sum_kernel(const float* __restrict__ x, int64_t n, float scale, float* __restrict__ out) {
@@ -606,9 +613,7 @@ extern "C" int lasr_colsum_f32(const float* x, float* out, int64_t rows, int64_t
   float* partials = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, rows, C, partials);
   LASR_LAUNCH_CHECK("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream), partials, nblk, C, out);
-  LASR_LAUNCH_CHECK("colsum_final_kernel");
-  return 0;
+  return launch_reduce_partials(partials, nblk, C, out, C, nullptr, as_stream(stream));   // f64, fixed order
 }
 extern "C" int lasr_scale_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream) {
   LASR_CHECK_ARG(x && out && n > 0, "lasr_scale_sum_f32: bad argument");
