@@ -81,7 +81,26 @@ __device__ __forceinline__ float lse2(float a, float b) { return lse3(a, b, kNeg
 
 // Workspace layout per utterance: alpha [T][SP], beta [T][SP] (SP = 64*NS), then next_same [S_max] int32.
 // grid: B blocks of 128 threads.
-template <int NS>
+// lse3 for the alpha/beta recursions on the raw transcendental units: v_exp_f32 / v_log_f32 ARE 2^x / log2(x), so
+// the differences are scaled by log2(e) and the logarithm by ln(2) (the sum is in [1,3], or exactly 0 when all
+// three are -inf: no denormal fix-ups, no range checks) - 15 instructions against ~30 for __expf/__logf with
+// their scalings and guards, with the same values in natural-log units (the rounding that matters, of
+// m + log(sum) at |alpha| ~ 1e3, is unchanged; a pure base-2 lattice was 1.4x faster still but its
+// unit conversions at that magnitude cost 30 % more gradient error against an f64 reference).
+static constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float lse3_fast(float a, float b, float c) {
+  const float m = fmaxf(fmaxf(a, b), c);
+  const float mm = (m == kNegInf) ? 0.f : m;
+  const float s = __builtin_amdgcn_exp2f((a - mm) * kLog2e) + __builtin_amdgcn_exp2f((b - mm) * kLog2e) +
+                  __builtin_amdgcn_exp2f((c - mm) * kLog2e);
+  return fmaf(kLn2, __builtin_amdgcn_logf(s), mm);
+}
+
+// EM_LDS: the utterance's whole emission matrix logp[b] (T x C f32; 56 KB at T'=501, C=28) is copied into LDS once
+// with coalesced 16-byte loads and both waves gather their per-state emissions from there one step ahead, so the
+// T' dependent steps contain no global load and never wait on vmcnt (which also counts the lattice stores).
+// Large vocabularies (C=4334) keep the register ring of global prefetches.
+template <int NS, bool EM_LDS>
 __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __restrict__ logp, const int64_t* __restrict__ targets,
                                                              const int32_t* __restrict__ in_lens,
                                                              const int32_t* __restrict__ tgt_lens, int64_t T, int64_t C,
@@ -115,6 +134,17 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
     if (threadIdx.x == 0) nll[b] = (S == 0) ? 0.f : INFINITY;
     return;
   }
+  extern __shared__ __attribute__((aligned(16))) float s_lp[];
+  if (EM_LDS) {
+    const int64_t n = (int64_t)Tb * C;            // the host checked (T*C) % 4 == 0 and 16-byte alignment of logp
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 128) {
+      const float4 v = reinterpret_cast<const float4*>(lp)[i];
+      reinterpret_cast<float4*>(s_lp)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 128) s_lp[i] = lp[i];
+    __syncthreads();
+  }
   // per-lane state description
   int cls[NS];
   bool skip_ok[NS];
@@ -142,6 +172,50 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
     a[i] = (start && s >= 0 && s < SS) ? em[i] : kNegInf;
     out[(int64_t)t_first * SP + s] = a[i];
   }
+  // one recursion step: a[] (t - dt) -> a[] (t) with emissions em[], lattice row stored
+  auto advance = [&](int t) {
+    float n[NS];
+    if (!is_beta) {
+      const float p1 = wave_shr1(a[NS - 1], kNegInf);
+      const float p2 = NS >= 2 ? wave_shr1(a[NS - 2], kNegInf) : kNegInf;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        // i==0: s-1 is the previous lane's last state, s-2 its second to last; i==1: s-2 is the previous lane's last
+        const float s1 = i >= 1 ? a[i - 1] : p1;
+        const float s2v = (i == 0) ? p2 : (i == 1 ? p1 : a[i - 2]);
+        n[i] = lse3_fast(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
+      }
+    } else {
+      const float q1 = wave_shl1(a[0], kNegInf);
+      const float q2 = NS >= 2 ? wave_shl1(a[1], kNegInf) : kNegInf;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const float s1 = i + 1 < NS ? a[i + 1] : q1;
+        const float s2v = (i + 2 < NS) ? a[i + 2] : (i + 2 == NS ? q1 : q2);
+        n[i] = lse3_fast(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int s = lane * NS + i;
+      a[i] = (s < SS) ? n[i] : kNegInf;
+      out[(int64_t)t * SP + s] = a[i];
+    }
+  };
+  if (EM_LDS) {
+    float nx[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) nx[i] = Tb > 1 ? s_lp[(t_first + dt) * (int)C + cls[i]] : 0.f;
+    for (int step = 1; step < Tb; ++step) {
+      const int t = t_first + dt * step;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) em[i] = nx[i];
+      const int tn = step + 1 < Tb ? t + dt : t;      // next step's emissions: issued before this step's arithmetic
+#pragma unroll
+      for (int i = 0; i < NS; ++i) nx[i] = s_lp[tn * (int)C + cls[i]];
+      advance(t);
+    }
+  } else {
   // Emissions are fetched kPre steps ahead into a register ring.  On CDNA4 s_waitcnt vmcnt counts
   // stores as well as loads, in issue order: with a one-step prefetch every step would also wait for
   // the previous step's lattice stores to retire (~0.7 us).  Eight steps of slack hide both.
@@ -151,7 +225,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
   for (int u = 0; u < kPre; ++u)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
-      ring[u][i] = (1 + u < Tb) ? lp[(int64_t)(t_first + dt * (1 + u)) * C + cls[i]] : kNegInf;   // states past SS read the blank column: in bounds, masked below
+      ring[u][i] = (1 + u < Tb && lane * NS + i < SS) ? lp[(int64_t)(t_first + dt * (1 + u)) * C + cls[i]] : kNegInf;
   for (int step0 = 1; step0 < Tb; step0 += kPre) {
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
@@ -163,37 +237,12 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
         if (step + kPre < Tb) {
 #pragma unroll
           for (int i = 0; i < NS; ++i)
-            ring[u][i] = lp[(int64_t)(t + dt * kPre) * C + cls[i]];   // unconditional: no exec-mask branch around the load
+            ring[u][i] = (lane * NS + i < SS) ? lp[(int64_t)(t + dt * kPre) * C + cls[i]] : kNegInf;
         }
-        float n[NS];
-        if (!is_beta) {
-          const float p1 = wave_shr1(a[NS - 1], kNegInf);
-          const float p2 = NS >= 2 ? wave_shr1(a[NS - 2], kNegInf) : kNegInf;
-#pragma unroll
-          for (int i = 0; i < NS; ++i) {
-            // i==0: s-1 is the previous lane's last state, s-2 its second to last; i==1: s-2 is the previous lane's last
-            const float s1 = i >= 1 ? a[i - 1] : p1;
-            const float s2v = (i == 0) ? p2 : (i == 1 ? p1 : a[i - 2]);
-            n[i] = lse3(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
-          }
-        } else {
-          const float q1 = wave_shl1(a[0], kNegInf);
-          const float q2 = NS >= 2 ? wave_shl1(a[1], kNegInf) : kNegInf;
-#pragma unroll
-          for (int i = 0; i < NS; ++i) {
-            const float s1 = i + 1 < NS ? a[i + 1] : q1;
-            const float s2v = (i + 2 < NS) ? a[i + 2] : (i + 2 == NS ? q1 : q2);
-            n[i] = lse3(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-          const int s = lane * NS + i;
-          a[i] = (s < SS) ? n[i] : kNegInf;
-          out[(int64_t)t * SP + s] = a[i];
-        }
+        advance(t);
       }
     }
+  }
   }
   if (!is_beta) {
     // ll = lse(alpha_{T-1}(SS-1), alpha_{T-1}(SS-2))
@@ -349,9 +398,22 @@ extern "C" int lasr_ctc_loss(const float* logp, const int64_t* targets, const in
   int32_t* next_same = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(workspace) + align_up(2 * ab * sizeof(float), 256));
   hipStream_t st = as_stream(stream);
   const int64_t sm = S_max > 0 ? S_max : 1;
-#define LASR_CTC_AB(NS_)                                                                                                  \
-  hipLaunchKernelGGL(ctc_alpha_beta_kernel<NS_>, dim3((unsigned)B), dim3(128), 0, st, logp, targets, in_lens, tgt_lens, T, C, \
-                     sm, blank, alpha, beta, next_same, nll)
+  // emissions in LDS when one utterance's T x C f32 block fits beside the kernel's other needs (cfg2: 56 KB)
+  const size_t em_bytes = (size_t)T * C * sizeof(float);
+  const bool em_lds = em_bytes <= 144 * 1024 && (T * C) % 4 == 0 && reinterpret_cast<uintptr_t>(logp) % 16 == 0 &&
+                      !getenv("LASR_CTC_NO_LDS");
+#define LASR_CTC_AB(NS_)                                                                                                   \
+  do {                                                                                                                     \
+    if (em_lds) {                                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_alpha_beta_kernel<NS_, true>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+      hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS_, true>), dim3((unsigned)B), dim3(128), em_bytes, st, logp, targets, in_lens, \
+                         tgt_lens, T, C, sm, blank, alpha, beta, next_same, nll);                                          \
+    } else {                                                                                                               \
+      hipLaunchKernelGGL((ctc_alpha_beta_kernel<NS_, false>), dim3((unsigned)B), dim3(128), 0, st, logp, targets, in_lens, \
+                         tgt_lens, T, C, sm, blank, alpha, beta, next_same, nll);                                          \
+    }                                                                                                                      \
+  } while (0)
   if (ns == 4) LASR_CTC_AB(4); else if (ns == 8) LASR_CTC_AB(8); else LASR_CTC_AB(16);
 #undef LASR_CTC_AB
   LASR_LAUNCH_CHECK("ctc_alpha_beta_kernel");
