@@ -428,15 +428,15 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(const T* __restric
   const int kpad = ng * 8;
   const int WT = kSub * ts;             // frames per LDS step
   const int in_rows = WT + kpad + 8;
-  T* s_x = reinterpret_cast<T*>(smem_raw);                         // [in_rows][kCB]
-  T* s_d = s_x + (size_t)in_rows * kCB;                             // [WT][kCB]
+  using P = S1<T>;
+  constexpr int LD = P::kTileLd;                                    // padded row pitch (144 B in bf16): conflict-free 8-byte reads
+  T* s_x = reinterpret_cast<T*>(smem_raw);                         // [in_rows][LD]
+  T* s_d = s_x + (size_t)in_rows * LD;                              // [WT][LD]
   const int b = blockIdx.z;
   const int64_t c0 = (int64_t)blockIdx.y * kCB;
   const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int jg = grp % ng, sp = grp / ng;
   const bool active = sp < ts;
-  const int64_t c = c0 + cl * 4;
-  const bool c_ok = c < C;
   const T* xb = x + (int64_t)b * Tlen * C;
   const T* db = dy + (int64_t)b * Tlen * C;
   float4 acc[8];
@@ -447,26 +447,49 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(const T* __restric
   for (int64_t t0 = tbeg; t0 < tend; t0 += WT) {
     __syncthreads();
     const int64_t in0 = t0 - pad;
-    for (int r = grp; r < in_rows; r += 16) {
-      const int64_t ti = in0 + r;
-      lds_copy4<T>(s_x + (size_t)r * kCB + cl * 4, xb + ti * C + c, c_ok && ti >= 0 && ti < Tlen);
-    }
-    for (int r = grp; r < WT; r += 16) {
-      const int64_t t = t0 + r;
-      lds_copy4<T>(s_d + (size_t)r * kCB + cl * 4, db + t * C + c, c_ok && t < tend);
+    {
+      // all 16-byte loads of the step first (x rows, then dy rows), then the LDS writes
+      constexpr int kXP = (3 * kSub + kMaxK + 8 + P::kRowsPerPass - 1) / P::kRowsPerPass, kDP = (3 * kSub + P::kRowsPerPass - 1) / P::kRowsPerPass;
+      const int lr = threadIdx.x / P::kLanesPerRow, lc = (threadIdx.x % P::kLanesPerRow) * P::kVec;
+      const bool c_in = c0 + lc < C;
+      uint4 vx[kXP], vd[kDP];
+#pragma unroll
+      for (int p = 0; p < kXP; ++p) {
+        const int r = lr + p * P::kRowsPerPass;
+        const int64_t ti = in0 + r;
+        vx[p] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < in_rows && c_in && ti >= 0 && ti < Tlen) vx[p] = *reinterpret_cast<const uint4*>(xb + ti * C + c0 + lc);
+      }
+#pragma unroll
+      for (int p = 0; p < kDP; ++p) {
+        const int r = lr + p * P::kRowsPerPass;
+        const int64_t t = t0 + r;
+        vd[p] = make_uint4(0u, 0u, 0u, 0u);
+        if (r < WT && c_in && t < tend) vd[p] = *reinterpret_cast<const uint4*>(db + t * C + c0 + lc);
+      }
+#pragma unroll
+      for (int p = 0; p < kXP; ++p) {
+        const int r = lr + p * P::kRowsPerPass;
+        if (r < in_rows) *reinterpret_cast<uint4*>(s_x + (size_t)r * LD + lc) = vx[p];
+      }
+#pragma unroll
+      for (int p = 0; p < kDP; ++p) {
+        const int r = lr + p * P::kRowsPerPass;
+        if (r < WT) *reinterpret_cast<uint4*>(s_d + (size_t)r * LD + lc) = vd[p];
+      }
     }
     __syncthreads();
     if (active) {
-      const T* xs = s_x + (size_t)(sp * kSub + jg * 8) * kCB + cl * 4;   // frame t, tap j0 -> row t + j0
-      const T* ds = s_d + (size_t)(sp * kSub) * kCB + cl * 4;
+      const T* xs = s_x + (size_t)(sp * kSub + jg * 8) * LD + cl * 4;   // frame t, tap j0 -> row t + j0
+      const T* ds = s_d + (size_t)(sp * kSub) * LD + cl * 4;
       float4 win[8];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) win[i] = lds_ld4<T>(xs + (size_t)i * kCB);
+      for (int i = 0; i < 7; ++i) win[i] = lds_ld4<T>(xs + (size_t)i * LD);
       for (int tq = 0; tq < kSub; tq += 8) {
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) {
-          win[(tt + 7) & 7] = lds_ld4<T>(xs + (size_t)(tq + tt + 7) * kCB);
-          const float4 dv = lds_ld4<T>(ds + (size_t)(tq + tt) * kCB);
+          win[(tt + 7) & 7] = lds_ld4<T>(xs + (size_t)(tq + tt + 7) * LD);
+          const float4 dv = lds_ld4<T>(ds + (size_t)(tq + tt) * LD);
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj) {
             const float4 xv = win[(tt + jj) & 7];
@@ -576,7 +599,7 @@ extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int d
     int ts = 16 / ng;
     if (ts > 3) ts = 3;
     const int WT = kSub * ts, kpad = ng * 8;
-    size_t sh1 = (size_t)(WT + kpad + 8 + WT) * kCB * dtype_size(dtype);
+    size_t sh1 = (size_t)(WT + kpad + 8 + WT) * (kCB + (dtype_size(dtype) == 2 ? 8 : 0)) * dtype_size(dtype);   // padded rows
     const size_t red = (size_t)ts * kpad * kCB * sizeof(float);
     if (red > sh1) sh1 = red;
     if (dtype == LASR_F32) {

@@ -370,17 +370,26 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
                                          const Bf16Args& g, int m0, int n0, int k_store, int k_load, int kend, int wm, int wn,
                                          int lane) {
   using namespace big;
+  // fragments of group ks+1 are requested before the MFMAs of group ks are issued (two register sets), so a
+  // wave's MFMA stream does not stop for its own LDS latency; only the first group after the barrier waits
+  bf16x8 a[2][4], b[2][2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) b[0][ni] = load_frag<TRANS_B, LDR>(sB, wn * 64 + ni * 32, 0, lane);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) a[0][mi] = load_frag<TRANS_A, LDR>(sA, wm * 128 + mi * 32, 0, lane);
 #pragma unroll
   for (int ks = 0; ks < TK / 16; ++ks) {
-    bf16x8 a[4], b[2];
+    const int cur = ks & 1, nxt = cur ^ 1;
+    if (ks + 1 < TK / 16) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) b[ni] = load_frag<TRANS_B, LDR>(sB, wn * 64 + ni * 32, ks, lane);
+      for (int ni = 0; ni < 2; ++ni) b[nxt][ni] = load_frag<TRANS_B, LDR>(sB, wn * 64 + ni * 32, ks + 1, lane);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a[mi] = load_frag<TRANS_A, LDR>(sA, wm * 128 + mi * 32, ks, lane);
+      for (int mi = 0; mi < 4; ++mi) a[nxt][mi] = load_frag<TRANS_A, LDR>(sA, wm * 128 + mi * 32, ks + 1, lane);
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
     if constexpr (STORE) {
       store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
       store_chunk<TRANS_B, BTN, NT, LD_KC, LDR>(dB, rb[ks], k_store, kend, ks);
