@@ -49,6 +49,8 @@ struct TensorInfo {
 
 struct BnRef { int64_t gamma = -1, beta = -1, rmean = -1, rvar = -1; };
 
+// split-K of the 1x1 weight gradients (K = B*T' rows): 16 slices x 16 tiles x 2 problems = 512 workgroups
+static int wgrad_split() { static const int v = getenv("LASR_WGRAD_SPLIT") ? atoi(getenv("LASR_WGRAD_SPLIT")) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }
 static bool no_fuse() { static const bool v = getenv("LASR_NO_FUSE") != nullptr; return v; }
 
 // One "unit": [depthwise conv] -> 1x1 GEMM (+mask) -> BN  [+ residual 1x1 GEMM -> BN] -> activation
@@ -215,7 +217,7 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
     cmax = std::max<int64_t>(cmax, std::max(u.ci, u.co));
     scratch = std::max(scratch, 2 * lasr_gemm_workspace_bytes(N, u.co, 1, 1));
     scratch = std::max(scratch, lasr_bn_bwd_workspace_bytes(B, p.T, u.co));
-    scratch = std::max(scratch, 2 * lasr_gemm_workspace_bytes(u.co, u.ci, 16, 0));
+    scratch = std::max(scratch, 2 * lasr_gemm_workspace_bytes(u.co, u.ci, wgrad_split(), 0));
     if (u.has_dw) scratch = std::max(scratch, lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k));
   }
   const int64_t C = m->cfg.n_class;
@@ -460,7 +462,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       lasr_gemm_problem pr[2];
       pr[0] = {dy, gin, grads + u.w_pw, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
       if (u.has_res) pr[1] = {dy2, x_in, grads + u.w_res, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
-      LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, 16, scratch, sb, stream));
+      LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
     }
     const bool need_dx = ui > 0;
     void* dx = at(ws, p.o_g[cur ^ 1]);
