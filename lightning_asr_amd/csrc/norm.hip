@@ -83,17 +83,24 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
 // Accumulation is f64: these sums are BatchNorm statistics and gradient reductions, and the
 // network's backward map amplifies relative noise in them by ~1e2-1e3 (measured), so f32 sums
 // of a few hundred partials cost visible gradient parity.
-// one partial lane's share of column c: rows pl, pl+8, ... with 4 independent f64 sums (fixed order)
+// one partial lane's share of column c: rows pl, pl+8, ... in a fixed order.  The partials were written by the
+// previous kernel on other XCDs, so every load is a trip to the fabric: 16 rows are requested before the
+// first is added (a loop of 4 loads per trip exposed that latency ~16 times for 501 rows: 8.6 us per call).
 __device__ __forceinline__ double partial_lane_sum(const float* __restrict__ partials, int n_part, int64_t ncols, int64_t c, int pl) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int p = pl;
-  for (; p + 24 < n_part; p += 32) {
-    a0 += (double)partials[(int64_t)p * ncols + c];
-    a1 += (double)partials[(int64_t)(p + 8) * ncols + c];
-    a2 += (double)partials[(int64_t)(p + 16) * ncols + c];
-    a3 += (double)partials[(int64_t)(p + 24) * ncols + c];
+  for (int p = pl; p < n_part; p += 128) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = p + 8 * i;
+      const float x = partials[(int64_t)min(r, n_part - 1) * ncols + c];   // clamped address, masked value: no branch around the load
+      v[i] = r < n_part ? x : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      a0 += (double)v[i]; a1 += (double)v[i + 1]; a2 += (double)v[i + 2]; a3 += (double)v[i + 3];
+    }
   }
-  for (; p < n_part; p += 8) a0 += (double)partials[(int64_t)p * ncols + c];
   return (a0 + a1) + (a2 + a3);
 }
 
