@@ -412,6 +412,221 @@ __global__ __launch_bounds__(256) void dwconv_s1_bf16_kernel(const bf16_t* __res
   }
 }
 
+// ---- bf16 stride-1 depthwise conv on the matrix cores ------------------------------------------------
+// The VALU forms above are bound by issue rate (2*k FLOP per element: 15 us per 512-channel layer against
+// 7 us of HBM traffic).  Per channel the convolution is a banded Toeplitz product,
+//     y[16*blk + m] = sum_kap  A[m][kap] * img[16*blk + kap],    A[m][kap] = w'[kap - m - sh]
+// (img = the channel's time series shifted by P = round-up-8(pad), sh = P - pad, w' = taps, reversed for the
+// data gradient), i.e. D(16 x 16) += A(16 x 32) * B(32 x 16) on v_mfma_f32_16x16x32_bf16 with M = 16
+// consecutive output frames, N = 16 frame blocks (256 frames per MFMA set) and K = the 15 + k + sh wide input
+// window in steps of 32: 2-4 MFMAs per 256 outputs of a channel.  A is the same for every block of a
+// channel: it is built once per channel from two packed tap tables (even / odd start) in LDS.
+// What is left is data movement:
+//   * B wants 8 consecutive FRAMES of one channel per lane, HBM has channels contiguous.  The tile is staged
+//     as it is ([frame][channel], 16-byte writes), read back through ds_read_b64_tr_b16 (lane <- 4 frames of
+//     one channel) and written frame-contiguous ([channel][frame], 8-byte writes): one LDS round trip, all
+//     accesses conflict-free by the pitches chosen below; B fragments are then plain ds_read_b128.
+//   * D leaves the MFMA with lane = (block, 4 consecutive frames) for ONE channel; a wave runs 8 channels
+//     (one 16-byte octet) into 8 accumulator sets, so a lane ends up holding 8 channels x 4 frames and
+//     stores 16 bytes per frame straight to HBM: no output transpose.  Lines are completed by the 8 waves.
+// Workgroup = 64 channels x one utterance (512-frame time tiles), 512 threads, wave = channel octet.
+namespace dwm {
+static constexpr int TT = 512;            // output frames per time tile (2 MFMA sets of 256)
+static constexpr int KWMAX = 128;         // input window per 16-frame block, max (k <= 101)
+static constexpr int TIN = TT - 16 + KWMAX;   // 624 staged frames at most
+static constexpr int LDI = 1296;          // bytes per channel row of the frame-contiguous image: a multiple of 16 (the B fragments are
+                                          // 16-byte reads; at 1288 = 2 mod 32 dwords the 8-byte transposition writes were conflict-free but
+                                          // every odd channel row misaligned them: phase 2 took 5.8 us instead of 2), writes 2-way
+static constexpr int RS = 128;            // frames per staging round
+static constexpr int LDST = 160;          // bytes per frame row of the staging image (40 dwords: see the tr-read banking)
+static constexpr int IMG_BYTES = kCB * LDI;            // 82 944
+static constexpr int STAGE_BYTES = RS * LDST;          // 20 480
+static constexpr int WROW = 160;                       // dwords per channel: TE[0..79] | TO[0..79], packed bf16 tap pairs of the
+                                                       // zero-padded row W[i] = w'[i - 24]: TE[i] = (W[2i], W[2i+1]), TO[i] = (W[2i+1], W[2i+2])
+static constexpr int WSM_OFF = IMG_BYTES + STAGE_BYTES;
+static constexpr int SMEM = WSM_OFF + kCB * WROW * 4;  // 144 384
+}
+typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+typedef short dw_s16x4 __attribute__((ext_vector_type(4)));
+
+#ifdef LASR_DW_STAMPS
+__device__ unsigned long long* g_dw_stamps = nullptr;   // debug builds only (tools/dw_stamps.py)
+#define DW_STAMP(i_) do { if (g_dw_stamps && threadIdx.x == 0) g_dw_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i_)] = wall_clock64(); } while (0)
+#else
+#define DW_STAMP(i_) do {} while (0)
+#endif
+template <int NKS>
+__global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+                                                                int Tlen, int C, int k, int flip) {
+  using namespace dwm;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* img = smem_raw;                               // [64 channels][LDI]: frame tau at byte 2*tau
+  char* stage = smem_raw + IMG_BYTES;                 // [RS frames][LDST]
+  uint32_t* wsm = reinterpret_cast<uint32_t*>(smem_raw + WSM_OFF);   // [64][WROW]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.x * kCB;
+  // the block's taps -> LDS once, as packed bf16 pair tables (reversed for the data gradient); a Toeplitz
+  // fragment W[s .. s+7] is 4 consecutive dwords of TE (s even) or TO (s odd): no per-channel work in phase 2.
+  // Loads are unconditional (clamped index, masked value) and all issued before the first conversion.
+  {   // (kept in front of the tile's loads: issued behind them it cost 4 us more)
+    constexpr int kIt = kCB * WROW / 512;             // 20
+    float f0[kIt], f1[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int i = tid + 512 * it;
+      const int ch = i / WROW, idx = i - ch * WROW;
+      const int i0 = idx < 80 ? 2 * idx : 2 * (idx - 80) + 1;
+      const int j0 = i0 - 24, j1 = i0 - 23;
+      const float* wc = w + (size_t)min(c0 + ch, C - 1) * k;
+      const bool cok = c0 + ch < C;
+      const int q0 = min(max(j0, 0), k - 1), q1 = min(max(j1, 0), k - 1);
+      const float a0 = wc[flip ? k - 1 - q0 : q0], a1 = wc[flip ? k - 1 - q1 : q1];
+      f0[it] = (cok && j0 >= 0 && j0 < k) ? a0 : 0.f;
+      f1[it] = (cok && j1 >= 0 && j1 < k) ? a1 : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) wsm[tid + 512 * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
+  }
+  const int pad = k / 2, P = (pad + 7) & ~7, sh = P - pad;
+  constexpr int KW = 32 * NKS;                        // = round-up-32(15 + k + sh) (host dispatch)
+  const bf16_t* xb = x + (size_t)b * Tlen * C;
+  const int n16 = lane & 15, g4 = lane >> 4;          // MFMA lane coordinates
+
+  DW_STAMP(0);
+  for (int tA = 0; tA < Tlen; tA += TT) {
+    const int tin = TT - 16 + KW;                     // staged frames: t = tA - P + tau, tau in [0, tin)
+    // ---- phase 1: HBM -> staging ([frame][channel]) -> transposed image ([channel][frame]) ------------------
+    // all global loads of the tile first (two 16-byte chunks per thread and round), then round by round
+    constexpr int kRounds = (TIN + RS - 1) / RS;      // 5
+    uint4 v[kRounds][2];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ch = tid + 512 * h;                 // chunk of the round: frame ch>>3, channel octet ch&7
+        const int tau = r * RS + (ch >> 3);
+        const int t = tA - P + tau;
+        const int cc = c0 + ((ch & 7) << 3);
+        const bool ok = tau < tin && t >= 0 && t < Tlen && cc < C;
+        const uint4 ld = *reinterpret_cast<const uint4*>(xb + (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8));
+        const uint32_t mk = ok ? 0xffffffffu : 0u;
+        v[r][h] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      if (r * RS < tin) {                             // workgroup-uniform
+        __syncthreads();                              // the previous round's (or tile's) readers are done
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ch = tid + 512 * h;
+          *reinterpret_cast<uint4*>(stage + (ch >> 3) * LDST + ((ch & 7) << 4)) = v[r][h];
+        }
+        __syncthreads();
+        // 16 frames x 16 channels per wave instruction: lanes 0-15 / 16-31 / 32-47 / 48-63 take the frame
+        // quads 0, 4, 8, 12 of the block (a half-wave's two quads sit 4 rows = 160 dwords = 32 banks apart)
+        typedef __attribute__((address_space(3))) dw_s16x4 lds_s4;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int blk = wid * 4 + it;               // 32 blocks per round: 8 frame groups x 4 channel groups
+          const int fb = (blk >> 2) * 16 + g4 * 4, cg = blk & 3;
+          const int q = n16 >> 2, pp = n16 & 3;
+          const dw_s16x4 d = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(stage + (fb + q) * LDST + (cg * 16 + pp * 4) * 2));
+          const int tau = r * RS + fb;
+          *reinterpret_cast<dw_s16x4*>(img + (cg * 16 + n16) * LDI + tau * 2) = d;
+        }
+      }
+    }
+    __syncthreads();
+    DW_STAMP(1);
+
+    // ---- phase 2: one channel octet per wave, 8 channels x 2 MFMA sets x 4 frames per lane --------------------
+    dw_f32x4 acc[8][2];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const int cl = wid * 8 + ch;
+      acc[ch][0] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[ch][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* row = img + cl * LDI;
+      // A[m][kap] = W[kap - m - sh + 24]: lane (m = n16, K group g4) needs W[s0 + 32*ks .. +7], s0 = 8*g4 - m - sh + 24:
+      // 4 dwords of the channel's even- or odd-start table.  Every LDS read of the channel is issued up front.
+      const int s0 = 8 * g4 - n16 - sh + 24;
+      const uint32_t* wrow = wsm + cl * WROW + ((s0 & 1) ? 80 + ((s0 - 1) >> 1) : (s0 >> 1));
+      uint32_t wa[NKS][4];
+      uint4 b0[NKS], b1[NKS];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[ks][i] = wrow[16 * ks + i];
+        b0[ks] = *reinterpret_cast<const uint4*>(row + (16 * n16 + 32 * ks + 8 * g4) * 2);
+        b1[ks] = *reinterpret_cast<const uint4*>(row + (256 + 16 * n16 + 32 * ks + 8 * g4) * 2);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        union { uint32_t u[4]; dw_bf16x8 v; } af, bf0, bf1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af.u[i] = wa[ks][i];
+        bf0.u[0] = b0[ks].x; bf0.u[1] = b0[ks].y; bf0.u[2] = b0[ks].z; bf0.u[3] = b0[ks].w;
+        bf1.u[0] = b1[ks].x; bf1.u[1] = b1[ks].y; bf1.u[2] = b1[ks].z; bf1.u[3] = b1[ks].w;
+        acc[ch][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf0.v, acc[ch][0], 0, 0, 0);
+        acc[ch][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf1.v, acc[ch][1], 0, 0, 0);
+      }
+    }
+    DW_STAMP(2);
+    // ---- phase 3: lane = (block n16, frames 4*g4 .. +3) holds 8 channels (its wave's octet) per frame.  Each
+    //      frame's 16 bytes go to an LDS image [frame][64 channels] (rows permuted so that the 16 blocks of a
+    //      wave instruction fall on 16 consecutive rows: conflict-free 16-byte writes), then the tile leaves as
+    //      whole 128-byte channel rows (8 lanes x 16 bytes), with the addend read the same way.
+    // One 256-frame MFMA set at a time (the f32 form of a half tile, kept for the addend sum, fills the image space).
+    constexpr int LDO = 144, LDOF = 272;              // row pitch: bf16 (36 dwords) / f32 (68 dwords), both = 4 mod 32
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+      __syncthreads();                                // every wave is done with what the space held before
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int fl = n16 * 16 + g4 * 4 + r;         // frame within the set; physical row (fl & 15) * 16 + (fl >> 4)
+        const int prow = (fl & 15) * 16 + (fl >> 4);
+        float o[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) o[ch] = acc[ch][ns][r];
+        if (!addend) {
+          Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(img + prow * LDO) + wid * 8, o);
+        } else {                                      // the sum with the addend is rounded once, at the end
+          *reinterpret_cast<float4*>(img + prow * LDOF + wid * 32) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(img + prow * LDOF + wid * 32 + 16) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int ci = tid + 512 * it;                // chunk: frame ci >> 3 of the set, octet ci & 7
+        const int fl = ci >> 3, oc = ci & 7;
+        const int prow = (fl & 15) * 16 + (fl >> 4);
+        const int t = tA + ns * 256 + fl, cc = c0 + oc * 8;
+        if (t < Tlen && cc < C) {
+          const size_t off = ((size_t)b * Tlen + t) * C + cc;
+          if (!addend) {
+            *reinterpret_cast<uint4*>(y + off) = *reinterpret_cast<const uint4*>(img + prow * LDO + oc * 16);
+          } else {
+            const float4 lo = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32);
+            const float4 hi = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32 + 16);
+            float a8[8];
+            Vec<bf16_t>::load(addend + off, a8);
+            float o[8] = {lo.x + a8[0], lo.y + a8[1], lo.z + a8[2], lo.w + a8[3], hi.x + a8[4], hi.y + a8[5], hi.z + a8[6], hi.w + a8[7]};
+            Vec<bf16_t>::store(y + off, o);
+          }
+        }
+      }
+    }
+  }
+#ifdef LASR_DW_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  DW_STAMP(3);
+}
+
 // Weight gradient, stride 1.  Lane = 4 channels x 8 consecutive taps (group jg) x one time split;
 // the 8 frames x[t+j0 .. t+j0+7] slide through a register window as t advances, so a frame costs
 // two LDS vector reads (new x row, dy row) for 32 FMAs.  16 lane groups per workgroup are dealt as
@@ -552,8 +767,21 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
       hipLaunchKernelGGL(dwconv_s1_kernel<float>, grid, dim3(256), sh1, as_stream(stream), (const float*)x, w, (const float*)addend,
                          (float*)y, Tin, C, k, flip);
     } else {
-      static const bool fma_form = getenv("LASR_DWCONV_FMA") != nullptr;   // A/B switch: the f32-FMA form of the same kernel
-      if (fma_form) {
+      static const bool fma_form = getenv("LASR_DWCONV_FMA") != nullptr;   // A/B switches: the f32-FMA and the dot2 VALU forms
+      static const bool dot2_form = getenv("LASR_DWCONV_DOT2") != nullptr;
+      const int padk = k / 2, shk = ((padk + 7) & ~7) - padk;
+      if (!fma_form && !dot2_form && C % 8 == 0 && 15 + k + shk <= dwm::KWMAX && Tin < (1 << 30)) {
+        const int nks = (15 + k + shk + 31) / 32;
+        const dim3 gridm((unsigned)cdiv(C, kCB), (unsigned)B);
+#define LASR_DWM(N_)                                                                                                         \
+  do {                                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_mfma_kernel<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(dwconv_s1_mfma_kernel<N_>, gridm, dim3(512), dwm::SMEM, as_stream(stream), (const bf16_t*)x, w,        \
+                       (const bf16_t*)addend, (bf16_t*)y, (int)Tin, (int)C, k, flip);                                        \
+  } while (0)
+        if (nks == 1) LASR_DWM(1); else if (nks == 2) LASR_DWM(2); else if (nks == 3) LASR_DWM(3); else LASR_DWM(4);
+#undef LASR_DWM
+      } else if (fma_form) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(dwconv_s1_kernel<bf16_t>, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, w,
                            (const bf16_t*)addend, (bf16_t*)y, Tin, C, k, flip);
@@ -624,3 +852,10 @@ extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int d
   const int64_t n = C * k;
   return launch_reduce_partials(partials, (int)(B * n_chunks), n, dw, n, nullptr, as_stream(stream));
 }
+
+#ifdef LASR_DW_STAMPS
+extern "C" int lasr_debug_set_dw_stamps(void* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lasr::g_dw_stamps), &p, sizeof(p));
+}
+#endif
