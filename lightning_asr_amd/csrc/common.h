@@ -96,18 +96,24 @@ template <>
 struct Vec<float> {
   static constexpr int kN = 4;
   __device__ static __forceinline__ void load(const float* p, float (&o)[4]) { Elem<float>::ld4(p, o); }
+  // raw 16 bytes now, element values later (keeps batched loads at 4 registers each)
+  __device__ static __forceinline__ uint4 raw(const float* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[4]) {
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+  }
   __device__ static __forceinline__ void store(float* p, const float (&o)[4]) { Elem<float>::st4(p, o); }
 };
 template <>
 struct Vec<bf16_t> {
   static constexpr int kN = 8;
-  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
+  __device__ static __forceinline__ uint4 raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[8]) {
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
     o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
     o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
   }
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) { unpack(raw(p), o); }
   __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
     uint4 v;
     v.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);

@@ -233,26 +233,30 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   }
 }
 
-// pass 1: per-block partial sums -> partials[blk][4][C]  (s1, s2 of branch 1; s1', s2' of branch 2)
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ y,
-                                                           const float* __restrict__ coef, const float* __restrict__ saved,
-                                                           const T* __restrict__ y2, const float* __restrict__ coef2,
-                                                           const float* __restrict__ saved2, const float* __restrict__ se,
-                                                           const float* __restrict__ seg, float* __restrict__ partials,
-                                                           int rows, int Tt, int C, int act) {
+// pass 1: per-block partial sums -> partials[blk][4][C]  (s1, s2 of branch 1; s1', s2' of branch 2).
+// HAS2 is a template parameter and every load is unconditional (clamped row, contribution masked), so there is
+// no branch around a load; a thread's rows are taken two at a time with all six 16-byte loads issued before the
+// first is unpacked (four at a time, or the constants streamed from LDS, cost the second wave per SIMD:
+// measured 34 us against 11).  The kernel was a chain of eight exposed memory round trips per slab.
+template <typename T, bool HAS2>
+__global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                              const float* __restrict__ coef, const float* __restrict__ saved,
+                                                              const T* __restrict__ y2, const float* __restrict__ coef2,
+                                                              const float* __restrict__ saved2, const float* __restrict__ se,
+                                                              const float* __restrict__ seg, float* __restrict__ partials,
+                                                              int rows, int Tt, int C, int act) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [row_lanes][4][C]
   constexpr int V = Vec<T>::kN;
+  constexpr int RB = 2;                                           // rows in flight per thread
   const ColGeom g = col_geom<V>(C);
   const int r0 = blockIdx.x * kRowsPerBlock;
   const int r1 = min(r0 + kRowsPerBlock, rows);
-  const bool has2 = y2 != nullptr;
   if (g.rl < g.row_lanes) {
     for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
       const int c = cvi * V;
       float a1[V], b1[V], m1[V], q1[V], a2[V], b2[V], m2[V], q2[V];
       lds_vec8(coef + c, a1); lds_vec8(coef + C + c, b1); lds_vec8(saved + c, m1); lds_vec8(saved + C + c, q1);
-      if (has2) {
+      if (HAS2) {
         lds_vec8(coef2 + c, a2); lds_vec8(coef2 + C + c, b2); lds_vec8(saved2 + c, m2); lds_vec8(saved2 + C + c, q2);
       } else {
 #pragma unroll
@@ -263,28 +267,38 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
-      int ub = (r0 + g.rl) / Tt, ut = (r0 + g.rl) - ub * Tt;
-      for (int r = r0 + g.rl; r < r1; r += g.row_lanes) {
-        const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
-        float dv[V], yv[V], rv[V];
-        Vec<T>::load(dout + off, dv);
-        Vec<T>::load(y + off, yv);
-        if (has2) Vec<T>::load(y2 + off, rv);
-        const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-        const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-        ut += g.row_lanes;
-        while (ut >= Tt) { ut -= Tt; ++ub; }
+      for (int rb = r0 + g.rl; rb < r1; rb += RB * g.row_lanes) {
+        uint4 rd[RB], ry[RB], rr[RB];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float sej = sp ? sp[j] : 1.f;
-          const float z = fmaf(yv[j], a1[j], b1[j]) * sej + (has2 ? fmaf(rv[j], a2[j], b2[j]) : 0.f);
-          const float d = dv[j] * act_grad(z, act);
-          const float d1 = fmaf(d, sej, gp ? gp[j] : 0.f);
-          acc[0][j] += d1;
-          acc[1][j] = fmaf(d1, (yv[j] - m1[j]) * q1[j], acc[1][j]);
-          if (has2) {
-            acc[2][j] += d;
-            acc[3][j] = fmaf(d, (rv[j] - m2[j]) * q2[j], acc[3][j]);
+        for (int i = 0; i < RB; ++i) {
+          const uint32_t off = (uint32_t)min(rb + i * g.row_lanes, rows - 1) * (uint32_t)C + (uint32_t)c;
+          rd[i] = Vec<T>::raw(dout + off);
+          ry[i] = Vec<T>::raw(y + off);
+          if (HAS2) rr[i] = Vec<T>::raw(y2 + off);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          float dvi[V], yvi[V], rvi[V];
+          Vec<T>::unpack(rd[i], dvi);
+          Vec<T>::unpack(ry[i], yvi);
+          if (HAS2) Vec<T>::unpack(rr[i], rvi);
+          const int r = rb + i * g.row_lanes;
+          const float live = r < r1 ? 1.f : 0.f;                  // rows past the slab contribute nothing
+          const int ub = min(r, rows - 1) / Tt;
+          const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+          const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float sej = sp ? sp[j] : 1.f;
+            const float z = fmaf(yvi[j], a1[j], b1[j]) * sej + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
+            const float d = dvi[j] * act_grad(z, act) * live;
+            const float d1 = fmaf(d, sej, gp ? gp[j] * live : 0.f);
+            acc[0][j] += d1;
+            acc[1][j] = fmaf(d1, (yvi[j] - m1[j]) * q1[j], acc[1][j]);
+            if (HAS2) {
+              acc[2][j] += d;
+              acc[3][j] = fmaf(d, (rvi[j] - m2[j]) * q2[j], acc[3][j]);
+            }
           }
         }
       }
@@ -525,9 +539,15 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
   const size_t shmem = (size_t)row_lanes * 4 * C * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_stats: C too large for LDS staging");
   float* partials = reinterpret_cast<float*>(workspace);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nblk), dim3(256), shmem, as_stream(stream), (const T*)dout,
-                                           (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad, partials,
-                                           (int)rows, (int)T_, (int)C, act));
+  if (y2) {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act));
+  } else {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act));
+  }
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
   if (!sums) return 0;   // partials stay in the workspace for lasr_bn_act_bwd_apply(sums = NULL)
   return launch_reduce_partials(partials, nblk, 4 * C, sums, 2 * C, sums2, as_stream(stream));
