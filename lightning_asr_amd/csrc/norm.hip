@@ -197,8 +197,9 @@ __device__ __forceinline__ void lds_vec8(const float* p, float (&o)[4]) {
   o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
 }
 
-// out = act((a*y + b)*se + a2*y2 + b2);  s_tab = [a | b | a2 | b2][C]
-template <typename T>
+// out = act((a*y + b)*se + a2*y2 + b2);  s_tab = [a | b | a2 | b2][C].  Two items per thread in flight, no branch
+// around a load (HAS2 is a template parameter, the second item's index is clamped and only its store predicated).
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                          const T* __restrict__ y2, const float* __restrict__ coef2,
                                                          const float* __restrict__ se, T* __restrict__ out,
@@ -207,29 +208,47 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   constexpr int V = Vec<T>::kN;
   for (int i = threadIdx.x * 4; i < 2 * C; i += 1024) {
     *reinterpret_cast<float4*>(s_tab + i) = *reinterpret_cast<const float4*>(coef + i);
-    *reinterpret_cast<float4*>(s_tab + 2 * C + i) = y2 ? *reinterpret_cast<const float4*>(coef2 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(s_tab + 2 * C + i) = HAS2 ? *reinterpret_cast<const float4*>(coef2 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   const int cv = C / V;
   const int r0 = blockIdx.x * kFwdSlabRows;
   const int n_items = (min(r0 + kFwdSlabRows, rows) - r0) * cv;
-  for (int it = threadIdx.x; it < n_items; it += 256) {
-    const int rl = it / cv, c = (it - rl * cv) * V, r = r0 + rl;
-    const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
-    float v[V], w[V], a[V], b[V], a2[V], b2[V], o[V];
-    Vec<T>::load(y + off, v);
-    if (y2) Vec<T>::load(y2 + off, w);
-    lds_vec8(s_tab + c, a); lds_vec8(s_tab + C + c, b);
-    lds_vec8(s_tab + 2 * C + c, a2); lds_vec8(s_tab + 3 * C + c, b2);
-    const float* sp = se ? se + (uint32_t)(r / Tt) * (uint32_t)C + (uint32_t)c : nullptr;
+  for (int it0 = threadIdx.x; it0 < n_items; it0 += 512) {
+    uint4 rv[2], rw[2];
+    uint32_t off[2];
+    int cc[2], rr[2];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      float z = fmaf(v[j], a[j], b[j]);
-      if (sp) z *= sp[j];
-      if (y2) z += fmaf(w[j], a2[j], b2[j]);
-      o[j] = act_fwd(z, act);
+    for (int u = 0; u < 2; ++u) {
+      const int it = min(it0 + 256 * u, n_items - 1);
+      const int rl = it / cv;
+      cc[u] = (it - rl * cv) * V; rr[u] = r0 + rl;
+      off[u] = (uint32_t)rr[u] * (uint32_t)C + (uint32_t)cc[u];
+      rv[u] = Vec<T>::raw(y + off[u]);
+      if (HAS2) rw[u] = Vec<T>::raw(y2 + off[u]);
     }
-    Vec<T>::store(out + off, o);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = cc[u];
+      float v[V], w[V], a[V], b[V], o[V];
+      Vec<T>::unpack(rv[u], v);
+      lds_vec8(s_tab + c, a); lds_vec8(s_tab + C + c, b);
+      const float* sp = se ? se + (uint32_t)(rr[u] / Tt) * (uint32_t)C + (uint32_t)c : nullptr;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        o[j] = fmaf(v[j], a[j], b[j]);
+        if (sp) o[j] *= sp[j];
+      }
+      if (HAS2) {
+        Vec<T>::unpack(rw[u], w);
+        lds_vec8(s_tab + 2 * C + c, a); lds_vec8(s_tab + 3 * C + c, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] += fmaf(w[j], a[j], b[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = act_fwd(o[j], act);
+      if (it0 + 256 * u < n_items) Vec<T>::store(out + off[u], o);
+    }
   }
 }
 
@@ -384,8 +403,9 @@ __global__ __launch_bounds__(256) void bn_bwd_table_partials_kernel(const float*
   }
 }
 
-// pass 2b: dy = G1*d1 + B1*y + C1 (rows past the utterance length zeroed), dy2 = G2*d + B2*y2 + C2
-template <typename T>
+// pass 2b: dy = G1*d1 + B1*y + C1 (rows past the utterance length zeroed), dy2 = G2*d + B2*y2 + C2.
+// Two items per thread in flight, HAS2 a template parameter: no branch around a load.
+template <typename T, bool HAS2>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const T* __restrict__ y2, const float* __restrict__ tab,
                                                            const float* __restrict__ se, const float* __restrict__ seg,
@@ -395,46 +415,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   constexpr int V = Vec<T>::kN;
   for (int i = threadIdx.x * 4; i < 10 * C; i += 1024) *reinterpret_cast<float4*>(s_tab + i) = *reinterpret_cast<const float4*>(tab + i);
   __syncthreads();
-  const bool has2 = y2 != nullptr;
   const int cv = C / V;
   const int r0 = blockIdx.x * kSlabRows;
   const int n_items = (min(r0 + kSlabRows, rows) - r0) * cv;
-  for (int it = threadIdx.x; it < n_items; it += 256) {
-    const int rl = it / cv, c = (it - rl * cv) * V, r = r0 + rl;
-    const uint32_t off = (uint32_t)r * (uint32_t)C + (uint32_t)c;
-    float dv[V], yv[V], rv[V], o1[V], o2[V];
-    Vec<T>::load(dout + off, dv);
-    Vec<T>::load(y + off, yv);
-    if (has2) Vec<T>::load(y2 + off, rv);
-    const int ub = r / Tt;
-    const bool masked = row_lens && (r - ub * Tt) >= row_lens[ub];
-    const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-    const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-    float a1[V], b1[V], G[V], Bc[V], Cc[V];
-    lds_vec8(s_tab + c, a1); lds_vec8(s_tab + C + c, b1);
-    float z[V];
+  for (int it0 = threadIdx.x; it0 < n_items; it0 += 512) {
+    uint4 rd[2], ry[2], rr2[2];
+    uint32_t off[2];
+    int cc[2], rr[2];
 #pragma unroll
-    for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (sp ? sp[j] : 1.f);
-    if (has2) {
-      lds_vec8(s_tab + 5 * C + c, a1); lds_vec8(s_tab + 6 * C + c, b1);
-#pragma unroll
-      for (int j = 0; j < V; ++j) z[j] += fmaf(rv[j], a1[j], b1[j]);
+    for (int u = 0; u < 2; ++u) {
+      const int it = min(it0 + 256 * u, n_items - 1);
+      const int rl = it / cv;
+      cc[u] = (it - rl * cv) * V; rr[u] = r0 + rl;
+      off[u] = (uint32_t)rr[u] * (uint32_t)C + (uint32_t)cc[u];
+      rd[u] = Vec<T>::raw(dout + off[u]);
+      ry[u] = Vec<T>::raw(y + off[u]);
+      if (HAS2) rr2[u] = Vec<T>::raw(y2 + off[u]);
     }
-    float d[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
-    lds_vec8(s_tab + 2 * C + c, G); lds_vec8(s_tab + 3 * C + c, Bc); lds_vec8(s_tab + 4 * C + c, Cc);
+    for (int u = 0; u < 2; ++u) {
+      const int c = cc[u], r = rr[u];
+      const bool live = it0 + 256 * u < n_items;
+      float dv[V], yv[V], rv[V], o1[V], o2[V];
+      Vec<T>::unpack(rd[u], dv);
+      Vec<T>::unpack(ry[u], yv);
+      if (HAS2) Vec<T>::unpack(rr2[u], rv);
+      const int ub = r / Tt;
+      const bool masked = row_lens && (r - ub * Tt) >= row_lens[ub];
+      const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+      const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
+      float a1[V], b1[V], G[V], Bc[V], Cc[V];
+      lds_vec8(s_tab + c, a1); lds_vec8(s_tab + C + c, b1);
+      float z[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float d1 = fmaf(d[j], sp ? sp[j] : 1.f, gp ? gp[j] : 0.f);
-      o1[j] = masked ? 0.f : fmaf(G[j], d1, fmaf(Bc[j], yv[j], Cc[j]));
-    }
-    Vec<T>::store(dy + off, o1);
-    if (has2) {
-      lds_vec8(s_tab + 7 * C + c, G); lds_vec8(s_tab + 8 * C + c, Bc); lds_vec8(s_tab + 9 * C + c, Cc);
+      for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (sp ? sp[j] : 1.f);
+      if (HAS2) {
+        lds_vec8(s_tab + 5 * C + c, a1); lds_vec8(s_tab + 6 * C + c, b1);
 #pragma unroll
-      for (int j = 0; j < V; ++j) o2[j] = fmaf(G[j], d[j], fmaf(Bc[j], rv[j], Cc[j]));
-      Vec<T>::store(dy2 + off, o2);
+        for (int j = 0; j < V; ++j) z[j] += fmaf(rv[j], a1[j], b1[j]);
+      }
+      float d[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
+      lds_vec8(s_tab + 2 * C + c, G); lds_vec8(s_tab + 3 * C + c, Bc); lds_vec8(s_tab + 4 * C + c, Cc);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float d1 = fmaf(d[j], sp ? sp[j] : 1.f, gp ? gp[j] : 0.f);
+        o1[j] = masked ? 0.f : fmaf(G[j], d1, fmaf(Bc[j], yv[j], Cc[j]));
+      }
+      if (live) Vec<T>::store(dy + off[u], o1);
+      if (HAS2) {
+        lds_vec8(s_tab + 7 * C + c, G); lds_vec8(s_tab + 8 * C + c, Bc); lds_vec8(s_tab + 9 * C + c, Cc);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o2[j] = fmaf(G[j], d[j], fmaf(Bc[j], rv[j], Cc[j]));
+        if (live) Vec<T>::store(dy2 + off[u], o2);
+      }
     }
   }
 }
@@ -512,8 +547,15 @@ extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2,
   LASR_TRY(check_bn_shape("lasr_bn_act_fwd", dtype, B, T_, C));
   const int64_t rows = B * T_;
   const size_t shmem = (size_t)4 * C * sizeof(float);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem, as_stream(stream),
-                                           (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows, (int)T_, (int)C, act));
+  if (y2) {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act));
+  } else {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act));
+  }
   LASR_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
 }
@@ -585,9 +627,15 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
   }
   const size_t shmem = (size_t)10 * C * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_apply: C too large for the LDS coefficient table");
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
-                                           (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy, (T*)dy2,
-                                           (int)rows, (int)T_, (int)C, act));
+  if (y2) {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act));
+  } else {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act));
+  }
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;
 }
