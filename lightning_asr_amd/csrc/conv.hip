@@ -672,15 +672,18 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(const T* __restric
       for (int p = 0; p < kXP; ++p) {
         const int r = lr + p * P::kRowsPerPass;
         const int64_t ti = in0 + r;
-        vx[p] = make_uint4(0u, 0u, 0u, 0u);
-        if (r < in_rows && c_in && ti >= 0 && ti < Tlen) vx[p] = *reinterpret_cast<const uint4*>(xb + ti * C + c0 + lc);
+        // unconditional load from a clamped address, value masked: no exec-mask branch (and vmcnt drain) per pass
+        const uint4 ld = *reinterpret_cast<const uint4*>(xb + (int64_t)min(max(ti, (int64_t)0), Tlen - 1) * C + min(c0 + lc, C - P::kVec));
+        const uint32_t mk = (r < in_rows && c_in && ti >= 0 && ti < Tlen) ? 0xffffffffu : 0u;
+        vx[p] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
       }
 #pragma unroll
       for (int p = 0; p < kDP; ++p) {
         const int r = lr + p * P::kRowsPerPass;
         const int64_t t = t0 + r;
-        vd[p] = make_uint4(0u, 0u, 0u, 0u);
-        if (r < WT && c_in && t < tend) vd[p] = *reinterpret_cast<const uint4*>(db + t * C + c0 + lc);
+        const uint4 ld = *reinterpret_cast<const uint4*>(db + (int64_t)min(t, Tlen - 1) * C + min(c0 + lc, C - P::kVec));
+        const uint32_t mk = (r < WT && c_in && t < tend) ? 0xffffffffu : 0u;
+        vd[p] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
       }
 #pragma unroll
       for (int p = 0; p < kXP; ++p) {

@@ -124,11 +124,13 @@ def test_dwconv_bf16(dev):
     assert max_rel(got.float().transpose(1, 2), ref) < 1e-2
 
 
-@pytest.mark.parametrize("C,k,T", [(256, 33, 501), (512, 75, 260), (336, 51, 77), (512, 87, 130), (64, 1, 40), (72, 5, 300)])
+@pytest.mark.parametrize("C,k,T", [(256, 33, 501), (512, 75, 260), (336, 51, 77), (512, 87, 130), (64, 1, 40), (72, 5, 300),
+                                   (64, 63, 801), (128, 39, 1300), (64, 101, 513)])
 def test_dwconv_bf16_dot2_exact_taps(dev, C, k, T):
-    """bf16 stride-1 kernel (tap pairs on v_dot2c_f32_bf16): activations and taps are bf16, products exact in
-    f32, so against an f64 convolution of the same bf16 operands only the f32 accumulation order and the
-    final bf16 rounding differ.  Forward, and the flipped form with an addend (data gradient)."""
+    """bf16 stride-1 kernels (Toeplitz MFMA form; tap pairs on v_dot2c_f32_bf16 with LASR_DWCONV_DOT2=1): activations
+    and taps are bf16, products exact in f32, so against an f64 convolution of the same bf16 operands only the f32
+    accumulation order and the final bf16 rounding differ.  Forward, and the flipped form with an addend (data
+    gradient); T > 512 runs several time tiles, k = 101 is the widest window the MFMA form takes."""
     from lightning_asr_amd import ops
     g = torch.Generator().manual_seed(C * 3 + k)
     B = 3
