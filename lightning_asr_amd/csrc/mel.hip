@@ -17,6 +17,7 @@ static constexpr int kNfft = 512, kWin = 320, kHop = 160, kPad = 32, kMel = 64, 
 static constexpr int kWinOff = (kNfft - kWin) / 2;  // 96
 static constexpr int kFramesPerBlock = 16;
 static constexpr int kWaves = 4;
+static constexpr int kSigLen = kFramesPerBlock * kHop + kNfft;   // 3072 samples staged per block
 
 struct MelTables {
   double window[kWin];
@@ -92,18 +93,12 @@ __device__ __forceinline__ void fft8(cplx (&v)[8]) {
 }
 __device__ static const int kPerm[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 
-// sample of the zero-padded (32|L|32), pre-emphasised, dithered signal at padded index i in [0, L+64)
-__device__ __forceinline__ float padded_sample(const float* __restrict__ y, const float* __restrict__ nz,
-                                               int64_t L, int64_t i) {
-  const int64_t j = i - kPad;
-  if (j < 0 || j >= L) return 0.f;
-  // f32 steps, as the reference computes them (data_module.py:155,157)
-  float cur = y[j];
-  if (nz) cur += 1e-5f * nz[j];
-  if (j == 0) return cur;
-  float prev = y[j - 1];
-  if (nz) prev += 1e-5f * nz[j - 1];
-  return cur - 0.97f * prev;
+// Each wave transforms its own frame in its own LDS rows: the exchanges between FFT passes only need the wave's
+// own LDS traffic ordered (LDS executes a wave's accesses in order), not a workgroup barrier.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // grid: (ceil(T/16), B), block 256.  dB values -> db_out [B][T][64] f32 (workspace); per-block
@@ -118,6 +113,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   __shared__ double s_twr[kNfft];
   __shared__ double s_twi[kNfft];
   __shared__ double s_red[kWaves][2];
+  __shared__ float s_sig[kSigLen];
 
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -133,6 +129,38 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   }
   int rx = 0, wx = 0, ry = 0, wy = 0;
   if (aug) { rx = aug[b * 4 + 0]; wx = aug[b * 4 + 1]; ry = aug[b * 4 + 2]; wy = aug[b * 4 + 3]; }
+  // The block's stretch of the reflect-padded, zero-padded, pre-emphasised, dithered signal -> LDS once
+  // (16 frames x hop 160 + one window): every load unconditional (clamped index, masked value) and all of a
+  // thread's loads issued before the first is used.  Loading per frame behind per-lane bounds branches made
+  // each frame a chain of ~6 exposed memory round trips (the kernel took 136 us for 20 MB).
+  {
+    constexpr int kSigIt = kSigLen / 256;          // 12
+    const int64_t i0 = (int64_t)blockIdx.x * kFramesPerBlock * kHop - kNfft / 2;   // padded-signal index of s_sig[0]
+    float cur[kSigIt], prv[kSigIt], ncur[kSigIt], nprv[kSigIt];
+#pragma unroll
+    for (int u = 0; u < kSigIt; ++u) {
+      int64_t i = i0 + threadIdx.x + 256 * u;
+      i = i < 0 ? -i : i;                                   // reflect at both ends (center=True, pad_mode reflect)
+      i = i >= Lp ? 2 * (Lp - 1) - i : i;
+      const int64_t j = i - kPad;                           // index into the utterance
+      const int64_t jmax = max(Lb - 1, (int64_t)0);
+      const int64_t jc = min(max(j, (int64_t)0), jmax), jp = min(max(j - 1, (int64_t)0), jmax);
+      cur[u] = y[jc]; prv[u] = y[jp];
+      ncur[u] = nz ? nz[jc] : 0.f; nprv[u] = nz ? nz[jp] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kSigIt; ++u) {
+      int64_t i = i0 + threadIdx.x + 256 * u;
+      i = i < 0 ? -i : i;
+      i = i >= Lp ? 2 * (Lp - 1) - i : i;
+      const int64_t j = i - kPad;
+      // f32 steps, as the reference computes them (data_module.py:155,157)
+      float c = cur[u], p = prv[u];
+      if (nz) { c += 1e-5f * ncur[u]; p += 1e-5f * nprv[u]; }
+      const float v = j == 0 ? c : c - 0.97f * p;
+      s_sig[threadIdx.x + 256 * u] = (j < 0 || j >= Lb || i < 0) ? 0.f : v;
+    }
+  }
   __syncthreads();
 
   double acc_s = 0.0, acc_q = 0.0;
@@ -146,20 +174,16 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int n = lane + 64 * r;
-      double x = 0.0;
-      if (live && n >= kWinOff && n < kWinOff + kWin) {
-        int64_t i = f * kHop - kNfft / 2 + n;  // index into the padded signal, reflect at both ends
-        if (i < 0) i = -i;
-        if (i >= Lp) i = 2 * (Lp - 1) - i;
-        x = (double)padded_sample(y, nz, Lb, i) * g_mel.window[n - kWinOff];
-      }
+      const bool inw = live && n >= kWinOff && n < kWinOff + kWin;
+      const int fl = it * kWaves + wid;                       // frame within the block
+      const double x = inw ? (double)s_sig[fl * kHop + n] * g_mel.window[min(max(n - kWinOff, 0), kWin - 1)] : 0.0;
       v[r] = {x, 0.0};
     }
     fft8(v);
-    __syncthreads();  // previous iteration's readers are done with sre/sim
+    wave_sync();  // previous iteration's readers are done with sre/sim
 #pragma unroll
     for (int r = 0; r < 8; ++r) { sre[lane * 8 + r] = v[kPerm[r]].re; sim[lane * 8 + r] = v[kPerm[r]].im; }
-    __syncthreads();
+    wave_sync();
     // ---- pass 1 (Ns = 8)
     {
       const int k = lane & 7;
@@ -170,11 +194,11 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
         v[r] = cmul(x, cplx{s_twr[tw], s_twi[tw]});
       }
       fft8(v);
-      __syncthreads();
+      wave_sync();
       const int base = (lane >> 3) * 64 + k;
 #pragma unroll
       for (int r = 0; r < 8; ++r) { sre[base + r * 8] = v[kPerm[r]].re; sim[base + r * 8] = v[kPerm[r]].im; }
-      __syncthreads();
+      wave_sync();
     }
     // ---- pass 2 (Ns = 64)
     {
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
         v[r] = cmul(x, cplx{s_twr[tw], s_twi[tw]});
       }
       fft8(v);
-      __syncthreads();
+      wave_sync();
       // X[lane + 64 r] = v[perm r]; keep the power of bins 0..256 in sre
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
         const cplx z = v[kPerm[4]];
         sre[256] = z.re * z.re + z.im * z.im;
       }
-      __syncthreads();
+      wave_sync();
     }
     // ---- mel + dB: lane = mel channel
     float db = 0.f;
