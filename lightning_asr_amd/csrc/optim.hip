@@ -23,7 +23,17 @@ __global__ __launch_bounds__(256) void novograd_norm_kernel(const float* __restr
   for (int t = lo; t < n_tensors && seg < end; ++t) {
     const int64_t tend = offsets[t + 1] < end ? offsets[t + 1] : end;
     double acc = 0.0;
-    for (int64_t e = seg + threadIdx.x; e < tend; e += 256) {
+    int64_t e0 = seg;
+    if ((seg & 3) == 0) {   // 16-byte groups of the segment (every tensor of the model starts on one), scalar tail
+      const int64_t nv = (tend - seg) >> 2;
+      for (int64_t q = threadIdx.x; q < nv; q += 256) {
+        const float4 g4 = *reinterpret_cast<const float4*>(grads + seg + 4 * q);
+        const float a = g4.x * grad_scale, b = g4.y * grad_scale, c = g4.z * grad_scale, d = g4.w * grad_scale;
+        acc += ((double)a * (double)a + (double)b * (double)b) + ((double)c * (double)c + (double)d * (double)d);
+      }
+      e0 = seg + 4 * nv;
+    }
+    for (int64_t e = e0 + threadIdx.x; e < tend; e += 256) {
       const float g = grads[e] * grad_scale;
       acc += (double)g * (double)g;
     }
@@ -54,19 +64,47 @@ __global__ __launch_bounds__(256) void novograd_update_kernel(float* __restrict_
                                                               int n_tensors, const float* __restrict__ denom,
                                                               const float* __restrict__ lr_ptr, float beta1, float wd,
                                                               float grad_scale, int64_t n) {
+  // The tensor of an element is found by bisection over the offset table: the table lives in LDS (a search from
+  // global memory is seven dependent loads per element) and one search serves four consecutive elements, which
+  // move as 16-byte vectors whenever the group lies inside one tensor (always, for this model's shapes).
+  extern __shared__ int64_t s_off[];   // [n_tensors + 1]
+  for (int i = threadIdx.x; i <= n_tensors; i += 256) s_off[i] = offsets[i];
+  __syncthreads();
   const float lr = *lr_ptr;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-    int lo = 0, hi = n_tensors;  // offsets[lo] <= e < offsets[hi]
+  const int64_t ngrp = (n + 3) >> 2;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < ngrp; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = 4 * q;
+    int lo = 0, hi = n_tensors;  // s_off[lo] <= e < s_off[hi]
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (offsets[mid] <= e) lo = mid; else hi = mid;
+      if (s_off[mid] <= e) lo = mid; else hi = mid;
     }
-    const float p = params[e];
-    float g = (grads[e] * grad_scale) / denom[lo];
-    if (wd != 0.f) g = g + wd * p;
-    const float m = exp_avg[e] * beta1 + g;
-    exp_avg[e] = m;
-    params[e] = p - lr * m;
+    if (e + 4 <= n && s_off[lo + 1] >= e + 4) {
+      const float dn = denom[lo];
+      const float4 p = *reinterpret_cast<const float4*>(params + e);
+      const float4 g = *reinterpret_cast<const float4*>(grads + e);
+      const float4 m0 = *reinterpret_cast<const float4*>(exp_avg + e);
+      float pv[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g.x, g.y, g.z, g.w}, mv[4] = {m0.x, m0.y, m0.z, m0.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float gi = (gv[i] * grad_scale) / dn;
+        if (wd != 0.f) gi = gi + wd * pv[i];
+        mv[i] = mv[i] * beta1 + gi;
+        pv[i] = pv[i] - lr * mv[i];
+      }
+      *reinterpret_cast<float4*>(exp_avg + e) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      *reinterpret_cast<float4*>(params + e) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    } else {
+      for (int64_t ee = e; ee < e + 4 && ee < n; ++ee) {
+        while (lo + 1 < n_tensors && s_off[lo + 1] <= ee) ++lo;
+        const float pe = params[ee];
+        float gi = (grads[ee] * grad_scale) / denom[lo];
+        if (wd != 0.f) gi = gi + wd * pe;
+        const float m = exp_avg[ee] * beta1 + gi;
+        exp_avg[ee] = m;
+        params[ee] = pe - lr * m;
+      }
+    }
   }
 }
 
@@ -114,10 +152,12 @@ extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_
   hipLaunchKernelGGL(novograd_moment_kernel, dim3((unsigned)cdiv(n_tensors, 256)), dim3(256), 0, st, norm2, exp_avg_sq, denom,
                      (int)n_tensors, beta2, eps);
   LASR_LAUNCH_CHECK("novograd_moment_kernel");
-  int64_t blocks = cdiv(n_elems, 256);
-  if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(novograd_update_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, exp_avg, offsets, (int)n_tensors,
-                     denom, lr, beta1, weight_decay, grad_scale, n_elems);
+  int64_t blocks = cdiv(cdiv(n_elems, 4), 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  const size_t off_bytes = (size_t)(n_tensors + 1) * sizeof(int64_t);
+  LASR_CHECK_SHAPE(off_bytes <= 48 * 1024, "lasr_novograd_step: offset table too large for LDS (%lld tensors)", (long long)n_tensors);
+  hipLaunchKernelGGL(novograd_update_kernel, dim3((unsigned)blocks), dim3(256), off_bytes, st, params, grads, exp_avg, offsets,
+                     (int)n_tensors, denom, lr, beta1, weight_decay, grad_scale, n_elems);
   LASR_LAUNCH_CHECK("novograd_update_kernel");
   return 0;
 }
