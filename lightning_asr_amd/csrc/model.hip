@@ -51,6 +51,7 @@ struct BnRef { int64_t gamma = -1, beta = -1, rmean = -1, rvar = -1; };
 
 // split-K of the 1x1 weight gradients (K = B*T' rows): 16 slices x 16 tiles x 2 problems = 512 workgroups
 static int wgrad_split() { static const int v = getenv("LASR_WGRAD_SPLIT") ? atoi(getenv("LASR_WGRAD_SPLIT")) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }
+static int dec_split_k() { static const int v = getenv("LASR_DEC_SPLIT") ? atoi(getenv("LASR_DEC_SPLIT")) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }
 static bool no_fuse() { static const bool v = getenv("LASR_NO_FUSE") != nullptr; return v; }
 
 // One "unit": [depthwise conv] -> 1x1 GEMM (+mask) -> BN  [+ residual 1x1 GEMM -> BN] -> activation
@@ -222,6 +223,7 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   }
   const int64_t C = m->cfg.n_class;
   scratch = std::max(scratch, lasr_gemm_workspace_bytes(C, 1024, 16, 0));
+  scratch = std::max(scratch, lasr_gemm_workspace_bytes(N, C, 16, 0));   // decoder forward, split-K partials
   scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, C));
   if (m->cfg.variant != LASR_VARIANT_PLAIN) {
     p.o_cat = take(cur, (size_t)N * 336 * es);
@@ -391,8 +393,11 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
   }
   // decoder 1x1 1024 -> C with bias (models/QuartNet.py:275), f32 logits, then log_softmax (+argmax)
   const int64_t C = m->cfg.n_class;
+  // a narrow vocabulary leaves N/128 = 1 tile column: split K so that the 32 MB of activations are streamed by
+  // 4 x 126 workgroups instead of 126 (the split partials are C/1024 of the input: negligible)
+  const int dec_split = (dt == LASR_BF16 && C <= 128) ? dec_split_k() : 1;
   LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->w_dec), atf(ws, p.o_logits), dt, LASR_F32, N, C, 1024, 0, 0, params + m->b_dec,
-                     nullptr, nullptr, 0, nullptr, 1, scratch, p.scratch_bytes, stream));
+                     nullptr, nullptr, 0, nullptr, dec_split, scratch, p.scratch_bytes, stream));
   LASR_TRY(lasr_log_softmax(atf(ws, p.o_logits), logp_out, argmax_out, N, C, stream));
   return 0;
 }
