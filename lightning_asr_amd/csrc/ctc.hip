@@ -96,6 +96,13 @@ __device__ __forceinline__ float lse3_fast(float a, float b, float c) {
   return fmaf(kLn2, __builtin_amdgcn_logf(s), mm);
 }
 
+__device__ __forceinline__ float lse2_fast(float a, float b) {
+  const float m = fmaxf(a, b);
+  const float mm = (m == kNegInf) ? 0.f : m;
+  const float s = __builtin_amdgcn_exp2f((a - mm) * kLog2e) + __builtin_amdgcn_exp2f((b - mm) * kLog2e);
+  return fmaf(kLn2, __builtin_amdgcn_logf(s), mm);
+}
+
 // EM_LDS: the utterance's whole emission matrix logp[b] (T x C f32; 56 KB at T'=501, C=28) is copied into LDS once
 // with coalesced 16-byte loads and both waves gather their per-state emissions from there one step ahead, so the
 // T' dependent steps contain no global load and never wait on vmcnt (which also counts the lattice stores).
@@ -183,7 +190,8 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
         // i==0: s-1 is the previous lane's last state, s-2 its second to last; i==1: s-2 is the previous lane's last
         const float s1 = i >= 1 ? a[i - 1] : p1;
         const float s2v = (i == 0) ? p2 : (i == 1 ? p1 : a[i - 2]);
-        n[i] = lse3_fast(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
+        // even states are blanks (NS is even, so the parity of s is the parity of i): no skip transition, two terms
+        n[i] = ((i & 1) ? lse3_fast(a[i], s1, skip_ok[i] ? s2v : kNegInf) : lse2_fast(a[i], s1)) + em[i];
       }
     } else {
       const float q1 = wave_shl1(a[0], kNegInf);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(128) void ctc_alpha_beta_kernel(const float* __rest
       for (int i = 0; i < NS; ++i) {
         const float s1 = i + 1 < NS ? a[i + 1] : q1;
         const float s2v = (i + 2 < NS) ? a[i + 2] : (i + 2 == NS ? q1 : q2);
-        n[i] = lse3_fast(a[i], s1, skip_ok[i] ? s2v : kNegInf) + em[i];
+        n[i] = ((i & 1) ? lse3_fast(a[i], s1, skip_ok[i] ? s2v : kNegInf) : lse2_fast(a[i], s1)) + em[i];
       }
     }
 #pragma unroll
