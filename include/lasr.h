@@ -116,6 +116,21 @@ int lasr_gemm_ld(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
                  int64_t M, int64_t N, int64_t K, int transA, int transB, const float* bias, int split_k, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* Deferred reductions.  The split-K weight-gradient GEMMs and the depthwise weight gradient end in a small
+ * "sum the partial slabs" kernel each; a backward stage can instead leave the slabs where they are and sum all of
+ * them with ONE launch at its end:
+ *   lasr_gemm_batch_split_partials: lasr_gemm_batch(split_k > 1, f32 result) without the final sums;
+ *       partials[i] -> [splits[i]][M_i*N_i] f32 inside `workspace` (which the caller must keep until the reduce);
+ *   lasr_dwconv_wgrad_partials: lasr_dwconv_wgrad without the final sum; `workspace` holds [*n_partials][C*k];
+ *   lasr_reduce_many: out[i] = sum_p partials[p*n + i] for up to 64 segments, f64 accumulation, fixed order. */
+typedef struct { const float* partials; float* out; int64_t n; int32_t n_partials; } lasr_reduce_desc;
+int lasr_reduce_many(const lasr_reduce_desc* descs, int n_descs, void* stream);
+int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int transA, int transB,
+                                   int split_k, void* workspace, size_t workspace_bytes, const float** partials,
+                                   int* splits, void* stream);
+int lasr_dwconv_wgrad_partials(const void* x, const void* dy, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
+                               int stride, void* workspace, size_t workspace_bytes, int* n_partials, void* stream);
+
 /* lasr_gemm_batch that leaves each problem's BN partial sums UNREDUCED in the workspace (no split-K):
  * for every problem with stats != NULL, stat_partials[i] points at [stat_tiles[i]][2][N] f32 inside
  * `workspace` (valid until the workspace is reused) and problem.stats itself is not written.

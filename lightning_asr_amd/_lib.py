@@ -43,6 +43,9 @@ SIGNATURES = {
     "lasr_bn_act_bwd_stats": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),
     "lasr_bn_act_bwd_apply": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),
     "lasr_bn_bwd_apply_workspace_bytes": (_sz, [_i64]),
+    "lasr_reduce_many": (_i32, [_p, _i32, _p]),
+    "lasr_gemm_batch_split_partials": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
+    "lasr_dwconv_wgrad_partials": (_i32, [_p, _p, _i32, _i64, _i64, _i64, _i32, _i32, _p, _sz, _p, _p]),
     "lasr_gemm_batch_partials": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "lasr_bn_finalize_partials": (_i32, [_p, _i32, _i64, _i64, C.c_float, C.c_float, _p]),
     "lasr_seqsum": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p]),

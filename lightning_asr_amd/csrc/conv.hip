@@ -812,9 +812,24 @@ extern "C" size_t lasr_dwconv_wgrad_workspace_bytes(int64_t B, int64_t Tout, int
   return (size_t)B * cdiv(Tout, kWChunkG) * C * k * sizeof(float);   // the finer of the two chunkings
 }
 
+static int dwconv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
+                            int stride, void* workspace, size_t workspace_bytes, void* stream, int* n_partials_out);
+
 extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
                                  int stride, void* workspace, size_t workspace_bytes, void* stream) {
-  LASR_CHECK_ARG(x && dy && dw && workspace, "lasr_dwconv_wgrad: null pointer");
+  LASR_CHECK_ARG(dw, "lasr_dwconv_wgrad: null pointer");
+  return dwconv_wgrad_impl(x, dy, dw, dtype, B, Tin, C, k, stride, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int lasr_dwconv_wgrad_partials(const void* x, const void* dy, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
+                                          int stride, void* workspace, size_t workspace_bytes, int* n_partials, void* stream) {
+  LASR_CHECK_ARG(n_partials, "lasr_dwconv_wgrad_partials: null pointer");
+  return dwconv_wgrad_impl(x, dy, nullptr, dtype, B, Tin, C, k, stride, workspace, workspace_bytes, stream, n_partials);
+}
+
+static int dwconv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
+                             int stride, void* workspace, size_t workspace_bytes, void* stream, int* n_partials_out) {
+  LASR_CHECK_ARG(x && dy && workspace, "lasr_dwconv_wgrad: null pointer");
   LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_dwconv_wgrad: bad dtype");
   LASR_CHECK_SHAPE(k >= 1 && k <= kMaxK && (k & 1) && (stride == 1 || stride == 2) && C % 4 == 0 && B > 0 && B < 65536 && Tin > 0,
                    "lasr_dwconv_wgrad: k=%d stride=%d C=%lld", k, stride, (long long)C);
@@ -853,6 +868,7 @@ extern "C" int lasr_dwconv_wgrad(const void* x, const void* dy, float* dw, int d
   }
   LASR_LAUNCH_CHECK("dwconv_wgrad_kernel");
   const int64_t n = C * k;
+  if (n_partials_out) { *n_partials_out = (int)(B * n_chunks); return 0; }   // the caller sums the slabs later (lasr_reduce_many)
   return launch_reduce_partials(partials, (int)(B * n_chunks), n, dw, n, nullptr, as_stream(stream));
 }
 

@@ -343,12 +343,17 @@ extern "C" size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs
   return b;
 }
 
+// split_out != null: the split-K slabs are left unreduced; split_out[i] = {slabs, count}
+struct SplitOut { const float* partials; int splits; };
 static int gemm_batch_impl(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
-                           int split_k, void* workspace, size_t workspace_bytes, void* stream, StatOut* stat_out) {
+                           int split_k, void* workspace, size_t workspace_bytes, void* stream, StatOut* stat_out,
+                           SplitOut* split_out = nullptr) {
   LASR_CHECK_ARG(probs && n_probs >= 1 && n_probs <= 2, "lasr_gemm_batch: 1 or 2 problems");
   const size_t need = lasr_gemm_batch_workspace_bytes(probs, n_probs, split_k);
   if (need > 0 && (!workspace || workspace_bytes < need)) return fail(LASR_E_WORKSPACE, "lasr_gemm_batch: workspace %zu < %zu", workspace_bytes, need);
   char* wsp = reinterpret_cast<char*>(workspace);
+  if (split_out && (dtype_ab != LASR_BF16 || n_probs == 1))
+    return fail(LASR_E_ARG, "lasr_gemm_batch_split_partials: two bf16 problems per call");
   if (dtype_ab != LASR_BF16 || n_probs == 1 || getenv("LASR_NO_GEMM_BATCH")) {
     for (int i = 0; i < n_probs; ++i) {
       const lasr_gemm_problem& q = probs[i];
@@ -397,7 +402,9 @@ static int gemm_batch_impl(const lasr_gemm_problem* probs, int n_probs, int dtyp
   const int rc = launch_gemm_bf16_batch(g, splits, 2, dtype_c, transA, transB, st, stat_tiles);
   prof_end(tok, st);
   if (rc) return rc;
-  if (g[0].split_ws && g[1].split_ws && dtype_c == LASR_F32) {
+  if (split_out) {
+    for (int i = 0; i < 2; ++i) { split_out[i].partials = g[i].split_ws; split_out[i].splits = splits[i]; }
+  } else if (g[0].split_ws && g[1].split_ws && dtype_c == LASR_F32) {
     SplitReduce2 a;
     int64_t mx = 0;
     for (int i = 0; i < 2; ++i) {
@@ -443,5 +450,15 @@ extern "C" int lasr_gemm_batch_partials(const lasr_gemm_problem* probs, int n_pr
   StatOut so[2] = {{nullptr, 0}, {nullptr, 0}};
   LASR_TRY(gemm_batch_impl(probs, n_probs, dtype_ab, dtype_c, transA, transB, 1, workspace, workspace_bytes, stream, so));
   for (int i = 0; i < n_probs; ++i) { stat_partials[i] = so[i].partials; stat_tiles[i] = so[i].tiles; }
+  return 0;
+}
+
+extern "C" int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int transA, int transB,
+                                              int split_k, void* workspace, size_t workspace_bytes, const float** partials,
+                                              int* splits, void* stream) {
+  LASR_CHECK_ARG(partials && splits && split_k > 1, "lasr_gemm_batch_split_partials: bad argument");
+  SplitOut so[2] = {{nullptr, 0}, {nullptr, 0}};
+  LASR_TRY(gemm_batch_impl(probs, n_probs, dtype_ab, LASR_F32, transA, transB, split_k, workspace, workspace_bytes, stream, nullptr, so));
+  for (int i = 0; i < n_probs; ++i) { partials[i] = so[i].partials; splits[i] = so[i].splits; }
   return 0;
 }

@@ -64,6 +64,7 @@ struct Unit {
   // workspace offsets (bytes) filled by plan()
   size_t o_u = 0, o_y = 0, o_y2 = 0, o_out = 0, o_coef = 0, o_saved = 0, o_coef2 = 0, o_saved2 = 0, o_stats = 0, o_stats2 = 0;
   size_t o_se_sum = 0, o_se_pool = 0, o_se_hid = 0, o_se_scale = 0, o_se_grad = 0;   // SE: [B][co] (hid: [B][co/8]) f32
+  size_t o_wgp = 0, wgp_bytes = 0, o_dwp = 0, dwp_bytes = 0;   // deferred reductions: split-K slabs of dW / dWr, depthwise-dW partials
 };
 
 // BiLSTM context branch (Context / ContextSE): parameter offsets per direction
@@ -236,6 +237,16 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   p.o_logits = take(cur, (size_t)N * C * sizeof(float));
   p.o_glogits = take(cur, (size_t)N * C * sizeof(float));
   p.o_nll = take(cur, (size_t)(B + 1) * sizeof(float));
+  for (Unit& u : m->units) {   // slabs that outlive `scratch`: summed by one lasr_reduce_many per backward stage
+    if (u.has_res) {
+      u.wgp_bytes = 2 * lasr_gemm_workspace_bytes(u.co, u.ci, wgrad_split(), 0);
+      u.o_wgp = take(cur, u.wgp_bytes);
+    }
+    if (u.has_dw) {
+      u.dwp_bytes = lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k);
+      u.o_dwp = take(cur, u.dwp_bytes);
+    }
+  }
   p.scratch_bytes = scratch;
   p.o_scratch = take(cur, scratch);
   p.o_g[0] = take(cur, (size_t)N * cmax * es);
@@ -433,6 +444,11 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                         1, scratch, sb, stream));
   }
   if (unit_hi < 0) unit_hi = (int)m->units.size() - 1;
+  // The "sum the partial slabs" tails of the weight-gradient kernels are collected and issued as ONE launch when
+  // the stage ends (27 launches of ~5 us each off the step; LASR_NO_FUSE=1 keeps them inline for A/B runs).
+  static const bool no_defer = getenv("LASR_NO_DEFER") != nullptr;
+  const bool defer = !no_fuse() && !no_defer;
+  std::vector<lasr_reduce_desc> pending;
   for (int ui = unit_hi; ui >= unit_stop; --ui) {
     const Unit& u = m->units[ui];
     const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
@@ -467,7 +483,15 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       lasr_gemm_problem pr[2];
       pr[0] = {dy, gin, grads + u.w_pw, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
       if (u.has_res) pr[1] = {dy2, x_in, grads + u.w_res, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
-      LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
+      if (defer && u.has_res && dt == LASR_BF16) {
+        const float* parts[2];
+        int splits[2];
+        LASR_TRY(lasr_gemm_batch_split_partials(pr, 2, dt, 1, 1, wgrad_split(), at(ws, u.o_wgp), u.wgp_bytes, parts, splits, stream));
+        pending.push_back({parts[0], grads + u.w_pw, u.co * (int64_t)u.ci, splits[0]});
+        pending.push_back({parts[1], grads + u.w_res, u.co * (int64_t)u.ci, splits[1]});
+      } else {
+        LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
+      }
     }
     const bool need_dx = ui > 0;
     void* dx = at(ws, p.o_g[cur ^ 1]);
@@ -479,7 +503,15 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       if (with_res) pr[1] = {dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), N, u.ci, u.co, nullptr, nullptr, 0, nullptr};
       LASR_TRY(lasr_gemm_batch(pr, with_res ? 2 : 1, dt, dt, 0, 1, 1, scratch, sb, stream));
       // depthwise dW from (x, du); dx = flipped depthwise conv of du (+ residual dx)
-      LASR_TRY(lasr_dwconv_wgrad(x_in, at(ws, p.o_du), grads + u.w_dw, dt, B, Tx, u.ci, u.k, u.stride, scratch, sb, stream));
+      if (defer) {
+        int npart = 0;
+        LASR_TRY(lasr_dwconv_wgrad_partials(x_in, at(ws, p.o_du), dt, B, Tx, u.ci, u.k, u.stride, at(ws, u.o_dwp), u.dwp_bytes, &npart,
+                                            stream));
+        pending.push_back({atf(ws, u.o_dwp), grads + u.w_dw, u.ci * (int64_t)u.k, npart});
+      } else {
+        LASR_TRY(lasr_dwconv_wgrad(x_in, at(ws, p.o_du), grads + u.w_dw, dt, B, Tx, u.ci, u.k, u.stride, scratch, sb, stream));
+      }
+      if (pending.size() > 60) { LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream)); pending.clear(); }
       if (need_dx)
         LASR_TRY(lasr_dwconv_fwd(at(ws, p.o_du), params + u.w_dw, u.has_res ? at(ws, p.o_dxr) : nullptr, dx, dt, B, T, u.ci, u.k, 1,
                                  1, stream));
@@ -515,6 +547,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       cur ^= 1;
     }
   }
+  if (!pending.empty()) LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));   // the stage's gradients are final
   m->bwd_cur = cur;
   m->bwd_next = unit_stop - 1;
   return 0;

@@ -3,6 +3,7 @@
 // Replaces models/QuartNet.py:33-37 (MaskCNN lengths, BatchNorm1d(eps=1e-3), ReLU) and :74-77
 // (residual add + ReLU), plus their autograd backward.  All statistics are f32.
 #include "common.h"
+#include <algorithm>
 
 namespace lasr {
 
@@ -677,6 +678,44 @@ __global__ __launch_bounds__(64) void scale_sum_kernel(const float* __restrict__
   if (threadIdx.x == 0) out[0] = s * scale;
 }
 }  // namespace lasr
+
+// out[i] = sum_p partials[p*n + i] for up to 64 independent (partials, out, n, n_partials) segments in ONE launch:
+// the deferred reductions of a backward stage (split-K slabs of the 1x1 weight gradients, per-(utterance, chunk)
+// partials of the depthwise weight gradients).  f64 accumulation in a fixed order, 16 loads in flight.
+namespace lasr {
+struct ReduceMany { lasr_reduce_desc d[64]; };
+__global__ __launch_bounds__(256) void reduce_many_kernel(ReduceMany a) {
+  const lasr_reduce_desc& q = a.d[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= q.n) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  for (int p = 0; p < q.n_partials; p += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float x = q.partials[(int64_t)min(p + u, q.n_partials - 1) * q.n + i];
+      v[u] = p + u < q.n_partials ? x : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { a0 += (double)v[u]; a1 += (double)v[u + 1]; a2 += (double)v[u + 2]; a3 += (double)v[u + 3]; }
+  }
+  q.out[i] = (float)((a0 + a1) + (a2 + a3));
+}
+}  // namespace lasr
+
+extern "C" int lasr_reduce_many(const lasr_reduce_desc* descs, int n_descs, void* stream) {
+  LASR_CHECK_ARG(descs && n_descs >= 1 && n_descs <= 64, "lasr_reduce_many: 1..64 segments");
+  lasr::ReduceMany a;
+  int64_t nmax = 0;
+  for (int i = 0; i < n_descs; ++i) {
+    LASR_CHECK_ARG(descs[i].partials && descs[i].out && descs[i].n > 0 && descs[i].n_partials > 0, "lasr_reduce_many: bad segment");
+    a.d[i] = descs[i];
+    nmax = std::max<int64_t>(nmax, descs[i].n);
+  }
+  hipLaunchKernelGGL(lasr::reduce_many_kernel, dim3((unsigned)cdiv(nmax, 256), (unsigned)n_descs), dim3(256), 0, as_stream(stream), a);
+  LASR_LAUNCH_CHECK("reduce_many_kernel");
+  return 0;
+}
 
 extern "C" size_t lasr_colsum_workspace_bytes(int64_t rows, int64_t C) {
   return (size_t)cdiv(rows, kColsumRows) * C * sizeof(float);
