@@ -740,6 +740,146 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(const T* __restric
   }
 }
 
+// ---- bf16 stride-1 depthwise WEIGHT gradient on the matrix cores ---------------------------------------
+// dW_c[j] = sum_b sum_t dY_c[b,t] * X_c[b, t + j - pad] is a correlation: per (channel, utterance) a matrix-VECTOR
+// product, and the obvious matrix forms need an operand that depends on both output indices.  Re-indexing does it:
+// with img[tau] = X[tau - P] (P = round-up-8(pad), sh = P - pad), j + sh = 16 n + m and u = t + m,
+//     dW'[16 n + m] = sum_u  dY[u - m] * img[u + 16 n]   =   (A B)[m][n],   A[m][u] = dY[u - m],  B[u][n] = img[u + 16 n]
+// A is a Toeplitz matrix of dY (no n), B a strided-window matrix of X (no m): one v_mfma_f32_16x16x32_bf16 per 32
+// values of u covers 16 x NC taps (NC = ceil((k+sh)/16) <= 7 of the 16 columns are used - still ~10x the MAC rate of
+// the VALU form, which ran at 68 % of its own bound).  Data movement as in the forward kernel: both tensors go
+// through the transposing LDS round trip into frame-contiguous images; B fragments are aligned 16-byte reads, A
+// fragments start at any element, so dY is kept twice (even / odd element alignment) and read as 4 dwords.
+// Workgroup = 64 channels x one utterance (u tiles of 288), 512 threads, wave = channel octet, accumulators live
+// across the tiles; the per-utterance partials are summed by the caller (lasr_reduce_many / reduce_partials).
+namespace dwg {
+static constexpr int TU = 288;                          // u values per tile: 9 MFMA K steps
+static constexpr int XF = TU + 16 * 7 + 8;              // 408 staged x frames  (lambda = u_local + 16 n)
+static constexpr int DF = TU + 16;                      // 304 staged dY frames (tau = u_local - m + 16)
+static constexpr int LDX = XF * 2;                      // 816 B
+static constexpr int LDD = DF * 2;                      // 608 B = 152 dwords
+static constexpr int X_OFF = 0, D0_OFF = kCB * LDX;     // 52 224
+static constexpr int D1_OFF = D0_OFF + kCB * LDD + 64;  // odd-alignment copy, 16 dwords further: its reads fall on the other banks
+static constexpr int ST_OFF = D1_OFF + kCB * LDD;
+static constexpr int SMEM = ST_OFF + dwm::STAGE_BYTES;  // 150 592
+static constexpr int XR = (XF + dwm::RS - 1) / dwm::RS, DR = (DF + dwm::RS - 1) / dwm::RS;   // 4 + 3 staging rounds
+}
+
+__global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                      float* __restrict__ partials, int Tlen, int C, int k) {
+  using namespace dwg;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* ximg = smem_raw + X_OFF;
+  char* d0 = smem_raw + D0_OFF;
+  char* d1 = smem_raw + D1_OFF;
+  char* stage = smem_raw + ST_OFF;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.x * kCB;
+  const int pad = k / 2, P = (pad + 7) & ~7, sh = P - pad;
+  const int n16 = lane & 15, g4 = lane >> 4;
+  const bf16_t* xb = x + (size_t)b * Tlen * C;
+  const bf16_t* db = dy + (size_t)b * Tlen * C;
+  typedef __attribute__((address_space(3))) dw_s16x4 lds_s4;
+
+  dw_f32x4 acc[8];
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) acc[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_tiles = (Tlen + 15 + TU) / TU;            // u runs over [0, T + 15]
+  for (int q = 0; q < n_tiles; ++q) {
+    // ---- phase 1: both tiles' loads first (branch-free), then round by round through the transposing staging
+    uint4 v[XR + DR][2];
+#pragma unroll
+    for (int r = 0; r < XR + DR; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int chk = tid + 512 * h;
+        const bool isx = r < XR;
+        const int fr = (isx ? r : r - XR) * dwm::RS + (chk >> 3);     // frame index inside the image
+        const int t = isx ? TU * q + fr - P : TU * q - 16 + fr;
+        const int cc = c0 + ((chk & 7) << 3);
+        const bool ok = fr < (isx ? XF : DF) && t >= 0 && t < Tlen && cc < C;
+        const bf16_t* src = isx ? xb : db;
+        const uint4 ld = *reinterpret_cast<const uint4*>(src + (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8));
+        const uint32_t mk = ok ? 0xffffffffu : 0u;
+        v[r][h] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < XR + DR; ++r) {
+      const bool isx = r < XR;
+      const int rr = isx ? r : r - XR;
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int chk = tid + 512 * h;
+        *reinterpret_cast<uint4*>(stage + (chk >> 3) * dwm::LDST + ((chk & 7) << 4)) = v[r][h];
+      }
+      __syncthreads();
+      char* img = isx ? ximg : d0;
+      const int ldi = isx ? LDX : LDD, nfr = isx ? XF : DF;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int blk = wid * 4 + it;                   // 32 blocks of 16 frames x 16 channels per round
+        const int fb = (blk >> 2) * 16 + g4 * 4, cg = blk & 3;
+        const int qq = n16 >> 2, pp = n16 & 3;
+        const dw_s16x4 d = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(stage + (fb + qq) * dwm::LDST + (cg * 16 + pp * 4) * 2));
+        const int fr = rr * dwm::RS + fb;
+        if (fr < nfr) *reinterpret_cast<dw_s16x4*>(img + (cg * 16 + n16) * ldi + fr * 2) = d;   // nfr is a multiple of 4
+      }
+    }
+    __syncthreads();
+    // odd-alignment copy of the dY image: dword d of d1 = elements (2d+1, 2d+2) of d0
+    for (int i = tid; i < kCB * (LDD / 4); i += 512) {
+      const int c = i / (LDD / 4), d = i - c * (LDD / 4);
+      const uint32_t lo = *reinterpret_cast<const uint32_t*>(d0 + c * LDD + d * 4);
+      const uint32_t hi = d + 1 < LDD / 4 ? *reinterpret_cast<const uint32_t*>(d0 + c * LDD + d * 4 + 4) : 0u;
+      *reinterpret_cast<uint32_t*>(d1 + c * LDD + d * 4) = (lo >> 16) | (hi << 16);
+    }
+    __syncthreads();
+
+    // ---- phase 2: 9 K steps per channel, 8 channels per wave
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const int cl = wid * 8 + ch;
+      // A[m][u] = dY[u - m]: element e = 32 ks + 8 g4 - m + 16 of the dY image (m = n16); its parity is the lane's
+      const int e0 = 8 * g4 - n16 + 16;
+      const uint32_t* arow = reinterpret_cast<const uint32_t*>(((e0 & 1) ? d1 : d0) + cl * LDD) + ((e0 - (e0 & 1)) >> 1);
+      const char* brow = ximg + cl * LDX + (16 * n16 + 8 * g4) * 2;
+#pragma unroll
+      for (int kb = 0; kb < TU / 32; kb += 3) {
+        uint32_t wa[3][4];
+        uint4 bb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wa[j][i] = arow[16 * (kb + j) + i];
+          bb[j] = *reinterpret_cast<const uint4*>(brow + 64 * (kb + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af.u[i] = wa[j][i];
+          bf.u[0] = bb[j].x; bf.u[1] = bb[j].y; bf.u[2] = bb[j].z; bf.u[3] = bb[j].w;
+          acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, acc[ch], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- D[m][n] = dW'[16 n + m]: lane (n = n16, rows 4 g4 + r) -> tap j = 16 n + 4 g4 + r - sh
+  float* out = partials + (size_t)b * C * k;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    const int c = c0 + wid * 8 + ch;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * n16 + 4 * g4 + r - sh;
+      if (c < C && j >= 0 && j < k) out[(size_t)c * k + j] = acc[ch][r];
+    }
+  }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -835,6 +975,19 @@ static int dwconv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype
                    "lasr_dwconv_wgrad: k=%d stride=%d C=%lld", k, stride, (long long)C);
   const int64_t Tout = conv_out_len(Tin, k, stride);
   if (workspace_bytes < lasr_dwconv_wgrad_workspace_bytes(B, Tout, C, k)) return fail(LASR_E_WORKSPACE, "lasr_dwconv_wgrad: workspace");
+  {
+    static const bool valu_form = getenv("LASR_DWWGRAD_VALU") != nullptr;   // A/B switch: the VALU form below
+    const int padk = k / 2, shk = ((padk + 7) & ~7) - padk;
+    if (!valu_form && stride == 1 && dtype == LASR_BF16 && C % 8 == 0 && k + shk <= 16 * 7 && Tin < (1 << 30)) {
+      float* parts = reinterpret_cast<float*>(workspace);   // [B][C*k]: one partial per utterance
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_s1_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(dwconv_wgrad_s1_mfma_kernel, dim3((unsigned)cdiv(C, kCB), (unsigned)B), dim3(512), dwg::SMEM, as_stream(stream),
+                         (const bf16_t*)x, (const bf16_t*)dy, parts, (int)Tin, (int)C, k);
+      LASR_LAUNCH_CHECK("dwconv_wgrad_s1_mfma_kernel");
+      if (n_partials_out) { *n_partials_out = (int)B; return 0; }
+      return launch_reduce_partials(parts, (int)B, C * k, dw, C * k, nullptr, as_stream(stream));
+    }
+  }
   const int n_chunks = (int)cdiv(Tout, stride == 1 ? kWChunk : kWChunkG);
   const int in_rows = (kWT - 1) * stride + k;
   const size_t shmem = ((size_t)in_rows + kWT) * kCB * sizeof(float);

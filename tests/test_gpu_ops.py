@@ -493,3 +493,21 @@ def test_gemm_ld_padded_narrow_operand(dev):
     # dW = gl^T h : A row-contiguous with 28 of 32 columns valid, split-K, f32 result
     dW = ops.gemm_ld(glp_d, 32, h_d, H, C, H, rows, transA=True, transB=True, split_k=16, out_dtype=torch.float32)
     assert torch.equal(dW.cpu(), gl.t() @ h)
+
+
+@pytest.mark.parametrize("C,k,T,B", [(512, 63, 501, 4), (256, 33, 501, 3), (336, 51, 77, 3), (512, 87, 130, 2), (64, 1, 40, 2),
+                                     (72, 5, 300, 2), (64, 75, 801, 2), (128, 101, 513, 2)])
+def test_dwconv_wgrad_bf16_mfma(dev, C, k, T, B):
+    """bf16 stride-1 depthwise weight gradient (Toeplitz / strided-window MFMA form; LASR_DWWGRAD_VALU=1 selects the
+    VALU form): bf16 operands, exact products, f32 accumulation over B*T terms, against an f64 correlation."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C + 7 * k + T)
+    x = torch.randn(B, T, C, generator=g).bfloat16()
+    dy = torch.randn(B, T, C, generator=g).bfloat16()
+    xd, dyd = x.double(), dy.double()
+    pad = k // 2
+    xp = torch.nn.functional.pad(xd, (0, 0, pad, pad))                       # (B, T + 2 pad, C)
+    ref = torch.stack([(dyd * xp[:, j:j + T, :]).sum(dim=(0, 1)) for j in range(k)], dim=1)   # (C, k)
+    got = ops.dwconv_wgrad(x.to(dev), dy.to(dev), k, 1)
+    scale = ref.abs().max()
+    assert (got.cpu().double() - ref).abs().max() < 2e-5 * scale + 1e-6
