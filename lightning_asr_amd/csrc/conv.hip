@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_s1_kernel(const T* __restric
 // values of u covers 16 x NC taps (NC = ceil((k+sh)/16) <= 7 of the 16 columns are used - still ~10x the MAC rate of
 // the VALU form, which ran at 68 % of its own bound).  Data movement as in the forward kernel: both tensors go
 // through the transposing LDS round trip into frame-contiguous images; B fragments are aligned 16-byte reads, A
-// fragments start at any element, so dY is kept twice (even / odd element alignment) and read as 4 dwords.
+// fragments start at any element: five dwords from the even position below and a 16-bit funnel shift for odd starts.
 // Workgroup = 64 channels x one utterance (u tiles of 288), 512 threads, wave = channel octet, accumulators live
 // across the tiles; the per-utterance partials are summed by the caller (lasr_reduce_many / reduce_partials).
 namespace dwg {
@@ -757,12 +757,12 @@ static constexpr int TU = 288;                          // u values per tile: 9 
 static constexpr int XF = TU + 16 * 7 + 8;              // 408 staged x frames  (lambda = u_local + 16 n)
 static constexpr int DF = TU + 16;                      // 304 staged dY frames (tau = u_local - m + 16)
 static constexpr int LDX = XF * 2;                      // 816 B
-static constexpr int LDD = DF * 2;                      // 608 B = 152 dwords
+static constexpr int LDD = DF * 2 + 16;                 // 624 B: 304 frames + one spare dword pair for the funnel shift
+static constexpr int RSG = 256;                         // frames per staging round (two rounds per image)
 static constexpr int X_OFF = 0, D0_OFF = kCB * LDX;     // 52 224
-static constexpr int D1_OFF = D0_OFF + kCB * LDD + 64;  // odd-alignment copy, 16 dwords further: its reads fall on the other banks
-static constexpr int ST_OFF = D1_OFF + kCB * LDD;
-static constexpr int SMEM = ST_OFF + dwm::STAGE_BYTES;  // 150 592
-static constexpr int XR = (XF + dwm::RS - 1) / dwm::RS, DR = (DF + dwm::RS - 1) / dwm::RS;   // 4 + 3 staging rounds
+static constexpr int ST_OFF = D0_OFF + kCB * LDD;       // 92 160
+static constexpr int SMEM = ST_OFF + RSG * dwm::LDST;   // 133 120
+static constexpr int XR = (XF + RSG - 1) / RSG, DR = (DF + RSG - 1) / RSG;   // 2 + 2 staging rounds
 }
 
 __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -771,7 +771,6 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* ximg = smem_raw + X_OFF;
   char* d0 = smem_raw + D0_OFF;
-  char* d1 = smem_raw + D1_OFF;
   char* stage = smem_raw + ST_OFF;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.y, c0 = blockIdx.x * kCB;
@@ -784,18 +783,21 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
   dw_f32x4 acc[8];
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) acc[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+  // the spare dwords behind frame 303 of every dY row read as zero
+  for (int i = tid; i < kCB * 4; i += 512) *reinterpret_cast<uint32_t*>(d0 + (i >> 2) * LDD + DF * 2 + (i & 3) * 4) = 0u;
 
   const int n_tiles = (Tlen + 15 + TU) / TU;            // u runs over [0, T + 15]
-  for (int q = 0; q < n_tiles; ++q) {
-    // ---- phase 1: both tiles' loads first (branch-free), then round by round through the transposing staging
-    uint4 v[XR + DR][2];
+  DW_STAMP(0);
+  // a tile's global loads (branch-free: clamped address, masked value); tile q+1's are issued before tile q's MFMAs
+  uint4 v[XR + DR][4];
+  auto issue_loads = [&](int q) {
 #pragma unroll
     for (int r = 0; r < XR + DR; ++r) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 4; ++h) {
         const int chk = tid + 512 * h;
         const bool isx = r < XR;
-        const int fr = (isx ? r : r - XR) * dwm::RS + (chk >> 3);     // frame index inside the image
+        const int fr = (isx ? r : r - XR) * RSG + (chk >> 3);         // frame index inside the image
         const int t = isx ? TU * q + fr - P : TU * q - 16 + fr;
         const int cc = c0 + ((chk & 7) << 3);
         const bool ok = fr < (isx ? XF : DF) && t >= 0 && t < Tlen && cc < C;
@@ -805,13 +807,17 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
         v[r][h] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
       }
     }
+  };
+  issue_loads(0);
+  for (int q = 0; q < n_tiles; ++q) {
+    // ---- phase 1: round by round through the transposing staging
 #pragma unroll
     for (int r = 0; r < XR + DR; ++r) {
       const bool isx = r < XR;
       const int rr = isx ? r : r - XR;
       __syncthreads();
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 4; ++h) {
         const int chk = tid + 512 * h;
         *reinterpret_cast<uint4*>(stage + (chk >> 3) * dwm::LDST + ((chk & 7) << 4)) = v[r][h];
       }
@@ -819,54 +825,52 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
       char* img = isx ? ximg : d0;
       const int ldi = isx ? LDX : LDD, nfr = isx ? XF : DF;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int blk = wid * 4 + it;                   // 32 blocks of 16 frames x 16 channels per round
+      for (int it = 0; it < 8; ++it) {
+        const int blk = wid * 8 + it;                   // 64 blocks of 16 frames x 16 channels per round
         const int fb = (blk >> 2) * 16 + g4 * 4, cg = blk & 3;
         const int qq = n16 >> 2, pp = n16 & 3;
         const dw_s16x4 d = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(stage + (fb + qq) * dwm::LDST + (cg * 16 + pp * 4) * 2));
-        const int fr = rr * dwm::RS + fb;
+        const int fr = rr * RSG + fb;
         if (fr < nfr) *reinterpret_cast<dw_s16x4*>(img + (cg * 16 + n16) * ldi + fr * 2) = d;   // nfr is a multiple of 4
       }
     }
     __syncthreads();
-    // odd-alignment copy of the dY image: dword d of d1 = elements (2d+1, 2d+2) of d0
-    for (int i = tid; i < kCB * (LDD / 4); i += 512) {
-      const int c = i / (LDD / 4), d = i - c * (LDD / 4);
-      const uint32_t lo = *reinterpret_cast<const uint32_t*>(d0 + c * LDD + d * 4);
-      const uint32_t hi = d + 1 < LDD / 4 ? *reinterpret_cast<const uint32_t*>(d0 + c * LDD + d * 4 + 4) : 0u;
-      *reinterpret_cast<uint32_t*>(d1 + c * LDD + d * 4) = (lo >> 16) | (hi << 16);
-    }
-    __syncthreads();
+    if (q == 0) DW_STAMP(1);
+    if (q + 1 < n_tiles) issue_loads(q + 1);
+    if (q == 0) DW_STAMP(2);
 
     // ---- phase 2: 9 K steps per channel, 8 channels per wave
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
       const int cl = wid * 8 + ch;
-      // A[m][u] = dY[u - m]: element e = 32 ks + 8 g4 - m + 16 of the dY image (m = n16); its parity is the lane's
+      // A[m][u] = dY[u - m]: elements e .. e+7 of the dY image, e = 32 ks + 8 g4 - m + 16 (m = n16).  e has the lane's
+      // parity: five dwords from floor(e/2) and a funnel shift by 16 bits for the odd lanes (v_alignbit, 0 for even)
       const int e0 = 8 * g4 - n16 + 16;
-      const uint32_t* arow = reinterpret_cast<const uint32_t*>(((e0 & 1) ? d1 : d0) + cl * LDD) + ((e0 - (e0 & 1)) >> 1);
+      const uint32_t shft = (e0 & 1) * 16;
+      const uint32_t* arow = reinterpret_cast<const uint32_t*>(d0 + cl * LDD) + (e0 >> 1);
       const char* brow = ximg + cl * LDX + (16 * n16 + 8 * g4) * 2;
 #pragma unroll
       for (int kb = 0; kb < TU / 32; kb += 3) {
-        uint32_t wa[3][4];
+        uint32_t wa[3][5];
         uint4 bb[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) wa[j][i] = arow[16 * (kb + j) + i];
+          for (int i = 0; i < 5; ++i) wa[j][i] = arow[16 * (kb + j) + i];
           bb[j] = *reinterpret_cast<const uint4*>(brow + 64 * (kb + j));
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af.u[i] = wa[j][i];
+          for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[j][i + 1], wa[j][i], shft);
           bf.u[0] = bb[j].x; bf.u[1] = bb[j].y; bf.u[2] = bb[j].z; bf.u[3] = bb[j].w;
           acc[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, acc[ch], 0, 0, 0);
         }
       }
     }
   }
+  DW_STAMP(3);
   // ---- D[m][n] = dW'[16 n + m]: lane (n = n16, rows 4 g4 + r) -> tap j = 16 n + 4 g4 + r - sh
   float* out = partials + (size_t)b * C * k;
 #pragma unroll
