@@ -128,6 +128,11 @@ int lasr_reduce_many(const lasr_reduce_desc* descs, int n_descs, void* stream);
 int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int transA, int transB,
                                    int split_k, void* workspace, size_t workspace_bytes, const float** partials,
                                    int* splits, void* stream);
+/* Up to 32 bf16 weight-gradient problems C_i[M_i][N_i] = A_i^T B_i (A_i is [K][M_i], B_i is [K][N_i]: transA = transB = 1)
+ * in ONE split-K launch; slabs[i] receives [splits[i]][M_i*N_i] f32 (splits[i] <= split_k), to be summed by
+ * lasr_reduce_many.  Batching a whole backward stage makes the K slices longer and the slabs smaller. */
+int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs,
+                                   int* splits, void* stream);
 int lasr_dwconv_wgrad_partials(const void* x, const void* dy, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
                                int stride, void* workspace, size_t workspace_bytes, int* n_partials, void* stream);
 

@@ -462,3 +462,37 @@ extern "C" int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, in
   for (int i = 0; i < n_probs; ++i) { partials[i] = so[i].partials; splits[i] = so[i].splits; }
   return 0;
 }
+
+extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs,
+                                              int* splits, void* stream) {
+  LASR_CHECK_ARG(probs && slabs && splits && n_probs >= 1 && n_probs <= 32 && split_k >= 1 && split_k <= 1024,
+                 "lasr_gemm_multi_split_partials: bad argument");
+  GemmArgs g[32];
+  int gz[32];
+  for (int i = 0; i < n_probs; ++i) {
+    const lasr_gemm_problem& q = probs[i];
+    LASR_CHECK_ARG(q.A && q.B && slabs[i], "lasr_gemm_multi_split_partials: null pointer");
+    LASR_CHECK_SHAPE(q.M > 0 && q.N > 0 && q.K > 0, "lasr_gemm_multi_split_partials: shape");
+    GemmArgs& a = g[i];
+    a.A = q.A; a.B = q.B; a.C = nullptr; a.M = q.M; a.N = q.N; a.K = q.K;
+    a.lda = q.M; a.ldb = q.N; a.ldc = q.N;                       // transA = transB = 1: A is [K][M], B is [K][N]
+    a.bias = nullptr; a.addend = nullptr; a.row_lens = nullptr; a.rows_per_seq = 0; a.stat_partials = nullptr;
+    a.split_ws = slabs[i];
+    a.vecA = (a.lda % 8 == 0) && (reinterpret_cast<uintptr_t>(q.A) % 16 == 0);
+    a.vecB = (a.ldb % 8 == 0) && (reinterpret_cast<uintptr_t>(q.B) % 16 == 0);
+    const int64_t per = cdiv(cdiv(q.K, split_k), 64) * 64;       // whole K tiles per slice
+    a.k_per_split = per;
+    gz[i] = (int)cdiv(q.K, per);
+    splits[i] = gz[i];
+  }
+  hipStream_t st = as_stream(stream);
+  double fl = 0, by = 0;
+  for (int i = 0; i < n_probs; ++i) {
+    fl += 2.0 * (double)probs[i].M * probs[i].N * probs[i].K;
+    by += (double)(probs[i].M * probs[i].K + probs[i].N * probs[i].K) * 2 + (double)probs[i].M * probs[i].N * 4;
+  }
+  const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
+  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, st);
+  prof_end(tok, st);
+  return rc;
+}

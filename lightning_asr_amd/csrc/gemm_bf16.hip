@@ -175,8 +175,9 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// one 128x128 output tile (tile `lid` of problem g); shared by the two-problem and the many-problem kernels
 template <typename TC, bool TRANS_A, bool TRANS_B, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
+__device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid) {
   __shared__ __attribute__((aligned(16))) char smem[2 * OPER_BYTES];
   __shared__ float s_stat[2][2][TN];
   __shared__ float s_keep[TM];
@@ -184,10 +185,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
   char* sB = smem + OPER_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int lid_all = xcd_remap(blockIdx.x, gb.total);
-  const bool second = lid_all >= gb.tiles0;              // workgroup-uniform
-  const Bf16Args& g = second ? gb.p[1] : gb.p[0];
-  const int lid = second ? lid_all - gb.tiles0 : lid_all;
   const int tn = lid % g.gn, tm = (lid / g.gn) % g.gm, tz = lid / (g.gn * g.gm);
   const int m0 = tm * TM, n0 = tn * TN;
   const int kbeg = tz * g.k_per_split;
@@ -345,6 +342,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
       }
     }
   }
+}
+
+template <typename TC, bool TRANS_A, bool TRANS_B, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
+  const int lid_all = xcd_remap(blockIdx.x, gb.total);
+  const bool second = lid_all >= gb.tiles0;              // workgroup-uniform
+  const Bf16Args& g = second ? gb.p[1] : gb.p[0];
+  gemm_bf16_tile<TC, TRANS_A, TRANS_B, VEC>(g, second ? lid_all - gb.tiles0 : lid_all);
+}
+
+// Up to 32 problems in one launch: the 1x1 weight gradients of a whole backward stage.  Per unit their split-K
+// launch is 16 K steps per workgroup between a prologue and a 32 MB partial-slab epilogue; batched, a stage needs
+// a third of the slices for the same number of workgroups, so slices are 3x longer and the slabs 3x smaller.
+static constexpr int kMaxMulti = 32;
+struct Bf16Multi { Bf16Args p[kMaxMulti]; int start[kMaxMulti + 1]; int n, total; };
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_multi_kernel(Bf16Multi gm) {
+  const int lid_all = xcd_remap(blockIdx.x, gm.total);
+  int i = 0;
+  while (i + 1 < gm.n && gm.start[i + 1] <= lid_all) ++i;   // workgroup-uniform scan of at most 32 entries
+  gemm_bf16_tile<float, true, true, VEC>(gm.p[i], lid_all - gm.start[i]);
 }
 
 // =====================================================================================================
@@ -626,6 +644,28 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
 #undef LASR_BF16_TC
 #undef LASR_BF16_CASE
   LASR_LAUNCH_CHECK("gemm_bf16_kernel");
+  return 0;
+}
+
+// n <= 32 split-K problems with f32 slab output, both operands row-contiguous ([K][M], [K][N]: weight gradients)
+int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, hipStream_t st) {
+  if (n < 1 || n > kMaxMulti) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: 1..%d problems", kMaxMulti);
+  Bf16Multi m;
+  bool vec = true;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!g[i].split_ws) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: every problem needs a slab buffer");
+    LASR_TRY(fill_args(m.p[i], g[i], TM, TN, gz[i]));
+    vec = vec && g[i].vecA && g[i].vecB;
+    m.start[i] = total;
+    total += m.p[i].gn * m.p[i].gm * m.p[i].gz;
+  }
+  for (int i = n; i < kMaxMulti; ++i) m.p[i] = m.p[0];
+  for (int i = n; i <= kMaxMulti; ++i) m.start[i] = total;
+  m.n = n; m.total = total;
+  if (vec) hipLaunchKernelGGL(gemm_bf16_multi_kernel<true>, dim3((unsigned)total), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL(gemm_bf16_multi_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, m);
+  LASR_LAUNCH_CHECK("gemm_bf16_multi_kernel");
   return 0;
 }
 

@@ -64,7 +64,7 @@ struct Unit {
   // workspace offsets (bytes) filled by plan()
   size_t o_u = 0, o_y = 0, o_y2 = 0, o_out = 0, o_coef = 0, o_saved = 0, o_coef2 = 0, o_saved2 = 0, o_stats = 0, o_stats2 = 0;
   size_t o_se_sum = 0, o_se_pool = 0, o_se_hid = 0, o_se_scale = 0, o_se_grad = 0;   // SE: [B][co] (hid: [B][co/8]) f32
-  size_t o_wgp = 0, wgp_bytes = 0, o_dwp = 0, dwp_bytes = 0;   // deferred reductions: split-K slabs of dW / dWr, depthwise-dW partials
+  size_t o_wgp = 0, wgp_bytes = 0, o_dwp = 0, dwp_bytes = 0, o_dy = 0, o_dy2 = 0;   // deferred reductions: split-K slabs of dW / dWr, depthwise-dW partials
 };
 
 // BiLSTM context branch (Context / ContextSE): parameter offsets per direction
@@ -241,6 +241,9 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
     if (u.has_res) {
       u.wgp_bytes = 2 * lasr_gemm_workspace_bytes(u.co, u.ci, wgrad_split(), 0);
       u.o_wgp = take(cur, u.wgp_bytes);
+      // the unit's dy / dy2 outlive its backward: their weight-gradient GEMMs run batched at the end of the stage
+      u.o_dy = take(cur, (size_t)N * u.co * es);
+      u.o_dy2 = take(cur, (size_t)N * u.co * es);
     }
     if (u.has_dw) {
       u.dwp_bytes = lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k);
@@ -413,6 +416,25 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
   return 0;
 }
 
+// The 1x1 weight gradients collected over a backward stage, as ONE split-K launch.  The slice count is chosen for
+// ~3 rounds of resident workgroups (512 at two per CU): a single unit needs 16 slices for that, a stage of 6-13 units
+// needs 2-6, so every workgroup runs 3-8x more K steps between its prologue and its slab write-out.
+static int flush_wgrads(std::vector<lasr_gemm_problem>& probs, std::vector<float*>& slabs, std::vector<lasr_reduce_desc>& pending,
+                        void* stream) {
+  int64_t tiles = 0;
+  for (const lasr_gemm_problem& q : probs) tiles += ((q.M + 127) / 128) * ((q.N + 127) / 128);
+  int split = (int)((1536 + tiles - 1) / tiles);
+  if (split < 1) split = 1;
+  if (split > wgrad_split()) split = wgrad_split();
+  int splits[32];
+  LASR_TRY(lasr_gemm_multi_split_partials(probs.data(), (int)probs.size(), split, slabs.data(), splits, stream));
+  for (size_t i = 0; i < probs.size(); ++i)
+    pending.push_back({slabs[i], reinterpret_cast<float*>(probs[i].C), probs[i].M * probs[i].N, splits[i]});
+  probs.clear();
+  slabs.clear();
+  return 0;
+}
+
 // backward from d(loss)/d(logits) already in the workspace (o_glogits)
 // unit_stop: the unit loop runs from the last unit down to `unit_stop` (0 = the whole model); a later
 // lasr_model_backward_continue call picks up at unit_stop-1.  with_head: run the decoder part first.
@@ -449,6 +471,8 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   static const bool no_defer = getenv("LASR_NO_DEFER") != nullptr;
   const bool defer = !no_fuse() && !no_defer;
   std::vector<lasr_reduce_desc> pending;
+  std::vector<lasr_gemm_problem> wprobs;
+  std::vector<float*> wslabs;
   for (int ui = unit_hi; ui >= unit_stop; --ui) {
     const Unit& u = m->units[ui];
     const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
@@ -456,8 +480,9 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     const int64_t Tx = ui > 0 ? T : T_in;
     const int act = u.act ? m->cfg.act : LASR_ACT_NONE;
     void* dout = at(ws, p.o_g[cur]);
-    void* dy = at(ws, p.o_d1);
-    void* dy2 = u.has_res ? at(ws, p.o_d2) : nullptr;
+    const bool defer_w = defer && u.has_res && dt == LASR_BF16;   // weight-gradient GEMMs batched per stage
+    void* dy = defer_w ? at(ws, u.o_dy) : at(ws, p.o_d1);
+    void* dy2 = u.has_res ? (defer_w ? at(ws, u.o_dy2) : at(ws, p.o_d2)) : nullptr;
     const float* se_scale = u.has_se ? atf(ws, u.o_se_scale) : nullptr;
     const float* se_grad = u.has_se ? atf(ws, u.o_se_grad) : nullptr;
     if (u.has_se)
@@ -483,12 +508,11 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       lasr_gemm_problem pr[2];
       pr[0] = {dy, gin, grads + u.w_pw, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
       if (u.has_res) pr[1] = {dy2, x_in, grads + u.w_res, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
-      if (defer && u.has_res && dt == LASR_BF16) {
-        const float* parts[2];
-        int splits[2];
-        LASR_TRY(lasr_gemm_batch_split_partials(pr, 2, dt, 1, 1, wgrad_split(), at(ws, u.o_wgp), u.wgp_bytes, parts, splits, stream));
-        pending.push_back({parts[0], grads + u.w_pw, u.co * (int64_t)u.ci, splits[0]});
-        pending.push_back({parts[1], grads + u.w_res, u.co * (int64_t)u.ci, splits[1]});
+      if (defer_w) {
+        float* slab = atf(ws, u.o_wgp);
+        wprobs.push_back(pr[0]); wslabs.push_back(slab);
+        wprobs.push_back(pr[1]); wslabs.push_back(slab + u.wgp_bytes / (2 * sizeof(float)));
+        if (wprobs.size() + 2 > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
       }
@@ -511,7 +535,11 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       } else {
         LASR_TRY(lasr_dwconv_wgrad(x_in, at(ws, p.o_du), grads + u.w_dw, dt, B, Tx, u.ci, u.k, u.stride, scratch, sb, stream));
       }
-      if (pending.size() > 60) { LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream)); pending.clear(); }
+      if (pending.size() + wprobs.size() > 60) {
+        if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
+        LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));
+        pending.clear();
+      }
       if (need_dx)
         LASR_TRY(lasr_dwconv_fwd(at(ws, p.o_du), params + u.w_dw, u.has_res ? at(ws, p.o_dxr) : nullptr, dx, dt, B, T, u.ci, u.k, 1,
                                  1, stream));
@@ -547,6 +575,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       cur ^= 1;
     }
   }
+  if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
   if (!pending.empty()) LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));   // the stage's gradients are final
   m->bwd_cur = cur;
   m->bwd_next = unit_stop - 1;
