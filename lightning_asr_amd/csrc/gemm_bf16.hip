@@ -11,6 +11,7 @@
 //                  transpose), so no operand is ever transposed through HBM or VALU.
 // bf16 results leave through an LDS transpose so every global store is 16 B per lane.
 #include "gemm.h"
+#include <algorithm>
 #include <stdlib.h>
 
 namespace lasr {
@@ -59,12 +60,12 @@ __device__ __forceinline__ uint4 mask_chunk(const uint4& v, int nvalid) {
   return make_uint4(v.x & dm(0), v.y & dm(1), v.z & dm(2), v.w & dm(3));
 }
 
-template <bool TRANS, int ROWS, int NT>
-__device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, uint4 (&reg)[4]) {
+template <bool TRANS, int ROWS, int NT, int NCH = 4>
+__device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, uint4 (&reg)[NCH]) {
   constexpr int RCH = ROWS / 8;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NCH; ++p) {
     const int c = tid + NT * p;
     uint32_t off;
     if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), ((kend + 7) & ~7) - 8);
@@ -73,12 +74,12 @@ __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, i
   }
 }
 
-template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_>
-__device__ __forceinline__ void store_vec(char* __restrict__ s, const uint4 (&reg)[4], int k0, int kend) {
+template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_, int NCH = 4>
+__device__ __forceinline__ void store_vec(char* __restrict__ s, const uint4 (&reg)[NCH], int k0, int kend) {
   constexpr int RCH = ROWS / 8;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NCH; ++p) {
     const int c = tid + NT * p;
     // elements past the K range become zero: whole k-rows of a row-contiguous operand, the tail elements of a
     // K-contiguous chunk (K need not be a multiple of 8; the pitch is, so the chunk itself is in bounds)
@@ -372,49 +373,66 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_multi_kernel(Bf16Multi gm) {
 // FLOP and reads 0.75 instead of 1 fragment per MFMA; a unit's main + residual problem (63 x 2 tiles
 // each at N=512) fill 252 of the 256 CUs in a single round.  bf16 results only.
 namespace big {
-static constexpr int BTM = 256, BTN = 256, NT = 512;
+static constexpr int BTM = 256, NT = 512;
 static constexpr int LDR = 576;               // [k][256 rows] image: 512 B + 64 B pad (bank residue 16 dwords, as LD_RC)
-static constexpr int OPER = 36864;            // 256*144 == 64*576
-static constexpr int BUF = 2 * OPER;          // A + B image of one K step
+static constexpr int OPER = 36864;            // A image: 256*144 == 64*576
+// Two tile widths.  WIDE: 256x256, 8 waves as 2 x 4, wave tile 128x64 (4 x 2 MFMA tiles).  NARROW: 256x128, 8 waves as
+// 4 x 2, wave tile 64x64 (2 x 2): for problems with N <= 256 (the 256-channel blocks), where 256-wide tiles would leave
+// half of the CUs without a workgroup (63 x 1 tiles per problem).
+template <bool NARROW>
+struct Cfg {
+  static constexpr int BN = NARROW ? 128 : 256;
+  static constexpr int WN = NARROW ? 2 : 4;             // waves along N (8 / WN along M)
+  static constexpr int MI = NARROW ? 2 : 4;             // 32-row MFMA tiles per wave
+  static constexpr int NCB = BN * 8 / NT;               // 16-byte B chunks per thread and K step: 2 / 4
+  static constexpr int LDRB = BN * 2 + 64;              // pitch of a row-contiguous B image: 320 / 576
+  static constexpr int OPER_B = (BN * LD_KC > 64 * LDRB) ? BN * LD_KC : 64 * LDRB;   // 20480 / 36864
+  static constexpr int BUF = OPER + OPER_B;             // A + B image of one K step
+  static constexpr int EPB = BN * 2 + 16;               // output image pitch: 272 / 528
+};
 }  // namespace big
 
 // One K step of the 256x256 tile: 4 groups of (6 fragment reads, 8 MFMAs); after group ks the thread moves
 // its chunk ks of the NEXT step from registers into the other LDS image and (re)issues the global load of
 // the step after that into the same registers, so LDS writes and VMEM issue ride in the MFMA shadows
 // instead of forming a separate all-waves staging phase in front of them.
-template <bool TRANS_A, bool TRANS_B, bool STORE, bool LOAD>
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD>
 __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char* __restrict__ sB, char* __restrict__ dA,
-                                         char* __restrict__ dB, f32x16 (&acc)[4][2], uint4 (&ra)[4], uint4 (&rb)[4],
-                                         const Bf16Args& g, int m0, int n0, int k_store, int k_load, int kend, int wm, int wn,
-                                         int lane) {
+                                         char* __restrict__ dB, f32x16 (&acc)[big::Cfg<NARROW>::MI][2], uint4 (&ra)[4],
+                                         uint4 (&rb)[big::Cfg<NARROW>::NCB], const Bf16Args& g, int m0, int n0, int k_store,
+                                         int k_load, int kend, int wm, int wn, int lane) {
   using namespace big;
+  using CF = Cfg<NARROW>;
+  constexpr int MI = CF::MI;
   // fragments of group ks+1 are requested before the MFMAs of group ks are issued (two register sets), so a
   // wave's MFMA stream does not stop for its own LDS latency; only the first group after the barrier waits
-  bf16x8 a[2][4], b[2][2];
+  bf16x8 a[2][MI], b[2][2];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) b[0][ni] = load_frag<TRANS_B, LDR>(sB, wn * 64 + ni * 32, 0, lane);
+  for (int ni = 0; ni < 2; ++ni) b[0][ni] = load_frag<TRANS_B, CF::LDRB>(sB, wn * 64 + ni * 32, 0, lane);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) a[0][mi] = load_frag<TRANS_A, LDR>(sA, wm * 128 + mi * 32, 0, lane);
+  for (int mi = 0; mi < MI; ++mi) a[0][mi] = load_frag<TRANS_A, LDR>(sA, wm * (32 * MI) + mi * 32, 0, lane);
 #pragma unroll
   for (int ks = 0; ks < TK / 16; ++ks) {
     const int cur = ks & 1, nxt = cur ^ 1;
     if (ks + 1 < TK / 16) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) b[nxt][ni] = load_frag<TRANS_B, LDR>(sB, wn * 64 + ni * 32, ks + 1, lane);
+      for (int ni = 0; ni < 2; ++ni) b[nxt][ni] = load_frag<TRANS_B, CF::LDRB>(sB, wn * 64 + ni * 32, ks + 1, lane);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) a[nxt][mi] = load_frag<TRANS_A, LDR>(sA, wm * 128 + mi * 32, ks + 1, lane);
+      for (int mi = 0; mi < MI; ++mi) a[nxt][mi] = load_frag<TRANS_A, LDR>(sA, wm * (32 * MI) + mi * 32, ks + 1, lane);
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
     if constexpr (STORE) {
       store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
-      store_chunk<TRANS_B, BTN, NT, LD_KC, LDR>(dB, rb[ks], k_store, kend, ks);
+      if constexpr (CF::NCB == 4) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks], k_store, kend, ks);
+      else if (ks < CF::NCB) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks < CF::NCB ? ks : 0], k_store, kend, ks);
     }
     if constexpr (LOAD) {
       ra[ks] = load_chunk<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, k_load, kend, ks);
-      rb[ks] = load_chunk<TRANS_B, BTN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
+      if constexpr (CF::NCB == 4) rb[ks] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
+      else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
     }
   }
 }
@@ -428,18 +446,20 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define LASR_STAMP(i_) do {} while (0)
 #endif
 
-template <bool TRANS_A, bool TRANS_B>
+template <bool TRANS_A, bool TRANS_B, bool NARROW>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
 #ifdef LASR_GEMM_STAMPS
   unsigned long long* stamps = g_stamps;
 #endif
   LASR_STAMP(0);
-  using big::BTM; using big::BTN; using big::NT; using big::LDR; using big::OPER; using big::BUF;
+  using big::BTM; using big::NT; using big::LDR; using big::OPER;
+  using CF = big::Cfg<NARROW>;
+  constexpr int BTN = CF::BN, BUF = CF::BUF, MI = CF::MI, WM = 8 / CF::WN;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  __shared__ float s_stat[2][2][BTN];
+  __shared__ float s_stat[WM][2][BTN];
   __shared__ float s_keep[BTM];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 2, wn = wid & 3;
+  const int wm = wid / CF::WN, wn = wid % CF::WN;
   const int lid_all = xcd_remap(blockIdx.x, gb.total);
   const bool second = lid_all >= gb.tiles0;
   const Bf16Args& g = second ? gb.p[1] : gb.p[0];
@@ -460,22 +480,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
     s_keep[tid] = keep ? 1.f : 0.f;
   }
 
-  f32x16 acc[4][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 ra[4], rb[4];
+  uint4 ra[4], rb[CF::NCB];
   load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
-  load_vec<TRANS_B, BTN, NT>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
+  load_vec<TRANS_B, BTN, NT, CF::NCB>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
   store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
-  store_vec<TRANS_B, BTN, NT, LD_KC, LDR>(smem + OPER, rb, kbeg, kend);
+  store_vec<TRANS_B, BTN, NT, LD_KC, CF::LDRB, CF::NCB>(smem + OPER, rb, kbeg, kend);
   if (nk > 1) {
     load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
-    load_vec<TRANS_B, BTN, NT>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
+    load_vec<TRANS_B, BTN, NT, CF::NCB>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
   }
   __syncthreads();
   LASR_STAMP(1);
@@ -485,20 +505,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
     for (; it + 2 < nk; ++it) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, true, true>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
+      big_step<TRANS_A, TRANS_B, NARROW, true, true>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
                                              kbeg + (it + 2) * TK, kend, wm, wn, lane);
       __syncthreads();
     }
     if (it + 1 < nk) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, true, false>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
+      big_step<TRANS_A, TRANS_B, NARROW, true, false>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
                                               wm, wn, lane);
       __syncthreads();
       ++it;
     }
     const char* sA = smem + (it & 1) * BUF;
-    big_step<TRANS_A, TRANS_B, false, false>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane);
+    big_step<TRANS_A, TRANS_B, NARROW, false, false>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane);
     __syncthreads();
   }
   LASR_STAMP(2);
@@ -508,7 +528,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   //      of the chip walk the rows in the same order, so the stores in flight form long runs (measured:
   //      8 rows x 128 B per instruction with per-wave images 7.5 us for a wave's first 8 stores, a per-wave
   //      rotated row order 13 us).
-  constexpr int EPB = 528;
+  constexpr int EPB = CF::EPB;
   const int half = lane >> 5, l31 = lane & 31;
   bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
   float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
@@ -518,10 +538,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   {
     char* img = smem + (wn * 64 + l31) * 2;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int lr = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int lr = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         const float kf = s_keep[lr];
         const bf16_t q0 = f32_to_bf16((acc[mi][0][r] + bv0) * kf);
         const bf16_t q1 = f32_to_bf16((acc[mi][1][r] + bv1) * kf);
@@ -547,14 +567,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   __syncthreads();
   LASR_STAMP(5);
   {
-    const int nst = n0 + l31 * 8;
+    // every wave stores 32 complete tile rows; a row is BTN*2 bytes = LPR lanes x 16 B, RPI rows per instruction
+    constexpr int LPR = BTN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+    const int lc = lane % LPR, lrow = lane / LPR;
+    const int nst = n0 + lc * 8;
     const bool full_n = g.vecC && nst + 7 < g.N;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int lr = wid * 32 + it * 2 + half;   // (orders that put a block's waves on adjacent rows at the same time measured 1.8x slower)
+    for (int it = 0; it < NIT; ++it) {
+      const int lr = wid * 32 + it * RPI + lrow;   // (orders that put a block's waves on adjacent rows at the same time measured 1.8x slower)
       const int m = m0 + lr;
       if (m < g.M && nst < g.N) {
-        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + l31 * 16);
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + lc * 16);
         bf16_t* dst = C + (uint32_t)m * (uint32_t)g.ldc + (uint32_t)nst;
         if (full_n) {
           *reinterpret_cast<uint4*>(dst) = v;
@@ -570,8 +593,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
     const int n = n0 + tid;
     if (n < g.N) {
       float* P = g.stat_partials + (size_t)tm * 2 * g.N;
-      P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
-      P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s0 += s_stat[w][0][tid]; s1 += s_stat[w][1][tid]; }
+      P[n] = s0;
+      P[g.N + n] = s1;
     }
   }
 #ifdef LASR_GEMM_STAMPS
@@ -603,12 +629,16 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
   const bool f32_out = dtype_c == LASR_F32 || g[0].split_ws != nullptr;   // split-K slabs are f32
   // The 256x256 tile pays when its (one per CU) workgroups cover most of the chip.
   static const int big_min = getenv("LASR_GEMM_BIG_MIN_TILES") ? atoi(getenv("LASR_GEMM_BIG_MIN_TILES")) : 120;
+  int64_t nmax = 0;
+  for (int i = 0; i < n; ++i) nmax = std::max<int64_t>(nmax, g[i].N);
+  const bool narrow = nmax <= 256;          // 256x128 tiles: two tile columns for the 256-channel layers
+  const int btn = narrow ? 128 : 256;
   int64_t big_tiles = 0;
-  for (int i = 0; i < n; ++i) big_tiles += cdiv(g[i].M, big::BTM) * cdiv(g[i].N, big::BTN) * gz[i];
+  for (int i = 0; i < n; ++i) big_tiles += cdiv(g[i].M, big::BTM) * cdiv(g[i].N, btn) * gz[i];
   bool vec = true;   // every operand aligned for 16-byte chunks (pitch % 8, base % 16): true for all model tensors
   for (int i = 0; i < n; ++i) vec = vec && g[i].vecA && g[i].vecB;
   const bool use_big = !f32_out && vec && big_tiles >= big_min;
-  const int tm = use_big ? big::BTM : TM, tn = use_big ? big::BTN : TN;
+  const int tm = use_big ? big::BTM : TM, tn = use_big ? btn : TN;
   Bf16Batch b;
   LASR_TRY(fill_args(b.p[0], g[0], tm, tn, gz[0]));
   b.p[1] = b.p[0];
@@ -619,7 +649,11 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
     for (int i = 0; i < n; ++i) stat_tiles[i] = b.p[i].gm;
   const dim3 grid1((unsigned)b.total);
   if (use_big) {
-#define LASR_BIG_CASE(TA_, TB_) hipLaunchKernelGGL((gemm_bf16_big_kernel<TA_, TB_>), grid1, dim3(big::NT), 0, st, b)
+#define LASR_BIG_CASE(TA_, TB_)                                                                              \
+  do {                                                                                                     \
+    if (narrow) hipLaunchKernelGGL((gemm_bf16_big_kernel<TA_, TB_, true>), grid1, dim3(big::NT), 0, st, b);  \
+    else hipLaunchKernelGGL((gemm_bf16_big_kernel<TA_, TB_, false>), grid1, dim3(big::NT), 0, st, b);        \
+  } while (0)
     if (!transA && !transB) LASR_BIG_CASE(false, false);
     else if (!transA && transB) LASR_BIG_CASE(false, true);
     else if (transA && !transB) LASR_BIG_CASE(true, false);
