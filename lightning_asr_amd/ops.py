@@ -132,6 +132,42 @@ def gemm_ld(A, lda, Bm, ldb, M, N, K, transA=False, transB=False, split_k: int =
     return Cm
 
 
+class _ReduceDesc(_lib.C.Structure):
+    _fields_ = [("partials", _lib.C.c_void_p), ("out", _lib.C.c_void_p), ("n", _lib.C.c_int64), ("n_partials", _lib.C.c_int32)]
+
+
+def reduce_many(segments):
+    """segments: list of (partials (P_i, n_i) f32, out (n_i,) f32): out_i = partials_i.sum(0), one launch (<= 64)."""
+    descs = (_ReduceDesc * len(segments))()
+    for i, (pt, out) in enumerate(segments):
+        descs[i].partials, descs[i].out, descs[i].n, descs[i].n_partials = _p(pt), _p(out), out.numel(), pt.shape[0]
+    call("lasr_reduce_many", descs, len(segments), _stream())
+
+
+def wgrad_multi(dys, xs, split_k: int = 4):
+    """The 1x1 weight gradients dW_i = dy_i^T x_i of several layers in ONE split-K launch + ONE reduction
+    (lasr_gemm_multi_split_partials + lasr_reduce_many).  dys[i] (rows, co_i), xs[i] (rows, ci_i) bf16."""
+    n = len(dys)
+    dev = dys[0].device
+    probs = (_GemmProblem * n)()
+    slabs = (_lib.C.c_void_p * n)()
+    splits = (_lib.C.c_int * n)()
+    outs, bufs = [], []
+    for i in range(n):
+        rows, co = dys[i].shape
+        ci = xs[i].shape[1]
+        out = torch.empty(co, ci, dtype=torch.float32, device=dev)
+        buf = torch.empty(split_k, co * ci, dtype=torch.float32, device=dev)
+        probs[i].A, probs[i].B, probs[i].C = _p(dys[i]), _p(xs[i]), _p(out)
+        probs[i].M, probs[i].N, probs[i].K = co, ci, rows
+        probs[i].bias = None; probs[i].row_lens = None; probs[i].rows_per_seq = 0; probs[i].stats = None
+        slabs[i] = _p(buf)
+        outs.append(out); bufs.append(buf)
+    call("lasr_gemm_multi_split_partials", probs, n, split_k, slabs, splits, _stream())
+    reduce_many([(bufs[i][:splits[i]], outs[i].view(-1)) for i in range(n)])
+    return outs
+
+
 def bn_finalize(stats, gamma, beta, running_mean, running_var, n_rows: int, eps: float = 1e-3, momentum: float = 0.1,
                 training: bool = True):
     Cc = gamma.numel()

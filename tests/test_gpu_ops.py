@@ -511,3 +511,32 @@ def test_dwconv_wgrad_bf16_mfma(dev, C, k, T, B):
     got = ops.dwconv_wgrad(x.to(dev), dy.to(dev), k, 1)
     scale = ref.abs().max()
     assert (got.cpu().double() - ref).abs().max() < 2e-5 * scale + 1e-6
+
+
+def test_reduce_many_segments(dev):
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(16, 512 * 512), (1, 7), (32, 512 * 75), (5, 1000), (64, 33)]
+    segs, refs = [], []
+    for (P, n) in shapes:
+        pt = torch.randn(P, n, generator=g)
+        segs.append((pt.to(dev), torch.empty(n, device=dev)))
+        refs.append(pt.double().sum(0))
+    ops.reduce_many(segs)
+    for (pt, out), ref in zip(segs, refs):
+        assert max_rel(out, ref) < 1e-6
+
+
+def test_wgrad_multi_exact_integers(dev):
+    """A backward stage's 1x1 weight gradients in one split-K launch: mixed shapes (256- and 512-wide, 256 -> 512),
+    small-integer operands so every product and partial sum is exact in f32, result compared bit for bit."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    rows = 16032
+    shapes = [(512, 512), (512, 512), (256, 256), (512, 256), (256, 256), (1024, 512), (160, 256)]
+    dys = [torch.randint(-2, 3, (rows, co), generator=g).float() for co, _ in shapes]
+    xs = [(torch.rand(rows, ci, generator=g) < 0.05).float() * torch.randint(-1, 2, (rows, ci), generator=g).float() for _, ci in shapes]
+    for split in (1, 3, 6):
+        outs = ops.wgrad_multi([d.bfloat16().to(dev) for d in dys], [x.bfloat16().to(dev) for x in xs], split_k=split)
+        for d, x, o in zip(dys, xs, outs):
+            assert torch.equal(o.cpu(), d.t() @ x)
