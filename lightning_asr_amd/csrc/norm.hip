@@ -198,6 +198,28 @@ __device__ __forceinline__ void lds_vec8(const float* p, float (&o)[4]) {
   o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
 }
 
+// LDS tables of per-channel constants, [q][C] f32.  A bf16 lane owns 8 consecutive channels = two float4: read
+// straight from a linear table the lanes' addresses are 32 B apart and every 16-byte read is a 2-way bank
+// conflict (measured: 42-47 % of the LDS cycles of these kernels).  So each table row is stored as two planes -
+// the low float4 of every channel octet, then the high float4 - and both reads are unit-stride.  (f32 lanes own
+// 4 channels: the linear layout is already unit-stride.)
+template <int V>
+__device__ __forceinline__ int tab_pos(int i, int C) {        // i: linear index (multiple of 4) into [q][C]
+  if (V == 4) return i;
+  const int q = i / C, r = i - q * C, j = r >> 2;
+  return q * C + ((j & 1) ? (C >> 1) : 0) + ((j >> 1) << 2);
+}
+__device__ __forceinline__ void tab_vec(const float* row, int c, int C, float (&o)[8]) {   // row = table + q*C
+  const float4 lo = *reinterpret_cast<const float4*>(row + (c >> 1));
+  const float4 hi = *reinterpret_cast<const float4*>(row + (C >> 1) + (c >> 1));
+  o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w; o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+}
+__device__ __forceinline__ void tab_vec(const float* row, int c, int C, float (&o)[4]) {
+  (void)C;
+  const float4 lo = *reinterpret_cast<const float4*>(row + c);
+  o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
+}
+
 // out = act((a*y + b)*se + a2*y2 + b2);  s_tab = [a | b | a2 | b2][C].  Two items per thread in flight, no branch
 // around a load (HAS2 is a template parameter, the second item's index is clamped and only its store predicated).
 template <typename T, bool HAS2>
@@ -208,8 +230,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   extern __shared__ __attribute__((aligned(16))) float s_tab[];
   constexpr int V = Vec<T>::kN;
   for (int i = threadIdx.x * 4; i < 2 * C; i += 1024) {
-    *reinterpret_cast<float4*>(s_tab + i) = *reinterpret_cast<const float4*>(coef + i);
-    *reinterpret_cast<float4*>(s_tab + 2 * C + i) = HAS2 ? *reinterpret_cast<const float4*>(coef2 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int d = tab_pos<V>(i, C);
+    *reinterpret_cast<float4*>(s_tab + d) = *reinterpret_cast<const float4*>(coef + i);
+    *reinterpret_cast<float4*>(s_tab + 2 * C + d) = HAS2 ? *reinterpret_cast<const float4*>(coef2 + i) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   const int cv = C / V;
@@ -233,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       const int c = cc[u];
       float v[V], w[V], a[V], b[V], o[V];
       Vec<T>::unpack(rv[u], v);
-      lds_vec8(s_tab + c, a); lds_vec8(s_tab + C + c, b);
+      tab_vec(s_tab, c, C, a); tab_vec(s_tab + C, c, C, b);
       const float* sp = se ? se + (uint32_t)(rr[u] / Tt) * (uint32_t)C + (uint32_t)c : nullptr;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
@@ -242,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       }
       if (HAS2) {
         Vec<T>::unpack(rw[u], w);
-        lds_vec8(s_tab + 2 * C + c, a); lds_vec8(s_tab + 3 * C + c, b);
+        tab_vec(s_tab + 2 * C, c, C, a); tab_vec(s_tab + 3 * C, c, C, b);
 #pragma unroll
         for (int j = 0; j < V; ++j) o[j] += fmaf(w[j], a[j], b[j]);
       }
@@ -414,7 +437,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dy2, int rows, int Tt, int C, int act) {
   extern __shared__ __attribute__((aligned(16))) float s_tab[];  // [10][C]
   constexpr int V = Vec<T>::kN;
-  for (int i = threadIdx.x * 4; i < 10 * C; i += 1024) *reinterpret_cast<float4*>(s_tab + i) = *reinterpret_cast<const float4*>(tab + i);
+  for (int i = threadIdx.x * 4; i < 10 * C; i += 1024) *reinterpret_cast<float4*>(s_tab + tab_pos<V>(i, C)) = *reinterpret_cast<const float4*>(tab + i);
   __syncthreads();
   const int cv = C / V;
   const int r0 = blockIdx.x * kSlabRows;
@@ -446,19 +469,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
       const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
       float a1[V], b1[V], G[V], Bc[V], Cc[V];
-      lds_vec8(s_tab + c, a1); lds_vec8(s_tab + C + c, b1);
+      tab_vec(s_tab, c, C, a1); tab_vec(s_tab + C, c, C, b1);
       float z[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (sp ? sp[j] : 1.f);
       if (HAS2) {
-        lds_vec8(s_tab + 5 * C + c, a1); lds_vec8(s_tab + 6 * C + c, b1);
+        tab_vec(s_tab + 5 * C, c, C, a1); tab_vec(s_tab + 6 * C, c, C, b1);
 #pragma unroll
         for (int j = 0; j < V; ++j) z[j] += fmaf(rv[j], a1[j], b1[j]);
       }
       float d[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
-      lds_vec8(s_tab + 2 * C + c, G); lds_vec8(s_tab + 3 * C + c, Bc); lds_vec8(s_tab + 4 * C + c, Cc);
+      tab_vec(s_tab + 2 * C, c, C, G); tab_vec(s_tab + 3 * C, c, C, Bc); tab_vec(s_tab + 4 * C, c, C, Cc);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         const float d1 = fmaf(d[j], sp ? sp[j] : 1.f, gp ? gp[j] : 0.f);
@@ -466,7 +489,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       }
       if (live) Vec<T>::store(dy + off[u], o1);
       if (HAS2) {
-        lds_vec8(s_tab + 7 * C + c, G); lds_vec8(s_tab + 8 * C + c, Bc); lds_vec8(s_tab + 9 * C + c, Cc);
+        tab_vec(s_tab + 7 * C, c, C, G); tab_vec(s_tab + 8 * C, c, C, Bc); tab_vec(s_tab + 9 * C, c, C, Cc);
 #pragma unroll
         for (int j = 0; j < V; ++j) o2[j] = fmaf(G[j], d[j], fmaf(Bc[j], rv[j], Cc[j]));
         if (live) Vec<T>::store(dy2 + off[u], o2);
