@@ -599,24 +599,35 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
         }
       }
       __syncthreads();
+      // the four chunks of the thread: the addend loads first (branch-free: clamped offsets, a dummy source when
+      // there is no addend), then the arithmetic and the predicated stores
+      const bf16_t* addp = addend ? addend : y;           // never used for its value when addend is null
+      uint4 ra[4];
+      size_t offs[4];
+      bool okc[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int ci = tid + 512 * it;                // chunk: frame ci >> 3 of the set, octet ci & 7
         const int fl = ci >> 3, oc = ci & 7;
-        const int prow = (fl & 15) * 16 + (fl >> 4);
         const int t = tA + ns * 256 + fl, cc = c0 + oc * 8;
-        if (t < Tlen && cc < C) {
-          const size_t off = ((size_t)b * Tlen + t) * C + cc;
-          if (!addend) {
-            *reinterpret_cast<uint4*>(y + off) = *reinterpret_cast<const uint4*>(img + prow * LDO + oc * 16);
-          } else {
-            const float4 lo = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32);
-            const float4 hi = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32 + 16);
-            float a8[8];
-            Vec<bf16_t>::load(addend + off, a8);
-            float o[8] = {lo.x + a8[0], lo.y + a8[1], lo.z + a8[2], lo.w + a8[3], hi.x + a8[4], hi.y + a8[5], hi.z + a8[6], hi.w + a8[7]};
-            Vec<bf16_t>::store(y + off, o);
-          }
+        okc[it] = t < Tlen && cc < C;
+        offs[it] = ((size_t)b * Tlen + min(t, Tlen - 1)) * C + min(cc, C - 8);
+        ra[it] = Vec<bf16_t>::raw(addp + offs[it]);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int ci = tid + 512 * it;
+        const int fl = ci >> 3, oc = ci & 7;
+        const int prow = (fl & 15) * 16 + (fl >> 4);
+        if (!addend) {
+          if (okc[it]) *reinterpret_cast<uint4*>(y + offs[it]) = *reinterpret_cast<const uint4*>(img + prow * LDO + oc * 16);
+        } else {
+          const float4 lo = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32);
+          const float4 hi = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32 + 16);
+          float a8[8];
+          Vec<bf16_t>::unpack(ra[it], a8);
+          float o[8] = {lo.x + a8[0], lo.y + a8[1], lo.z + a8[2], lo.w + a8[3], hi.x + a8[4], hi.y + a8[5], hi.z + a8[6], hi.w + a8[7]};
+          if (okc[it]) Vec<bf16_t>::store(y + offs[it], o);
         }
       }
     }
