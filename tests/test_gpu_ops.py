@@ -540,3 +540,28 @@ def test_wgrad_multi_exact_integers(dev):
         outs = ops.wgrad_multi([d.bfloat16().to(dev) for d in dys], [x.bfloat16().to(dev) for x in xs], split_k=split)
         for d, x, o in zip(dys, xs, outs):
             assert torch.equal(o.cpu(), d.t() @ x)
+
+
+def test_gemm_bf16_random_shapes_exact(dev):
+    """Seeded sweep over ragged shapes and all four operand layouts: small tiles, 256x256 and 256x128 one-per-CU tiles,
+    aligned (16-byte) and unaligned pitches, K tails that are not multiples of 8 or 64.  Small-integer operands make
+    every product and partial sum exact, so bf16 results (|value| <= 256) must match bit for bit."""
+    from lightning_asr_amd import ops
+    rng = np.random.default_rng(2024)
+    g = torch.Generator().manual_seed(2024)
+    for case in range(28):
+        big = case % 2 == 0
+        M = int(rng.integers(15000, 40000)) if big else int(rng.integers(1, 3000))
+        N = int(rng.integers(1, 80)) * 8 if case % 4 != 3 else int(rng.integers(1, 600))
+        K = int(rng.integers(1, 90)) * 8 if case % 4 != 1 else int(rng.integers(1, 700))
+        tA, tB = bool(case & 1), bool(case & 2)
+        if big:
+            tA = False                      # an [K][M] operand with M ~ 30 000 rows is not a shape of this model; keep the sweep fast
+        A = torch.randint(-2, 3, (K, M) if tA else (M, K), generator=g).float()
+        Bm = (torch.rand((K, N) if tB else (N, K), generator=g) < 0.06).float()
+        ref = (A.t() if tA else A) @ (Bm if tB else Bm.t())
+        assert ref.abs().max() <= 256
+        got, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, tA, tB)
+        assert torch.equal(got.cpu().float(), ref), (case, M, N, K, tA, tB)
+        got32, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, tA, tB, out_dtype=torch.float32, split_k=3)
+        assert torch.equal(got32.cpu(), ref), (case, M, N, K, tA, tB, "f32 split")
