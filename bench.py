@@ -67,8 +67,8 @@ def cpu_baseline(n_clips: int = 4, steps: int = 2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # >= 10 warm-up, >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default=os.environ.get("LASR_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
                     help="activation dtype: bf16 (BASELINE config) or f32 (exact parity mode)")
     ap.add_argument("--batch", type=int, default=32)
