@@ -456,7 +456,9 @@ __device__ unsigned long long* g_dw_stamps = nullptr;   // debug builds only (to
 #else
 #define DW_STAMP(i_) do {} while (0)
 #endif
-template <int NKS>
+// NSET: 256-frame MFMA sets per time tile (2: one workgroup per 64 channels x 512 frames; 1: half tiles, twice the
+// workgroups - for layers whose C/64 x B grid would leave CUs idle); gridDim.z workgroups share an utterance's tiles.
+template <int NKS, int NSET>
 __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                 const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
                                                                 int Tlen, int C, int k, int flip) {
@@ -495,11 +497,12 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
   const int n16 = lane & 15, g4 = lane >> 4;          // MFMA lane coordinates
 
   DW_STAMP(0);
-  for (int tA = 0; tA < Tlen; tA += TT) {
-    const int tin = TT - 16 + KW;                     // staged frames: t = tA - P + tau, tau in [0, tin)
+  constexpr int TTS = 256 * NSET;                     // output frames per time tile
+  for (int tA = blockIdx.z * TTS; tA < Tlen; tA += TTS * gridDim.z) {
+    const int tin = TTS - 16 + KW;                     // staged frames: t = tA - P + tau, tau in [0, tin)
     // ---- phase 1: HBM -> staging ([frame][channel]) -> transposed image ([channel][frame]) ------------------
     // all global loads of the tile first (two 16-byte chunks per thread and round), then round by round
-    constexpr int kRounds = (TIN + RS - 1) / RS;      // 5
+    constexpr int kRounds = (TTS - 16 + KWMAX + RS - 1) / RS;      // 5 (3 for half tiles)
     uint4 v[kRounds][2];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
@@ -543,12 +546,12 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
     DW_STAMP(1);
 
     // ---- phase 2: one channel octet per wave, 8 channels x 2 MFMA sets x 4 frames per lane --------------------
-    dw_f32x4 acc[8][2];
+    dw_f32x4 acc[8][NSET];
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
       const int cl = wid * 8 + ch;
-      acc[ch][0] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[ch][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ns = 0; ns < NSET; ++ns) acc[ch][ns] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
       const char* row = img + cl * LDI;
       // A[m][kap] = W[kap - m - sh + 24]: lane (m = n16, K group g4) needs W[s0 + 32*ks .. +7], s0 = 8*g4 - m - sh + 24:
       // 4 dwords of the channel's even- or odd-start table.  Every LDS read of the channel is issued up front.
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) wa[ks][i] = wrow[16 * ks + i];
         b0[ks] = *reinterpret_cast<const uint4*>(row + (16 * n16 + 32 * ks + 8 * g4) * 2);
-        b1[ks] = *reinterpret_cast<const uint4*>(row + (256 + 16 * n16 + 32 * ks + 8 * g4) * 2);
+        if (NSET > 1) b1[ks] = *reinterpret_cast<const uint4*>(row + (256 + 16 * n16 + 32 * ks + 8 * g4) * 2);
       }
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -569,9 +572,11 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) af.u[i] = wa[ks][i];
         bf0.u[0] = b0[ks].x; bf0.u[1] = b0[ks].y; bf0.u[2] = b0[ks].z; bf0.u[3] = b0[ks].w;
-        bf1.u[0] = b1[ks].x; bf1.u[1] = b1[ks].y; bf1.u[2] = b1[ks].z; bf1.u[3] = b1[ks].w;
         acc[ch][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf0.v, acc[ch][0], 0, 0, 0);
-        acc[ch][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf1.v, acc[ch][1], 0, 0, 0);
+        if (NSET > 1) {
+          bf1.u[0] = b1[ks].x; bf1.u[1] = b1[ks].y; bf1.u[2] = b1[ks].z; bf1.u[3] = b1[ks].w;
+          acc[ch][NSET - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf1.v, acc[ch][NSET - 1], 0, 0, 0);
+        }
       }
     }
     DW_STAMP(2);
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
     // One 256-frame MFMA set at a time (the f32 form of a half tile, kept for the addend sum, fills the image space).
     constexpr int LDO = 144, LDOF = 272;              // row pitch: bf16 (36 dwords) / f32 (68 dwords), both = 4 mod 32
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
+    for (int ns = 0; ns < NSET; ++ns) {
       __syncthreads();                                // every wave is done with what the space held before
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -819,8 +824,10 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
       }
     }
   };
-  issue_loads(0);
-  for (int q = 0; q < n_tiles; ++q) {
+  // gridDim.z workgroups share an utterance's tiles (narrow layers: C/64 x B alone would leave CUs idle)
+  const int zq = blockIdx.z, zn = gridDim.z;
+  issue_loads(zq);
+  for (int q = zq; q < n_tiles; q += zn) {
     // ---- phase 1: round by round through the transposing staging
 #pragma unroll
     for (int r = 0; r < XR + DR; ++r) {
@@ -846,9 +853,9 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
       }
     }
     __syncthreads();
-    if (q == 0) DW_STAMP(1);
-    if (q + 1 < n_tiles) issue_loads(q + 1);
-    if (q == 0) DW_STAMP(2);
+    if (q == zq) DW_STAMP(1);
+    if (q + zn < n_tiles) issue_loads(q + zn);
+    if (q == zq) DW_STAMP(2);
 
     // ---- phase 2: 9 K steps per channel, 8 channels per wave
 #pragma unroll
@@ -883,7 +890,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
   }
   DW_STAMP(3);
   // ---- D[m][n] = dW'[16 n + m]: lane (n = n16, rows 4 g4 + r) -> tap j = 16 n + 4 g4 + r - sh
-  float* out = partials + (size_t)b * C * k;
+  float* out = partials + ((size_t)b * zn + zq) * C * k;
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) {
     const int c = c0 + wid * 8 + ch;
@@ -930,15 +937,21 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
       const int padk = k / 2, shk = ((padk + 7) & ~7) - padk;
       if (!fma_form && !dot2_form && C % 8 == 0 && 15 + k + shk <= dwm::KWMAX && Tin < (1 << 30)) {
         const int nks = (15 + k + shk + 31) / 32;
-        const dim3 gridm((unsigned)cdiv(C, kCB), (unsigned)B);
-#define LASR_DWM(N_)                                                                                                         \
+        // one workgroup per (64 channels, utterance) and 512-frame tile fills the chip from C = 512 on (B = 32);
+        // narrower layers take 256-frame half tiles spread over gridDim.z
+        static const bool no_half = getenv("LASR_DWCONV_NO_HALF") != nullptr;
+        const bool half = !no_half && Tin > 256 && cdiv(C, kCB) * B * cdiv(Tin, (int64_t)512) < 200;
+        const dim3 gridm((unsigned)cdiv(C, kCB), (unsigned)B, half ? (unsigned)std::min<int64_t>(cdiv(Tin, (int64_t)256), 8) : 1u);
+#define LASR_DWM2(N_, S_)                                                                                                    \
   do {                                                                                                                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_mfma_kernel<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL(dwconv_s1_mfma_kernel<N_>, gridm, dim3(512), dwm::SMEM, as_stream(stream), (const bf16_t*)x, w,        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_mfma_kernel<N_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((dwconv_s1_mfma_kernel<N_, S_>), gridm, dim3(512), dwm::SMEM, as_stream(stream), (const bf16_t*)x, w,  \
                        (const bf16_t*)addend, (bf16_t*)y, (int)Tin, (int)C, k, flip);                                        \
   } while (0)
+#define LASR_DWM(N_) do { if (half) LASR_DWM2(N_, 1); else LASR_DWM2(N_, 2); } while (0)
         if (nks == 1) LASR_DWM(1); else if (nks == 2) LASR_DWM(2); else if (nks == 3) LASR_DWM(3); else LASR_DWM(4);
 #undef LASR_DWM
+#undef LASR_DWM2
       } else if (fma_form) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(dwconv_s1_kernel<bf16_t>, grid, dim3(256), sh1, as_stream(stream), (const bf16_t*)x, w,
@@ -994,13 +1007,18 @@ static int dwconv_wgrad_impl(const void* x, const void* dy, float* dw, int dtype
     static const bool valu_form = getenv("LASR_DWWGRAD_VALU") != nullptr;   // A/B switch: the VALU form below
     const int padk = k / 2, shk = ((padk + 7) & ~7) - padk;
     if (!valu_form && stride == 1 && dtype == LASR_BF16 && C % 8 == 0 && k + shk <= 16 * 7 && Tin < (1 << 30)) {
-      float* parts = reinterpret_cast<float*>(workspace);   // [B][C*k]: one partial per utterance
+      float* parts = reinterpret_cast<float*>(workspace);   // [B * zsplit][C*k]: zsplit partials per utterance
+      // one workgroup per (64 channels, utterance) fills the chip from C = 512 on; narrower layers split the time tiles
+      const int n_tiles = (int)((Tin + 15 + dwg::TU) / dwg::TU);
+      static const int zmax = getenv("LASR_DWWGRAD_ZSPLIT") ? atoi(getenv("LASR_DWWGRAD_ZSPLIT")) : 2;
+      int zsplit = 1;
+      while (zsplit < zmax && zsplit * 2 <= n_tiles && cdiv(C, kCB) * B * zsplit < 200) zsplit *= 2;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_wgrad_s1_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(dwconv_wgrad_s1_mfma_kernel, dim3((unsigned)cdiv(C, kCB), (unsigned)B), dim3(512), dwg::SMEM, as_stream(stream),
-                         (const bf16_t*)x, (const bf16_t*)dy, parts, (int)Tin, (int)C, k);
+      hipLaunchKernelGGL(dwconv_wgrad_s1_mfma_kernel, dim3((unsigned)cdiv(C, kCB), (unsigned)B, (unsigned)zsplit), dim3(512), dwg::SMEM,
+                         as_stream(stream), (const bf16_t*)x, (const bf16_t*)dy, parts, (int)Tin, (int)C, k);
       LASR_LAUNCH_CHECK("dwconv_wgrad_s1_mfma_kernel");
-      if (n_partials_out) { *n_partials_out = (int)B; return 0; }
-      return launch_reduce_partials(parts, (int)B, C * k, dw, C * k, nullptr, as_stream(stream));
+      if (n_partials_out) { *n_partials_out = (int)B * zsplit; return 0; }
+      return launch_reduce_partials(parts, (int)B * zsplit, C * k, dw, C * k, nullptr, as_stream(stream));
     }
   }
   const int n_chunks = (int)cdiv(Tout, stride == 1 ? kWChunk : kWChunkG);

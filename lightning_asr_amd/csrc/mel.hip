@@ -18,6 +18,7 @@ static constexpr int kWinOff = (kNfft - kWin) / 2;  // 96
 static constexpr int kFramesPerBlock = 16;
 static constexpr int kWaves = 4;
 static constexpr int kSigLen = kFramesPerBlock * kHop + kNfft;   // 3072 samples staged per block
+static constexpr int kMaxBins = 24;   // widest triangular filter of the 64-band HTK bank over 257 bins is 20 bins (checked at init)
 
 struct MelTables {
   double window[kWin];
@@ -61,6 +62,8 @@ static int init_tables() {
         }
       }
     }
+    for (int m = 0; m < kMel; ++m)
+      if (t->hi[m] - t->lo[m] + 1 > kMaxBins) rc = fail(LASR_E_SHAPE, "mel filter %d spans %d bins (> %d)", m, t->hi[m] - t->lo[m] + 1, kMaxBins);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_mel), t, sizeof(MelTables));
     delete t;
     if (e != hipSuccess) rc = hip_fail(e, "mel table upload");
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   __shared__ double s_twr[kNfft];
   __shared__ double s_twi[kNfft];
   __shared__ double s_red[kWaves][2];
+  __shared__ double s_win[kWin];
   __shared__ float s_sig[kSigLen];
 
   const int b = blockIdx.y;
@@ -123,6 +127,17 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   const float* y = wave + (int64_t)b * L;
   const float* nz = dither ? dither + (int64_t)b * L : nullptr;
   for (int i = threadIdx.x; i < kNfft; i += 256) { s_twr[i] = g_mel.tw_re[i]; s_twi[i] = g_mel.tw_im[i]; }
+  for (int i = threadIdx.x; i < kWin; i += 256) s_win[i] = g_mel.window[i];
+  // this lane's mel filter (lane = mel channel): its <= kMaxBins weights live in registers for all of the block's
+  // frames.  (Fetching them inside the per-frame loop, behind its data-dependent bounds, was a chain of
+  // dependent global loads per frame.)
+  const int fb_lo = g_mel.lo[lane], fb_hi = g_mel.hi[lane];
+  float fbw[kMaxBins];
+#pragma unroll
+  for (int k = 0; k < kMaxBins; ++k) {
+    const float w = g_mel.fb[min(fb_lo + k, kFreq - 1) * kMel + lane];
+    fbw[k] = (fb_lo + k <= fb_hi) ? w : 0.f;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     frames_out[b] = (int32_t)Tb;
     pct_out[b] = (float)Tb / (float)T;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
       const int n = lane + 64 * r;
       const bool inw = live && n >= kWinOff && n < kWinOff + kWin;
       const int fl = it * kWaves + wid;                       // frame within the block
-      const double x = inw ? (double)s_sig[fl * kHop + n] * g_mel.window[min(max(n - kWinOff, 0), kWin - 1)] : 0.0;
+      const double x = inw ? (double)s_sig[fl * kHop + n] * s_win[min(max(n - kWinOff, 0), kWin - 1)] : 0.0;
       v[r] = {x, 0.0};
     }
     fft8(v);
@@ -226,8 +241,8 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
     float db = 0.f;
     if (live) {
       double m = 0.0;
-      const int lo = g_mel.lo[lane], hi = g_mel.hi[lane];
-      for (int k = lo; k <= hi; ++k) m = fma(sre[k], (double)g_mel.fb[k * kMel + lane], m);
+#pragma unroll
+      for (int k = 0; k < kMaxBins; ++k) m = fma(sre[min(fb_lo + k, kFreq - 1)], (double)fbw[k], m);   // ascending bins, zero weights past hi
       db = (float)(10.0 * log10(fmax(m, 1e-10)));
       if (aug && ((lane >= rx && lane < rx + wx) || (f >= ry && f < ry + wy))) db = 0.f;
       acc_s += (double)db;
