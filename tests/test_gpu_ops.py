@@ -565,3 +565,24 @@ def test_gemm_bf16_random_shapes_exact(dev):
         assert torch.equal(got.cpu().float(), ref), (case, M, N, K, tA, tB)
         got32, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, tA, tB, out_dtype=torch.float32, split_k=3)
         assert torch.equal(got32.cpu(), ref), (case, M, N, K, tA, tB, "f32 split")
+
+
+@pytest.mark.parametrize("C,k,T,B", [(512, 75, 501, 32), (64, 33, 2300, 2)])
+def test_dwconv_bf16_mfma_tile_forms(dev, C, k, T, B):
+    """The two time-tile forms of the stride-1 MFMA kernels: (512, 32 utterances) fills the chip with one 512-frame
+    tile per workgroup and no time split of the weight gradient (the bench shape); (64, T = 2300) runs 256-frame half
+    tiles with more tiles than gridDim.z, so workgroups loop over strided tiles."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C + k + T)
+    x = torch.randn(B, C, T, generator=g).bfloat16()
+    w = torch.randn(C, 1, k, generator=g) / math.sqrt(k)
+    wq = w.bfloat16().double()
+    ref = F.conv1d(x.double(), wq, None, 1, k // 2, 1, C)
+    xg = x.transpose(1, 2).contiguous().to(dev)
+    got = ops.dwconv(xg, w.to(dev))
+    assert max_rel(got.double().cpu().transpose(1, 2), ref) < 4e-3
+    dy = torch.randn(B, T, C, generator=g).bfloat16()
+    xp = torch.nn.functional.pad(x.double().transpose(1, 2), (0, 0, k // 2, k // 2))
+    dref = torch.stack([(dy.double() * xp[:, j:j + T, :]).sum(dim=(0, 1)) for j in range(k)], dim=1)
+    dw = ops.dwconv_wgrad(xg, dy.to(dev), k, 1)
+    assert (dw.cpu().double() - dref).abs().max() < 2e-5 * dref.abs().max() + 1e-6
