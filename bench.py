@@ -43,7 +43,7 @@ def synth_batch(B: int, n_samples: int, S: int, seed: int, device):
     return wave.to(device), tg.long().to(device), torch.full((B,), S, dtype=torch.int32, device=device)
 
 
-def cpu_baseline(n_clips: int = 4, steps: int = 2):
+def cpu_baseline(n_clips: int = 8, steps: int = 3):
     """The CPU oracle (oracle/ref_cpu.py, a port of the reference's path) timed on this box's host
     cores on a bounded sample of the same workload: n_clips x 10 s clips, features precomputed,
     fwd + CTC + bwd + NovoGrad."""

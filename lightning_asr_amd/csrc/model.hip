@@ -238,12 +238,12 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   p.o_glogits = take(cur, (size_t)N * C * sizeof(float));
   p.o_nll = take(cur, (size_t)(B + 1) * sizeof(float));
   for (Unit& u : m->units) {   // slabs that outlive `scratch`: summed by one lasr_reduce_many per backward stage
-    if (u.has_res) {
-      u.wgp_bytes = 2 * lasr_gemm_workspace_bytes(u.co, u.ci, wgrad_split(), 0);
+    {
+      u.wgp_bytes = (u.has_res ? 2 : 1) * lasr_gemm_workspace_bytes(u.co, u.ci, wgrad_split(), 0);
       u.o_wgp = take(cur, u.wgp_bytes);
       // the unit's dy / dy2 outlive its backward: their weight-gradient GEMMs run batched at the end of the stage
       u.o_dy = take(cur, (size_t)N * u.co * es);
-      u.o_dy2 = take(cur, (size_t)N * u.co * es);
+      if (u.has_res) u.o_dy2 = take(cur, (size_t)N * u.co * es);
     }
     if (u.has_dw) {
       u.dwp_bytes = lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k);
@@ -480,7 +480,8 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     const int64_t Tx = ui > 0 ? T : T_in;
     const int act = u.act ? m->cfg.act : LASR_ACT_NONE;
     void* dout = at(ws, p.o_g[cur]);
-    const bool defer_w = defer && u.has_res && dt == LASR_BF16;   // weight-gradient GEMMs batched per stage
+    // weight-gradient GEMMs batched per stage (the multi-problem kernel loads 16-byte operand rows)
+    const bool defer_w = defer && dt == LASR_BF16 && u.co % 8 == 0 && u.ci % 8 == 0;
     void* dy = defer_w ? at(ws, u.o_dy) : at(ws, p.o_d1);
     void* dy2 = u.has_res ? (defer_w ? at(ws, u.o_dy2) : at(ws, p.o_d2)) : nullptr;
     const float* se_scale = u.has_se ? atf(ws, u.o_se_scale) : nullptr;
@@ -511,7 +512,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       if (defer_w) {
         float* slab = atf(ws, u.o_wgp);
         wprobs.push_back(pr[0]); wslabs.push_back(slab);
-        wprobs.push_back(pr[1]); wslabs.push_back(slab + u.wgp_bytes / (2 * sizeof(float)));
+        if (u.has_res) { wprobs.push_back(pr[1]); wslabs.push_back(slab + u.wgp_bytes / (2 * sizeof(float))); }
         if (wprobs.size() + 2 > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
