@@ -423,7 +423,10 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][mi], b[cur][ni], acc[mi][ni], 0, 0, 0);
+      // operands swapped: D = B_tile * A_tile^T, i.e. the tile TRANSPOSED in the accumulators - lane (l31, half) holds output
+      // row l31 and, per register quad, 4 CONSECUTIVE output columns 8*(r>>2) + 4*half + (r&3): the epilogue packs them into
+      // 8-byte row-major LDS writes (the natural order left 2-byte writes: 128 ds_write_b16 per lane, 9 us per launch)
+      for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cur][ni], a[cur][mi], acc[mi][ni], 0, 0, 0);
     if constexpr (STORE) {
       store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
       if constexpr (CF::NCB == 4) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks], k_store, kend, ks);
@@ -435,6 +438,22 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
       else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
     }
   }
+}
+
+// two f32 -> one dword of two bf16 (RNE): a single v_cvt_pk_bf16_f32
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const pk_f32x2 f = {lo, hi};
+  const pk_bf16x2 h = __builtin_convertvector(f, pk_bf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+// N edge / unaligned C: element stores of the first n (1..8) values of v.  Out of line: the aligned path is the product path.
+__device__ __noinline__ void store_bf16_tail(bf16_t* dst, uint4 v, int n) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < n) dst[i] = (bf16_t)(w[i >> 1] >> (16 * (i & 1)));
 }
 
 #ifdef LASR_GEMM_STAMPS
@@ -454,9 +473,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   LASR_STAMP(0);
   using big::BTM; using big::NT; using big::LDR; using big::OPER;
   using CF = big::Cfg<NARROW>;
-  constexpr int BTN = CF::BN, BUF = CF::BUF, MI = CF::MI, WM = 8 / CF::WN;
+  constexpr int BTN = CF::BN, BUF = CF::BUF, MI = CF::MI;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  __shared__ float s_stat[WM][2][BTN];
   __shared__ float s_keep[BTM];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / CF::WN, wn = wid % CF::WN;
@@ -522,82 +540,111 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
     __syncthreads();
   }
   LASR_STAMP(2);
-  // ---- epilogue: bias, row mask, bf16 rounding, BN column sums.  The whole 256x256 bf16 tile is laid out
-  //      in LDS (528-byte rows: 132 KB of the operand images, free after the last barrier), then every
-  //      wave stores 32 complete tile rows: one instruction = 2 rows x 512 contiguous bytes, and the waves
-  //      of the chip walk the rows in the same order, so the stores in flight form long runs (measured:
-  //      8 rows x 128 B per instruction with per-wave images 7.5 us for a wave's first 8 stores, a per-wave
-  //      rotated row order 13 us).
+  // ---- epilogue: bias, row mask, bf16 rounding, BN column sums.  The whole tile is laid out row-major in LDS as
+  //      bf16 (528 / 272-byte rows over the operand images, free after the last barrier): a lane owns output row l31
+  //      of each of its MFMA tiles and 4 consecutive columns per register quad -> one packed conversion per pair and
+  //      one 8-byte LDS write per quad (conflict-free: pitch = 4 dwords mod 32).  Then every wave reads 32 complete
+  //      tile rows back as 16-byte vectors, adds them into its column sums (the statistics are of the values as
+  //      stored) and stores them: one instruction = 2 rows x 512 contiguous bytes.
+  //      (Measured on the 16 032 x 512 x 512 launch: K loop done at 16.8 us; the epilogue cost 21 us with per-element
+  //      conversion, statistics and 2-byte LDS writes in the natural accumulator order, of which the global stores
+  //      themselves were 1 us.)
   constexpr int EPB = CF::EPB;
   const int half = lane >> 5, l31 = lane & 31;
   bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
-  float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
   const int nb = n0 + wn * 64;
-  const float bv0 = (g.bias && nb + l31 < g.N) ? g.bias[nb + l31] : 0.f;
-  const float bv1 = (g.bias && nb + 32 + l31 < g.N) ? g.bias[nb + 32 + l31] : 0.f;
   {
-    char* img = smem + (wn * 64 + l31) * 2;
+    char* img = smem + (wm * (32 * MI) + l31) * EPB + (wn * 64 + 4 * half) * 2;
+    const bool has_bias = g.bias != nullptr;               // workgroup-uniform
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+      const uint32_t km = s_keep[wm * (32 * MI) + mi * 32 + l31] != 0.f ? 0xffffffffu : 0u;   // MaskCNN / M edge: the row is stored as zeros
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float kf = s_keep[lr];
-        const bf16_t q0 = f32_to_bf16((acc[mi][0][r] + bv0) * kf);
-        const bf16_t q1 = f32_to_bf16((acc[mi][1][r] + bv1) * kf);
-        const float v0 = bf16_to_f32(q0), v1 = bf16_to_f32(q1);   // statistics of the values as stored
-        csum[0] += v0; csq[0] = fmaf(v0, v0, csq[0]);
-        csum[1] += v1; csq[1] = fmaf(v1, v1, csq[1]);
-        *reinterpret_cast<bf16_t*>(img + lr * EPB) = q0;
-        *reinterpret_cast<bf16_t*>(img + lr * EPB + 64) = q1;
-      }
-    }
-  }
-  if (g.stat_partials) {
+      for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      csum[ni] += __shfl_xor(csum[ni], 32, 64);
-      csq[ni] += __shfl_xor(csq[ni], 32, 64);
-      if (half == 0) {
-        s_stat[wm][0][wn * 64 + ni * 32 + l31] = csum[ni];
-        s_stat[wm][1][wn * 64 + ni * 32 + l31] = csq[ni];
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+          if (has_bias) {
+            const int col = nb + ni * 32 + 8 * j + 4 * half;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (col + e < g.N) ? g.bias[min(col + e, g.N - 1)] : 0.f;
+          }
+          uint2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]) & km;
+          pk.y = pack_bf16x2(v[2], v[3]) & km;
+          *reinterpret_cast<uint2*>(img + mi * 32 * EPB + (ni * 32 + 8 * j) * 2) = pk;
+        }
       }
     }
   }
   __syncthreads();
   LASR_STAMP(5);
-  {
-    // every wave stores 32 complete tile rows; a row is BTN*2 bytes = LPR lanes x 16 B, RPI rows per instruction
-    constexpr int LPR = BTN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
-    const int lc = lane % LPR, lrow = lane / LPR;
-    const int nst = n0 + lc * 8;
-    const bool full_n = g.vecC && nst + 7 < g.N;
+  // every wave stores 32 complete tile rows; a row is BTN*2 bytes = LPR lanes x 16 B, RPI rows per instruction
+  constexpr int LPR = BTN / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+  const int lc = lane % LPR, lrow = lane / LPR;
+  const int nst = n0 + lc * 8;
+  const bool full_n = g.vecC && nst + 7 < g.N;
+  const bool want_stats = g.stat_partials != nullptr;      // workgroup-uniform
+  float cs[8], cq[8];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int lr = wid * 32 + it * RPI + lrow;   // (orders that put a block's waves on adjacent rows at the same time measured 1.8x slower)
-      const int m = m0 + lr;
-      if (m < g.M && nst < g.N) {
-        const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + lc * 16);
-        bf16_t* dst = C + (uint32_t)m * (uint32_t)g.ldc + (uint32_t)nst;
-        if (full_n) {
-          *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-          const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-          for (int i = 0; i < 8 && nst + i < g.N; ++i) dst[i] = e[i];
-        }
+  for (int i = 0; i < 8; ++i) { cs[i] = 0.f; cq[i] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int lr = wid * 32 + it * RPI + lrow;   // (orders that put a block's waves on adjacent rows at the same time measured 1.8x slower)
+    const int m = m0 + lr;
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + lc * 16);
+    if (want_stats) {                            // rows past M / past the utterance hold zeros
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+        cs[2 * i] += x0; cq[2 * i] = fmaf(x0, x0, cq[2 * i]);
+        cs[2 * i + 1] += x1; cq[2 * i + 1] = fmaf(x1, x1, cq[2 * i + 1]);
+      }
+    }
+    if (m < g.M && nst < g.N) {
+      bf16_t* dst = C + (uint32_t)m * (uint32_t)g.ldc + (uint32_t)nst;
+      if (full_n) {
+        *reinterpret_cast<uint4*>(dst) = v;
+      } else {
+        store_bf16_tail(dst, v, min(g.N - nst, 8));
       }
     }
   }
   LASR_STAMP(3);
-  if (g.stat_partials && tid < BTN) {
-    const int n = n0 + tid;
-    if (n < g.N) {
-      float* P = g.stat_partials + (size_t)tm * 2 * g.N;
-      float s0 = 0.f, s1 = 0.f;
+  if (want_stats) {
+    // lanes with the same lc hold the same 8 columns (rows lrow, lrow + RPI, ...): fold them, then one row of partial sums
+    // per wave into LDS (the image is dead once every wave is through its rows) and a fixed-order sum over the 8 waves
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { s0 += s_stat[w][0][tid]; s1 += s_stat[w][1][tid]; }
-      P[n] = s0;
-      P[g.N + n] = s1;
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int d = LPR; d < 64; d <<= 1) {
+        cs[i] += __shfl_xor(cs[i], d, 64);
+        cq[i] += __shfl_xor(cq[i], d, 64);
+      }
+    }
+    __syncthreads();
+    float* s_part = reinterpret_cast<float*>(smem);        // [8 waves][2][BTN]
+    if (lrow == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s_part[(wid * 2 + 0) * BTN + lc * 8 + i] = cs[i];
+        s_part[(wid * 2 + 1) * BTN + lc * 8 + i] = cq[i];
+      }
+    }
+    __syncthreads();
+    if (tid < BTN) {
+      const int n = n0 + tid;
+      if (n < g.N) {
+        float* P = g.stat_partials + (size_t)tm * 2 * g.N;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { s0 += s_part[(w * 2 + 0) * BTN + tid]; s1 += s_part[(w * 2 + 1) * BTN + tid]; }
+        P[n] = s0;
+        P[g.N + n] = s1;
+      }
     }
   }
 #ifdef LASR_GEMM_STAMPS
