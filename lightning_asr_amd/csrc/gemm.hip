@@ -9,6 +9,8 @@
 // floats per half-wave (conflict-free ds_read_b32) whatever the global layout was.
 #include "common.h"
 #include "gemm.h"
+#include <cmath>
+#include <climits>
 #include <stdlib.h>
 
 namespace lasr {
@@ -469,10 +471,33 @@ extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, in
                  "lasr_gemm_multi_split_partials: bad argument");
   GemmArgs g[32];
   int gz[32];
+  // Tile form and slice count for the whole launch (split_k is the cap the slabs were sized for).
+  //  * 256 x 256 tiles, one workgroup per CU: as many slices as keep the launch to one round of workgroups;
+  //  * 128 x 128 tiles, two workgroups per CU: ~3 rounds of resident workgroups (1536 tile-slices).
+  bool vec = true;
+  int64_t tiles_big = 0, tiles_small = 0, kmin = INT64_MAX;
   for (int i = 0; i < n_probs; ++i) {
     const lasr_gemm_problem& q = probs[i];
     LASR_CHECK_ARG(q.A && q.B && slabs[i], "lasr_gemm_multi_split_partials: null pointer");
     LASR_CHECK_SHAPE(q.M > 0 && q.N > 0 && q.K > 0, "lasr_gemm_multi_split_partials: shape");
+    vec = vec && q.M % 8 == 0 && q.N % 8 == 0 && reinterpret_cast<uintptr_t>(q.A) % 16 == 0 && reinterpret_cast<uintptr_t>(q.B) % 16 == 0;
+    tiles_big += cdiv(q.M, 256) * cdiv(q.N, 256);
+    tiles_small += cdiv(q.M, 128) * cdiv(q.N, 128);
+    kmin = std::min<int64_t>(kmin, q.K);
+  }
+  static const bool small_only = getenv("LASR_WGRAD_SMALL_TILE") != nullptr;   // A/B switch
+  const bool big_tile = !small_only && vec && kmin >= 1024;
+  int split = 1;
+  if (big_tile) {
+    // one round of workgroups, as many CUs as the slice count reaches (measured on the 71-tile stage of the plain model:
+    // 3 slices / 213 workgroups 175 us, 5 / 355 180 us, 7 / 497 194 us, 10 / 710 198 us: a second round costs its
+    // prologue and another 256 KB slab per tile)
+    split = (int)std::min<int64_t>(std::max<int64_t>(256 / std::max<int64_t>(tiles_big, 1), 1), std::min(split_k, 16));
+  } else {
+    split = (int)std::min<int64_t>(std::max<int64_t>(cdiv(1536, tiles_small), 1), split_k);
+  }
+  for (int i = 0; i < n_probs; ++i) {
+    const lasr_gemm_problem& q = probs[i];
     GemmArgs& a = g[i];
     a.A = q.A; a.B = q.B; a.C = nullptr; a.M = q.M; a.N = q.N; a.K = q.K;
     a.lda = q.M; a.ldb = q.N; a.ldc = q.N;                       // transA = transB = 1: A is [K][M], B is [K][N]
@@ -480,7 +505,7 @@ extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, in
     a.split_ws = slabs[i];
     a.vecA = (a.lda % 8 == 0) && (reinterpret_cast<uintptr_t>(q.A) % 16 == 0);
     a.vecB = (a.ldb % 8 == 0) && (reinterpret_cast<uintptr_t>(q.B) % 16 == 0);
-    const int64_t per = cdiv(cdiv(q.K, split_k), 64) * 64;       // whole K tiles per slice
+    const int64_t per = cdiv(cdiv(q.K, split), 64) * 64;         // whole K tiles per slice
     a.k_per_split = per;
     gz[i] = (int)cdiv(q.K, per);
     splits[i] = gz[i];
@@ -492,7 +517,7 @@ extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, in
     by += (double)(probs[i].M * probs[i].K + probs[i].N * probs[i].K) * 2 + (double)probs[i].M * probs[i].N * 4;
   }
   const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
-  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, st);
+  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st);
   prof_end(tok, st);
   return rc;
 }

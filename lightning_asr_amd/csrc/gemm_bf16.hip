@@ -465,8 +465,10 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define LASR_STAMP(i_) do {} while (0)
 #endif
 
-template <bool TRANS_A, bool TRANS_B, bool NARROW>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
+// one 256 x 256 (256 x 128) output tile `lid` of problem g; SLAB: split-K slice into the f32 slab g.split_ws (no LDS image,
+// no statistics) - shared by the two-problem kernel and the many-problem weight-gradient kernel
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB>
+__device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int lid) {
 #ifdef LASR_GEMM_STAMPS
   unsigned long long* stamps = g_stamps;
 #endif
@@ -478,10 +480,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   __shared__ float s_keep[BTM];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / CF::WN, wn = wid % CF::WN;
-  const int lid_all = xcd_remap(blockIdx.x, gb.total);
-  const bool second = lid_all >= gb.tiles0;
-  const Bf16Args& g = second ? gb.p[1] : gb.p[0];
-  const int lid = second ? lid_all - gb.tiles0 : lid_all;
   const int tn = lid % g.gn, tm = (lid / g.gn) % g.gm, tz = lid / (g.gn * g.gm);
   const int m0 = tm * BTM, n0 = tn * BTN;
   const int kbeg = tz * g.k_per_split;
@@ -551,8 +549,36 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   //      themselves were 1 us.)
   constexpr int EPB = CF::EPB;
   const int half = lane >> 5, l31 = lane & 31;
-  bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
   const int nb = n0 + wn * 64;
+  if constexpr (SLAB) {
+    // split-K slice: f32 straight from the accumulators, 16 bytes (4 consecutive columns) per lane and quad; a 128-byte
+    // line of the slab is completed by four instructions of the same wave (L2 merges them; the slab is written once)
+    float* W = g.split_ws + (size_t)tz * (size_t)g.M * (size_t)g.N;
+    const bool vec4 = (g.N & 3) == 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (32 * MI) + mi * 32 + l31;
+      if (m < g.M) {
+        float* wrow = W + (size_t)m * (size_t)g.N;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = nb + ni * 32 + 8 * j + 4 * half;
+            if (vec4 && n + 3 < g.N) {
+              *reinterpret_cast<float4*>(wrow + n) = make_float4(acc[mi][ni][4 * j], acc[mi][ni][4 * j + 1], acc[mi][ni][4 * j + 2], acc[mi][ni][4 * j + 3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) wrow[n + e] = acc[mi][ni][4 * j + e];
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  bf16_t* C = reinterpret_cast<bf16_t*>(g.C);
   {
     char* img = smem + (wm * (32 * MI) + l31) * EPB + (wn * 64 + 4 * half) * 2;
     const bool has_bias = g.bias != nullptr;               // workgroup-uniform
@@ -653,6 +679,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
 #endif
 }
 
+template <bool TRANS_A, bool TRANS_B, bool NARROW>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
+  const int lid_all = xcd_remap(blockIdx.x, gb.total);
+  const bool second = lid_all >= gb.tiles0;
+  const Bf16Args& g = second ? gb.p[1] : gb.p[0];
+  gemm_bf16_big_tile<TRANS_A, TRANS_B, NARROW, false>(g, second ? lid_all - gb.tiles0 : lid_all);
+}
+
+// The stage-batched 1x1 weight gradients on the 256 x 256 tile: C_i = A_i^T B_i with A_i [K][M_i], B_i [K][N_i]
+// (K = B*T' = 16 032 rows of dy and of the layer input), split-K slices into f32 slabs.  One workgroup per CU and
+// slice; the K loop of this tile runs at ~1.3 PFLOP/s against ~0.7 for the 128 x 128 form.
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi gm) {
+  const int lid_all = xcd_remap(blockIdx.x, gm.total);
+  int i = 0;
+  while (i + 1 < gm.n && gm.start[i + 1] <= lid_all) ++i;   // workgroup-uniform scan of at most 32 entries
+  gemm_bf16_big_tile<true, true, false, true>(gm.p[i], lid_all - gm.start[i]);
+}
+
 static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
   const int64_t lim = (int64_t)1 << 31;
   const int64_t gn = cdiv(g.N, tn), gm = cdiv(g.M, tm);
@@ -729,14 +773,14 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
 }
 
 // n <= 32 split-K problems with f32 slab output, both operands row-contiguous ([K][M], [K][N]: weight gradients)
-int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, hipStream_t st) {
+int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st) {
   if (n < 1 || n > kMaxMulti) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: 1..%d problems", kMaxMulti);
   Bf16Multi m;
   bool vec = true;
   int total = 0;
   for (int i = 0; i < n; ++i) {
     if (!g[i].split_ws) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: every problem needs a slab buffer");
-    LASR_TRY(fill_args(m.p[i], g[i], TM, TN, gz[i]));
+    LASR_TRY(fill_args(m.p[i], g[i], big_tile ? big::BTM : TM, big_tile ? 256 : TN, gz[i]));
     vec = vec && g[i].vecA && g[i].vecB;
     m.start[i] = total;
     total += m.p[i].gn * m.p[i].gm * m.p[i].gz;
@@ -744,6 +788,12 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, hipStream_t 
   for (int i = n; i < kMaxMulti; ++i) m.p[i] = m.p[0];
   for (int i = n; i <= kMaxMulti; ++i) m.start[i] = total;
   m.n = n; m.total = total;
+  if (big_tile) {
+    if (!vec) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: the 256-row tile needs 16-byte aligned operand rows");
+    hipLaunchKernelGGL(gemm_bf16_big_multi_kernel, dim3((unsigned)total), dim3(big::NT), 0, st, m);
+    LASR_LAUNCH_CHECK("gemm_bf16_big_multi_kernel");
+    return 0;
+  }
   if (vec) hipLaunchKernelGGL(gemm_bf16_multi_kernel<true>, dim3((unsigned)total), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(gemm_bf16_multi_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, m);
   LASR_LAUNCH_CHECK("gemm_bf16_multi_kernel");

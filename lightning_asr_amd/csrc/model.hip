@@ -421,11 +421,7 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
 // needs 2-6, so every workgroup runs 3-8x more K steps between its prologue and its slab write-out.
 static int flush_wgrads(std::vector<lasr_gemm_problem>& probs, std::vector<float*>& slabs, std::vector<lasr_reduce_desc>& pending,
                         void* stream) {
-  int64_t tiles = 0;
-  for (const lasr_gemm_problem& q : probs) tiles += ((q.M + 127) / 128) * ((q.N + 127) / 128);
-  int split = (int)((1536 + tiles - 1) / tiles);
-  if (split < 1) split = 1;
-  if (split > wgrad_split()) split = wgrad_split();
+  const int split = wgrad_split();   // the cap the slabs were sized for; the library picks the slice count for its tile form
   int splits[32];
   LASR_TRY(lasr_gemm_multi_split_partials(probs.data(), (int)probs.size(), split, slabs.data(), splits, stream));
   for (size_t i = 0; i < probs.size(); ++i)

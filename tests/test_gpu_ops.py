@@ -533,10 +533,10 @@ def test_wgrad_multi_exact_integers(dev):
     from lightning_asr_amd import ops
     g = torch.Generator().manual_seed(9)
     rows = 16032
-    shapes = [(512, 512), (512, 512), (256, 256), (512, 256), (256, 256), (1024, 512), (160, 256)]
+    shapes = [(512, 512), (512, 512), (256, 256), (512, 256), (256, 256), (1024, 512), (160, 256), (256, 64), (512, 336), (264, 520)]
     dys = [torch.randint(-2, 3, (rows, co), generator=g).float() for co, _ in shapes]
     xs = [(torch.rand(rows, ci, generator=g) < 0.05).float() * torch.randint(-1, 2, (rows, ci), generator=g).float() for _, ci in shapes]
-    for split in (1, 3, 6):
+    for split in (1, 3, 6, 16):    # the cap; the library picks the slice count for its tile form (256 x 256 here)
         outs = ops.wgrad_multi([d.bfloat16().to(dev) for d in dys], [x.bfloat16().to(dev) for x in xs], split_k=split)
         for d, x, o in zip(dys, xs, outs):
             assert torch.equal(o.cpu(), d.t() @ x)
