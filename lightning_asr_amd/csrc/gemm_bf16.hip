@@ -176,6 +176,22 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
 }
 
+// two f32 -> one dword of two bf16 (RNE): a single v_cvt_pk_bf16_f32
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const pk_f32x2 f = {lo, hi};
+  const pk_bf16x2 h = __builtin_convertvector(f, pk_bf16x2);
+  return __builtin_bit_cast(uint32_t, h);
+}
+// N edge / unaligned C: element stores of the first n (1..8) values of v.  Out of line: the aligned path is the product path.
+__device__ __noinline__ void store_bf16_tail(bf16_t* dst, uint4 v, int n) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < n) dst[i] = (bf16_t)(w[i >> 1] >> (16 * (i & 1)));
+}
+
 // one 128x128 output tile (tile `lid` of problem g); shared by the two-problem and the many-problem kernels
 template <typename TC, bool TRANS_A, bool TRANS_B, bool VEC>
 __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid) {
@@ -244,10 +260,10 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
       const bf16x8 a1 = load_frag<TRANS_A>(sA, wm * 64 + 32, ks, lane);                  \
       const bf16x8 b0 = load_frag<TRANS_B>(sB, wn * 64, ks, lane);                       \
       const bf16x8 b1 = load_frag<TRANS_B>(sB, wn * 64 + 32, ks, lane);                  \
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);   \
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);   \
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);   \
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);   \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);   \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);   \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);   \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);   \
     }                                                                                    \
   }
   for (int k0 = kbeg; k0 < kend; k0 += 2 * TK) {
@@ -259,55 +275,70 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
 #undef LASR_K_STEP
 
   const int half = lane >> 5, l31 = lane & 31;
-  // acc[mi][ni][r]: row = wm*64 + mi*32 + (r&3) + 8*(r>>2) + 4*half, col = wn*64 + ni*32 + l31
+  // The MFMA operands are swapped (D = B_tile * A_tile^T), so the tile sits TRANSPOSED in the accumulators:
+  // acc[mi][ni][r]: row = wm*64 + mi*32 + l31, col = wn*64 + ni*32 + 8*(r>>2) + 4*half + (r&3) - a lane owns one output
+  // row per MFMA tile and 4 consecutive columns per register quad: 16-byte f32 stores, or packed bf16 pairs and 8-byte
+  // LDS writes (the natural order left one 4-byte store / one 2-byte LDS write per element).
   if constexpr (Elem<TC>::kDtype == LASR_F32) {
-    // f32 destinations (split-K slabs, logits, weight gradients): straight from the accumulators,
-    // 32 lanes x 4 B = one 128-byte segment per row
+    // f32 destinations (split-K slabs, logits, weight gradients): straight from the accumulators
     float* W = g.split_ws ? g.split_ws + (size_t)tz * (size_t)g.M * (size_t)g.N : reinterpret_cast<float*>(g.C);
     const int ldw = g.split_ws ? g.N : g.ldc;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = n0 + wn * 64 + ni * 32 + l31;
-      const float bv = (!g.split_ws && g.bias && n < g.N) ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lr = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          const int m = m0 + lr;
-          if (m < g.M && n < g.N) W[(uint32_t)m * (uint32_t)ldw + (uint32_t)n] = g.split_ws ? acc[mi][ni][r] : (acc[mi][ni][r] + bv) * s_keep[lr];
-        }
-    }
-  } else {
-    // ---- bf16 destination: row mask, round, column sums; then LDS transpose and 16-byte stores
-    __syncthreads();  // every wave is done reading the operand images
-    char* epi = smem + wid * (64 * EPI_LD);
-    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
-    const float bv0 = (g.bias && n0 + wn * 64 + l31 < g.N) ? g.bias[n0 + wn * 64 + l31] : 0.f;
-    const float bv1 = (g.bias && n0 + wn * 64 + 32 + l31 < g.N) ? g.bias[n0 + wn * 64 + 32 + l31] : 0.f;
+    const bool vec4 = (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    const bool plain = g.split_ws != nullptr;                 // slabs: no bias, no mask
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
+      const int lr = wm * 64 + mi * 32 + l31;
+      const int m = m0 + lr;
+      const float kf = plain ? 1.f : s_keep[lr];
+      if (m < g.M) {
+        float* wrow = W + (uint32_t)m * (uint32_t)ldw;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float kf = s_keep[wm * 64 + lr];
-        const bf16_t q0 = f32_to_bf16((acc[mi][0][r] + bv0) * kf);
-        const bf16_t q1 = f32_to_bf16((acc[mi][1][r] + bv1) * kf);
-        const float v0 = bf16_to_f32(q0), v1 = bf16_to_f32(q1);   // statistics of the values as stored
-        csum[0] += v0; csq[0] = fmaf(v0, v0, csq[0]);
-        csum[1] += v1; csq[1] = fmaf(v1, v1, csq[1]);
-        *reinterpret_cast<bf16_t*>(epi + lr * EPI_LD + l31 * 2) = q0;
-        *reinterpret_cast<bf16_t*>(epi + lr * EPI_LD + (32 + l31) * 2) = q1;
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + ni * 32 + 8 * j + 4 * half;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[mi][ni][4 * j + e];
+              if (!plain) v[e] = (v[e] + ((g.bias && n + e < g.N) ? g.bias[min(n + e, g.N - 1)] : 0.f)) * kf;
+            }
+            if (vec4 && n + 3 < g.N) {
+              *reinterpret_cast<float4*>(wrow + n) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < g.N) wrow[n + e] = v[e];
+            }
+          }
+        }
       }
     }
-    if (g.stat_partials) {
+  } else {
+    // ---- bf16 destination: bias, row mask, round; per-wave 64 x 64 LDS image; read back as 16-byte vectors for the
+    //      column sums (statistics of the values as stored) and the stores (8 rows x 128 B per instruction)
+    __syncthreads();  // every wave is done reading the operand images
+    char* epi = smem + wid * (64 * EPI_LD);
+    const bool has_bias = g.bias != nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const uint32_t km = s_keep[wm * 64 + mi * 32 + l31] != 0.f ? 0xffffffffu : 0u;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        csum[ni] += __shfl_xor(csum[ni], 32, 64);
-        csq[ni] += __shfl_xor(csq[ni], 32, 64);
-        if (half == 0) {
-          s_stat[wm][0][wn * 64 + ni * 32 + l31] = csum[ni];
-          s_stat[wm][1][wn * 64 + ni * 32 + l31] = csq[ni];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+          if (has_bias) {
+            const int n = n0 + wn * 64 + ni * 32 + 8 * j + 4 * half;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (n + e < g.N) ? g.bias[min(n + e, g.N - 1)] : 0.f;
+          }
+          uint2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]) & km;
+          pk.y = pack_bf16x2(v[2], v[3]) & km;
+          *reinterpret_cast<uint2*>(epi + (mi * 32 + l31) * EPI_LD + (ni * 32 + 8 * j + 4 * half) * 2) = pk;
         }
       }
     }
@@ -318,28 +349,57 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
       const int cg = lane & 7, rr = lane >> 3;
       const int n = n0 + wn * 64 + cg * 8;
       const bool full_n = g.vecC && n + 7 < g.N;
+      const bool want_stats = g.stat_partials != nullptr;
+      float cs[8], cq[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { cs[i] = 0.f; cq[i] = 0.f; }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 8 + rr;
         const int m = m0 + wm * 64 + lr;
+        const uint4 v = *reinterpret_cast<const uint4*>(epi + lr * EPI_LD + cg * 16);
+        if (want_stats) {                          // rows past M / past the utterance hold zeros
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+            cs[2 * i] += x0; cq[2 * i] = fmaf(x0, x0, cq[2 * i]);
+            cs[2 * i + 1] += x1; cq[2 * i + 1] = fmaf(x1, x1, cq[2 * i + 1]);
+          }
+        }
         if (m < g.M && n < g.N) {
-          const uint4 v = *reinterpret_cast<const uint4*>(epi + lr * EPI_LD + cg * 16);
           bf16_t* dst = C + (uint32_t)m * (uint32_t)g.ldc + (uint32_t)n;
-          if (full_n) {
-            *reinterpret_cast<uint4*>(dst) = v;
-          } else {
-            const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
-            for (int i = 0; i < 8 && n + i < g.N; ++i) dst[i] = e[i];
+          if (full_n) *reinterpret_cast<uint4*>(dst) = v;
+          else store_bf16_tail(dst, v, min(g.N - n, 8));
+        }
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int d = 8; d < 64; d <<= 1) {
+            cs[i] += __shfl_xor(cs[i], d, 64);
+            cq[i] += __shfl_xor(cq[i], d, 64);
+          }
+        }
+        if (rr == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            s_stat[wm][0][wn * 64 + cg * 8 + i] = cs[i];
+            s_stat[wm][1][wn * 64 + cg * 8 + i] = cq[i];
           }
         }
       }
     }
-    if (g.stat_partials && tid < TN) {
-      const int n = n0 + tid;
-      if (n < g.N) {
-        float* P = g.stat_partials + (size_t)tm * 2 * g.N;
-        P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
-        P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+    if (g.stat_partials) {
+      __syncthreads();
+      if (tid < TN) {
+        const int n = n0 + tid;
+        if (n < g.N) {
+          float* P = g.stat_partials + (size_t)tm * 2 * g.N;
+          P[n] = s_stat[0][0][tid] + s_stat[1][0][tid];
+          P[g.N + n] = s_stat[0][1][tid] + s_stat[1][1][tid];
+        }
       }
     }
   }
@@ -438,22 +498,6 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
       else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
     }
   }
-}
-
-// two f32 -> one dword of two bf16 (RNE): a single v_cvt_pk_bf16_f32
-typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  const pk_f32x2 f = {lo, hi};
-  const pk_bf16x2 h = __builtin_convertvector(f, pk_bf16x2);
-  return __builtin_bit_cast(uint32_t, h);
-}
-// N edge / unaligned C: element stores of the first n (1..8) values of v.  Out of line: the aligned path is the product path.
-__device__ __noinline__ void store_bf16_tail(bf16_t* dst, uint4 v, int n) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (i < n) dst[i] = (bf16_t)(w[i >> 1] >> (16 * (i & 1)));
 }
 
 #ifdef LASR_GEMM_STAMPS
