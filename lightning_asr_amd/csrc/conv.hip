@@ -39,11 +39,23 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   }
   // input rows t0*stride - pad ... (+in_rows), zero outside [0, Tin)
   const int64_t in0 = t0 * stride - pad;
-  for (int r = tl; r < in_rows; r += 16) {
-    const int64_t ti = in0 + r;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c_ok && ti >= 0 && ti < Tin) Elem<T>::ld4(xb + ti * C + c, v);
-    *reinterpret_cast<float4*>(s_x + (size_t)r * kCB + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  // eight rows per thread in flight, every load unconditional (clamped address, masked value): a guarded load per row
+  // made the staging a chain of ~18 exposed memory round trips (15 us for the 64-channel stride-2 layer)
+  const int64_t cld = c_ok ? c : C - 4;
+  for (int rb = tl; rb < in_rows; rb += 16 * 8) {
+    float v[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t ti = in0 + rb + 16 * u;
+      Elem<T>::ld4(xb + min(max(ti, (int64_t)0), Tin - 1) * C + cld, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rb + 16 * u;
+      const int64_t ti = in0 + r;
+      const float m = (c_ok && ti >= 0 && ti < Tin) ? 1.f : 0.f;
+      if (r < in_rows) *reinterpret_cast<float4*>(s_x + (size_t)r * kCB + cl * 4) = make_float4(v[u][0] * m, v[u][1] * m, v[u][2] * m, v[u][3] * m);
+    }
   }
   __syncthreads();
 
@@ -112,17 +124,33 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
   for (int64_t t0 = tbeg; t0 < tend; t0 += kWT) {
     __syncthreads();
     const int64_t in0 = t0 * stride - pad;
-    for (int r = jl; r < in_rows; r += 16) {
-      const int64_t ti = in0 + r;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c_ok && ti >= 0 && ti < Tin) Elem<T>::ld4(xb + ti * C + c, v);
-      *reinterpret_cast<float4*>(s_x + (size_t)r * kCB + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    // branch-free staging, eight x rows (then the four dy rows) per thread in flight
+    const int64_t cld = c_ok ? c : C - 4;
+    for (int rb = jl; rb < in_rows; rb += 16 * 8) {
+      float v[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t ti = in0 + rb + 16 * u;
+        Elem<T>::ld4(xb + min(max(ti, (int64_t)0), Tin - 1) * C + cld, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 16 * u;
+        const int64_t ti = in0 + r;
+        const float m = (c_ok && ti >= 0 && ti < Tin) ? 1.f : 0.f;
+        if (r < in_rows) *reinterpret_cast<float4*>(s_x + (size_t)r * kCB + cl * 4) = make_float4(v[u][0] * m, v[u][1] * m, v[u][2] * m, v[u][3] * m);
+      }
     }
-    for (int r = jl; r < kWT; r += 16) {
-      const int64_t t = t0 + r;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c_ok && t < tend) Elem<T>::ld4(db + t * C + c, v);
-      *reinterpret_cast<float4*>(s_d + (size_t)r * kCB + cl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    {
+      float v[kWT / 16][4];
+#pragma unroll
+      for (int u = 0; u < kWT / 16; ++u) Elem<T>::ld4(db + min(t0 + jl + 16 * u, Tout - 1) * C + cld, v[u]);
+#pragma unroll
+      for (int u = 0; u < kWT / 16; ++u) {
+        const int r = jl + 16 * u;
+        const float m = (c_ok && t0 + r < tend) ? 1.f : 0.f;
+        *reinterpret_cast<float4*>(s_d + (size_t)r * kCB + cl * 4) = make_float4(v[u][0] * m, v[u][1] * m, v[u][2] * m, v[u][3] * m);
+      }
     }
     __syncthreads();
     for (int t = 0; t < kWT; ++t) {
