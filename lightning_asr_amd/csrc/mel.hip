@@ -181,18 +181,24 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   double acc_s = 0.0, acc_q = 0.0;
   double* sre = s_re[wid];
   double* sim = s_im[wid];
-  for (int it = 0; it < kFramesPerBlock / kWaves; ++it) {
-    const int64_t f = (int64_t)blockIdx.x * kFramesPerBlock + it * kWaves + wid;
-    const bool live = f < Tb && f < T;  // wave-uniform
+  // Two real frames per complex transform: frame A in the real part, frame B in the imaginary part,
+  //   X_A[k] = (Z[k] + conj(Z[N-k])) / 2,   X_B[k] = (Z[k] - conj(Z[N-k])) / (2i)
+  // - half the butterflies and LDS exchanges per frame (the kernel is bound by LDS traffic, not by HBM).  In f64 the
+  // cross-talk between the two frames is ~1e-16 of the louder one.
+  for (int it = 0; it < kFramesPerBlock / kWaves; it += 2) {
+    const int flA = it * kWaves + wid, flB = (it + 1) * kWaves + wid;         // frames within the block
+    const int64_t fA = (int64_t)blockIdx.x * kFramesPerBlock + flA, fB = (int64_t)blockIdx.x * kFramesPerBlock + flB;
+    const bool liveA = fA < Tb && fA < T, liveB = fB < Tb && fB < T;          // wave-uniform
     cplx v[8];
     // ---- pass 0 (Ns = 1): lane j loads x[j + 64 r]; only n in [96, 416) is inside the window
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int n = lane + 64 * r;
-      const bool inw = live && n >= kWinOff && n < kWinOff + kWin;
-      const int fl = it * kWaves + wid;                       // frame within the block
-      const double x = inw ? (double)s_sig[fl * kHop + n] * s_win[min(max(n - kWinOff, 0), kWin - 1)] : 0.0;
-      v[r] = {x, 0.0};
+      const bool inw = n >= kWinOff && n < kWinOff + kWin;
+      const double wn = s_win[min(max(n - kWinOff, 0), kWin - 1)];
+      const double xa = (inw && liveA) ? (double)s_sig[flA * kHop + n] * wn : 0.0;
+      const double xb = (inw && liveB) ? (double)s_sig[flB * kHop + n] * wn : 0.0;
+      v[r] = {xa, xb};
     }
     fft8(v);
     wave_sync();  // previous iteration's readers are done with sre/sim
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
       for (int r = 0; r < 8; ++r) { sre[base + r * 8] = v[kPerm[r]].re; sim[base + r * 8] = v[kPerm[r]].im; }
       wave_sync();
     }
-    // ---- pass 2 (Ns = 64)
+    // ---- pass 2 (Ns = 64): Z[lane + 64 r] = v[perm r]
     {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -225,30 +231,47 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
       }
       fft8(v);
       wave_sync();
-      // X[lane + 64 r] = v[perm r]; keep the power of bins 0..256 in sre
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const cplx z = v[kPerm[r]];
-        sre[lane + 64 * r] = z.re * z.re + z.im * z.im;
-      }
-      if (lane == 0) {
-        const cplx z = v[kPerm[4]];
-        sre[256] = z.re * z.re + z.im * z.im;
-      }
+      for (int r = 0; r < 8; ++r) { sre[lane + 64 * r] = v[kPerm[r]].re; sim[lane + 64 * r] = v[kPerm[r]].im; }
       wave_sync();
     }
-    // ---- mel + dB: lane = mel channel
-    float db = 0.f;
-    if (live) {
-      double m = 0.0;
+    // ---- split the two spectra: powers of bins 0..256 of A and B (bin k pairs with N - k)
+    double pa[5], pb[5];
 #pragma unroll
-      for (int k = 0; k < kMaxBins; ++k) m = fma(sre[min(fb_lo + k, kFreq - 1)], (double)fbw[k], m);   // ascending bins, zero weights past hi
-      db = (float)(10.0 * log10(fmax(m, 1e-10)));
-      if (aug && ((lane >= rx && lane < rx + wx) || (f >= ry && f < ry + wy))) db = 0.f;
-      acc_s += (double)db;
-      acc_q += (double)db * (double)db;
+    for (int r = 0; r < 5; ++r) {
+      const int k = (r < 4) ? lane + 64 * r : 256;
+      const int km = (kNfft - k) & (kNfft - 1);
+      const double zr = sre[k], zi = sim[k], mr = sre[km], mi = sim[km];
+      const double ar = zr + mr, ai = zi - mi, br = zi + mi, bi = mr - zr;
+      pa[r] = 0.25 * (ar * ar + ai * ai);
+      pb[r] = 0.25 * (br * br + bi * bi);
     }
-    if (f < T) db_out[((int64_t)b * T + f) * kMel + lane] = db;
+    wave_sync();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sre[lane + 64 * r] = pa[r]; sim[lane + 64 * r] = pb[r]; }
+    if (lane == 0) { sre[256] = pa[4]; sim[256] = pb[4]; }
+    wave_sync();
+    // ---- mel + dB: lane = mel channel, both frames
+    double mA = 0.0, mB = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxBins; ++k) {   // ascending bins, zero weights past hi
+      const int bin = min(fb_lo + k, kFreq - 1);
+      mA = fma(sre[bin], (double)fbw[k], mA);
+      mB = fma(sim[bin], (double)fbw[k], mB);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool live = h ? liveB : liveA;
+      const int64_t f = h ? fB : fA;
+      float db = 0.f;
+      if (live) {
+        db = (float)(10.0 * log10(fmax(h ? mB : mA, 1e-10)));
+        if (aug && ((lane >= rx && lane < rx + wx) || (f >= ry && f < ry + wy))) db = 0.f;
+        acc_s += (double)db;
+        acc_q += (double)db * (double)db;
+      }
+      if (f < T) db_out[((int64_t)b * T + f) * kMel + lane] = db;
+    }
   }
   acc_s = wave_sum_d(acc_s);
   acc_q = wave_sum_d(acc_q);
