@@ -473,6 +473,7 @@ static constexpr int WROW = 160;                       // dwords per channel: TE
                                                        // zero-padded row W[i] = w'[i - 24]: TE[i] = (W[2i], W[2i+1]), TO[i] = (W[2i+1], W[2i+2])
 static constexpr int WSM_OFF = IMG_BYTES + STAGE_BYTES;
 static constexpr int SMEM = WSM_OFF + kCB * WROW * 4;  // 144 384
+static_assert(LDI >= TIN * 2 && LDI % 16 == 0, "image pitch");
 }
 typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
@@ -545,6 +546,19 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
         const uint32_t mk = ok ? 0xffffffffu : 0u;
         v[r][h] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
       }
+    }
+    // the addend of the data gradient (same [frame][channel] tile as the output) is requested now, behind the tile's own
+    // loads, and used in phase 3: its latency rides under the staging and the MFMAs (it was exposed once per half: ~3 us)
+    uint4 ra[NSET][4];
+    if (addend) {                                       // workgroup-uniform
+#pragma unroll
+      for (int ns = 0; ns < NSET; ++ns)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int ci = tid + 512 * it;              // chunk: frame ci >> 3 of the set, octet ci & 7
+          const int t = tA + ns * 256 + (ci >> 3), cc = c0 + (ci & 7) * 8;
+          ra[ns][it] = Vec<bf16_t>::raw(addend + ((size_t)b * Tlen + min(t, Tlen - 1)) * C + min(cc, C - 8));
+        }
     }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
@@ -634,8 +648,6 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
       __syncthreads();
       // the four chunks of the thread: the addend loads first (branch-free: clamped offsets, a dummy source when
       // there is no addend), then the arithmetic and the predicated stores
-      const bf16_t* addp = addend ? addend : y;           // never used for its value when addend is null
-      uint4 ra[4];
       size_t offs[4];
       bool okc[4];
 #pragma unroll
@@ -645,7 +657,6 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
         const int t = tA + ns * 256 + fl, cc = c0 + oc * 8;
         okc[it] = t < Tlen && cc < C;
         offs[it] = ((size_t)b * Tlen + min(t, Tlen - 1)) * C + min(cc, C - 8);
-        ra[it] = Vec<bf16_t>::raw(addp + offs[it]);
       }
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -658,7 +669,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
           const float4 lo = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32);
           const float4 hi = *reinterpret_cast<const float4*>(img + prow * LDOF + oc * 32 + 16);
           float a8[8];
-          Vec<bf16_t>::unpack(ra[it], a8);
+          Vec<bf16_t>::unpack(ra[ns][it], a8);
           float o[8] = {lo.x + a8[0], lo.y + a8[1], lo.z + a8[2], lo.w + a8[3], hi.x + a8[4], hi.y + a8[5], hi.z + a8[6], hi.w + a8[7]};
           if (okc[it]) Vec<bf16_t>::store(y + offs[it], o);
         }
