@@ -80,12 +80,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is hand-written HIP with no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the N > 1 path on a box with fewer GPUs than ranks: LASR_BENCH_BACKEND=gloo shares the devices round-robin
+    # (RCCL refuses two ranks on one device); the driver's runs use one GPU per rank over nccl = RCCL
+    backend = os.environ.get("LASR_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if args.gpus > 1 or world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # nccl backend IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl backend IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
         world = dist.get_world_size()
     else:
         dist = None
@@ -128,14 +135,16 @@ def main():
 
     # ---- roofline leg: the same steps again with HIP events around every launch of the dominant
     # kernel class (the 1x1-conv GEMMs), recorded on the launch stream inside liblasr.
+    # Every rank runs these steps (they contain the gradient all-reduce); only rank 0 brackets its launches with events.
     lib = _lib.load()
     roofline = None
+    n_prof = max(2, min(args.steps, 5))
     if rank == 0:
         lib.lasr_prof_enable(1)
-        n_prof = max(2, min(args.steps, 5))
-        for _ in range(n_prof):
-            ts.step(wave, tg, tl)
-        torch.cuda.synchronize()
+    for _ in range(n_prof):
+        ts.step(wave, tg, tl)
+    torch.cuda.synchronize()
+    if rank == 0:
         lib.lasr_prof_enable(0)
         ms = (C.c_double * 4)(); fl = (C.c_double * 4)(); by = (C.c_double * 4)(); cnt = (C.c_int64 * 4)()
         _lib.check(lib.lasr_prof_collect(ms, fl, by, cnt), "lasr_prof_collect")
