@@ -135,6 +135,12 @@ int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, int n_probs, 
                                    int* splits, void* stream);
 int lasr_dwconv_wgrad_partials(const void* x, const void* dy, int dtype, int64_t B, int64_t Tin, int64_t C, int k,
                                int stride, void* workspace, size_t workspace_bytes, int* n_partials, void* stream);
+/* Both consumers of a unit's d(depthwise output) in one launch (stride 1): the weight-gradient partials of
+ * lasr_dwconv_wgrad_partials(x, dy) and dx = lasr_dwconv_fwd(dy, w, addend, flip = 1).  Falls back to those two calls
+ * for shapes / dtypes the fused MFMA kernel does not take.   (models/QuartNet.py:15-19 backward) */
+int lasr_dwconv_bwd_fused(const void* x, const void* dy, const float* w, const void* addend, void* dx, int dtype,
+                          int64_t B, int64_t T, int64_t C, int k, void* workspace, size_t workspace_bytes,
+                          int* n_partials, void* stream);
 
 /* lasr_gemm_batch that leaves each problem's BN partial sums UNREDUCED in the workspace (no split-K):
  * for every problem with stats != NULL, stat_partials[i] points at [stat_tiles[i]][2][N] f32 inside

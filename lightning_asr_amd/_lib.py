@@ -47,6 +47,7 @@ SIGNATURES = {
     "lasr_gemm_batch_split_partials": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "lasr_gemm_multi_split_partials": (_i32, [_p, _i32, _i32, _p, _p, _p]),
     "lasr_dwconv_wgrad_partials": (_i32, [_p, _p, _i32, _i64, _i64, _i64, _i32, _i32, _p, _sz, _p, _p]),
+    "lasr_dwconv_bwd_fused": (_i32, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i64, _i32, _p, _sz, _p, _p]),
     "lasr_gemm_batch_partials": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p, _p, _p]),
     "lasr_bn_finalize_partials": (_i32, [_p, _i32, _i64, _i64, C.c_float, C.c_float, _p]),
     "lasr_seqsum": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p]),

@@ -487,17 +487,18 @@ __device__ unsigned long long* g_dw_stamps = nullptr;   // debug builds only (to
 #endif
 // NSET: 256-frame MFMA sets per time tile (2: one workgroup per 64 channels x 512 frames; 1: half tiles, twice the
 // workgroups - for layers whose C/64 x B grid would leave CUs idle); gridDim.z workgroups share an utterance's tiles.
+// (bx, by, bz) of (gx, B, gz): channel group, utterance, time-tile lane - the kernel's own grid or a slice of a fused grid
 template <int NKS, int NSET>
-__global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                                                                const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-                                                                int Tlen, int C, int k, int flip) {
+__device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                    const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+                                                    int Tlen, int C, int k, int flip, int bx, int by, int bz, int gz,
+                                                    char* smem_raw) {
   using namespace dwm;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* img = smem_raw;                               // [64 channels][LDI]: frame tau at byte 2*tau
   char* stage = smem_raw + IMG_BYTES;                 // [RS frames][LDST]
   uint32_t* wsm = reinterpret_cast<uint32_t*>(smem_raw + WSM_OFF);   // [64][WROW]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.y, c0 = blockIdx.x * kCB;
+  const int b = by, c0 = bx * kCB;
   // the block's taps -> LDS once, as packed bf16 pair tables (reversed for the data gradient); a Toeplitz
   // fragment W[s .. s+7] is 4 consecutive dwords of TE (s even) or TO (s odd): no per-channel work in phase 2.
   // Loads are unconditional (clamped index, masked value) and all issued before the first conversion.
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
 
   DW_STAMP(0);
   constexpr int TTS = 256 * NSET;                     // output frames per time tile
-  for (int tA = blockIdx.z * TTS; tA < Tlen; tA += TTS * gridDim.z) {
+  for (int tA = bz * TTS; tA < Tlen; tA += TTS * gz) {
     const int tin = TTS - 16 + KW;                     // staged frames: t = tA - P + tau, tau in [0, tin)
     // ---- phase 1: HBM -> staging ([frame][channel]) -> transposed image ([channel][frame]) ------------------
     // all global loads of the tile first (two 16-byte chunks per thread and round), then round by round
@@ -682,6 +683,14 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
   DW_STAMP(3);
 }
 
+template <int NKS, int NSET>
+__global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
+                                                                int Tlen, int C, int k, int flip) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  dwconv_s1_mfma_body<NKS, NSET>(x, w, addend, y, Tlen, C, k, flip, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw);
+}
+
 // Weight gradient, stride 1.  Lane = 4 channels x 8 consecutive taps (group jg) x one time split;
 // the 8 frames x[t+j0 .. t+j0+7] slide through a register window as t advances, so a frame costs
 // two LDS vector reads (new x row, dy row) for 32 FMAs.  16 lane groups per workgroup are dealt as
@@ -820,15 +829,15 @@ static constexpr int SMEM = ST_OFF + RSG * dwm::LDST;   // 133 120
 static constexpr int XR = (XF + RSG - 1) / RSG, DR = (DF + RSG - 1) / RSG;   // 2 + 2 staging rounds
 }
 
-__global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                      float* __restrict__ partials, int Tlen, int C, int k) {
+__device__ __forceinline__ void dwconv_wgrad_s1_mfma_body(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          float* __restrict__ partials, int Tlen, int C, int k, int bx, int by,
+                                                          int bz, int gz, char* smem_raw) {
   using namespace dwg;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   char* ximg = smem_raw + X_OFF;
   char* d0 = smem_raw + D0_OFF;
   char* stage = smem_raw + ST_OFF;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = blockIdx.y, c0 = blockIdx.x * kCB;
+  const int b = by, c0 = bx * kCB;
   const int pad = k / 2, P = (pad + 7) & ~7, sh = P - pad;
   const int n16 = lane & 15, g4 = lane >> 4;
   const bf16_t* xb = x + (size_t)b * Tlen * C;
@@ -864,7 +873,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
     }
   };
   // gridDim.z workgroups share an utterance's tiles (narrow layers: C/64 x B alone would leave CUs idle)
-  const int zq = blockIdx.z, zn = gridDim.z;
+  const int zq = bz, zn = gz;
   issue_loads(zq);
   for (int q = zq; q < n_tiles; q += zn) {
     // ---- phase 1: round by round through the transposing staging
@@ -938,6 +947,35 @@ __global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16
       const int j = 16 * n16 + 4 * g4 + r - sh;
       if (c < C && j >= 0 && j < k) out[(size_t)c * k + j] = acc[ch][r];
     }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void dwconv_wgrad_s1_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                      float* __restrict__ partials, int Tlen, int C, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  dwconv_wgrad_s1_mfma_body(x, dy, partials, Tlen, C, k, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw);
+}
+
+// Both consumers of a unit's d(depthwise output) in ONE launch: the weight gradient (x, dy -> per-utterance partials) and
+// the data gradient (dy, flipped taps, + residual addend -> dx) are independent, so their workgroups share a grid (the
+// weight-gradient ones first): one launch ramp less per unit, and the second kernel's workgroups start as the first's
+// drain instead of behind a launch boundary.
+struct DwBwd {
+  const bf16_t* x; const bf16_t* dy; const float* w; const bf16_t* addend; bf16_t* dx; float* partials;
+  int Tlen, C, k;
+  int gx, B, gz_w, gz_d, n_w;     // channel groups, utterances, time lanes of either part, workgroups of the weight-gradient part
+};
+template <int NKS, int NSET>
+__global__ __launch_bounds__(512, 1) void dwconv_bwd_s1_mfma_kernel(DwBwd a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int id = blockIdx.x;
+  if (id < a.n_w) {               // workgroup-uniform
+    const int bx = id % a.gx, by = (id / a.gx) % a.B, bz = id / (a.gx * a.B);
+    dwconv_wgrad_s1_mfma_body(a.x, a.dy, a.partials, a.Tlen, a.C, a.k, bx, by, bz, a.gz_w, smem_raw);
+  } else {
+    id -= a.n_w;
+    const int bx = id % a.gx, by = (id / a.gx) % a.B, bz = id / (a.gx * a.B);
+    dwconv_s1_mfma_body<NKS, NSET>(a.dy, a.w, a.addend, a.dx, a.Tlen, a.C, a.k, 1, bx, by, bz, a.gz_d, smem_raw);
   }
 }
 
@@ -1103,3 +1141,53 @@ extern "C" int lasr_debug_set_dw_stamps(void* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(lasr::g_dw_stamps), &p, sizeof(p));
 }
 #endif
+
+extern "C" int lasr_dwconv_bwd_fused(const void* x, const void* dy, const float* w, const void* addend, void* dx, int dtype,
+                                     int64_t B, int64_t T, int64_t C, int k, void* workspace, size_t workspace_bytes,
+                                     int* n_partials, void* stream) {
+  LASR_CHECK_ARG(x && dy && w && dx && workspace && n_partials, "lasr_dwconv_bwd_fused: null pointer");
+  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_dwconv_bwd_fused: bad dtype");
+  LASR_CHECK_SHAPE(k >= 1 && k <= kMaxK && (k & 1) && C % 4 == 0 && B > 0 && B < 65536 && T > 0, "lasr_dwconv_bwd_fused: k=%d C=%lld", k,
+                   (long long)C);
+  const int padk = k / 2, shk = ((padk + 7) & ~7) - padk;
+  static const bool no_fused = getenv("LASR_DW_NO_FUSED_BWD") != nullptr;     // A/B switch: the two launches
+  static const bool valu = getenv("LASR_DWWGRAD_VALU") || getenv("LASR_DWCONV_FMA") || getenv("LASR_DWCONV_DOT2");
+  const bool ok = !no_fused && !valu && dtype == LASR_BF16 && C % 8 == 0 && 15 + k + shk <= dwm::KWMAX && k + shk <= 16 * 7 &&
+                  T < (1 << 30) && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0 &&
+                  workspace_bytes >= lasr_dwconv_wgrad_workspace_bytes(B, T, C, k);
+  if (!ok) {
+    LASR_TRY(lasr_dwconv_wgrad_partials(x, dy, dtype, B, T, C, k, 1, workspace, workspace_bytes, n_partials, stream));
+    return lasr_dwconv_fwd(dy, w, addend, dx, dtype, B, T, C, k, 1, 1, stream);
+  }
+  DwBwd a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.w = w; a.addend = (const bf16_t*)addend; a.dx = (bf16_t*)dx;
+  a.partials = reinterpret_cast<float*>(workspace);
+  a.Tlen = (int)T; a.C = (int)C; a.k = k; a.gx = (int)cdiv(C, kCB); a.B = (int)B;
+  // the same grid choices as the separate launches
+  const int n_tiles = (int)((T + 15 + dwg::TU) / dwg::TU);
+  static const int zmax = getenv("LASR_DWWGRAD_ZSPLIT") ? atoi(getenv("LASR_DWWGRAD_ZSPLIT")) : 2;
+  int zsplit = 1;
+  while (zsplit < zmax && zsplit * 2 <= n_tiles && cdiv(C, kCB) * B * zsplit < 200) zsplit *= 2;
+  a.gz_w = zsplit;
+  a.n_w = a.gx * a.B * a.gz_w;
+  static const bool no_half = getenv("LASR_DWCONV_NO_HALF") != nullptr;
+  const bool half = !no_half && T > 256 && cdiv(C, kCB) * B * cdiv(T, (int64_t)512) < 200;
+  a.gz_d = half ? (int)std::min<int64_t>(cdiv(T, (int64_t)256), 8) : 1;
+  const unsigned total = (unsigned)(a.n_w + a.gx * a.B * a.gz_d);
+  const int nks = (15 + k + shk + 31) / 32;
+  constexpr int kSmem = dwm::SMEM > dwg::SMEM ? dwm::SMEM : dwg::SMEM;
+  const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 4.0 * (double)B * T * C * k, (double)B * T * C * (addend ? 5 : 4) * 2);
+#define LASR_DWB2(N_, S_)                                                                                                      \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_bwd_s1_mfma_kernel<N_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((dwconv_bwd_s1_mfma_kernel<N_, S_>), dim3(total), dim3(512), kSmem, as_stream(stream), a);                \
+  } while (0)
+#define LASR_DWB(N_) do { if (half) LASR_DWB2(N_, 1); else LASR_DWB2(N_, 2); } while (0)
+  if (nks == 1) LASR_DWB(1); else if (nks == 2) LASR_DWB(2); else if (nks == 3) LASR_DWB(3); else LASR_DWB(4);
+#undef LASR_DWB
+#undef LASR_DWB2
+  prof_end(tok, as_stream(stream));
+  LASR_LAUNCH_CHECK("dwconv_bwd_s1_mfma_kernel");
+  *n_partials = (int)B * zsplit;
+  return 0;
+}

@@ -524,7 +524,13 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       if (with_res) pr[1] = {dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), N, u.ci, u.co, nullptr, nullptr, 0, nullptr};
       LASR_TRY(lasr_gemm_batch(pr, with_res ? 2 : 1, dt, dt, 0, 1, 1, scratch, sb, stream));
       // depthwise dW from (x, du); dx = flipped depthwise conv of du (+ residual dx)
-      if (defer) {
+      const bool fused_dw = defer && need_dx && u.stride == 1;   // both in one launch (falls back inside for other dtypes / shapes)
+      if (fused_dw) {
+        int npart = 0;
+        LASR_TRY(lasr_dwconv_bwd_fused(x_in, at(ws, p.o_du), params + u.w_dw, u.has_res ? at(ws, p.o_dxr) : nullptr, dx, dt, B, T, u.ci, u.k,
+                                       at(ws, u.o_dwp), u.dwp_bytes, &npart, stream));
+        pending.push_back({atf(ws, u.o_dwp), grads + u.w_dw, u.ci * (int64_t)u.k, npart});
+      } else if (defer) {
         int npart = 0;
         LASR_TRY(lasr_dwconv_wgrad_partials(x_in, at(ws, p.o_du), dt, B, Tx, u.ci, u.k, u.stride, at(ws, u.o_dwp), u.dwp_bytes, &npart,
                                             stream));
@@ -537,7 +543,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
         LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));
         pending.clear();
       }
-      if (need_dx)
+      if (need_dx && !fused_dw)
         LASR_TRY(lasr_dwconv_fwd(at(ws, p.o_du), params + u.w_dw, u.has_res ? at(ws, p.o_dxr) : nullptr, dx, dt, B, T, u.ci, u.k, 1,
                                  1, stream));
     } else if (need_dx) {

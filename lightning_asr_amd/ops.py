@@ -168,6 +168,21 @@ def wgrad_multi(dys, xs, split_k: int = 4):
     return outs
 
 
+def dwconv_bwd_fused(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, addend: Optional[torch.Tensor] = None):
+    """Depthwise backward of a stride-1 layer in one launch: (dW (C, k) f32, dx (B, T, C)) from x, dy (B, T, C) and the taps
+    w (C, 1, k) / (C, k) f32 (lasr_dwconv_bwd_fused + lasr_reduce_many)."""
+    B, T, Cc = x.shape
+    k = w.shape[-1]
+    dx = torch.empty_like(dy)
+    nb = _lib.load().lasr_dwconv_wgrad_workspace_bytes(B, T, Cc, k)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    npart = _lib.C.c_int(0)
+    call("lasr_dwconv_bwd_fused", _p(x), _p(dy), _p(w), _p(addend), _p(dx), _dt(x), B, T, Cc, k, _p(ws), nb, _lib.C.byref(npart), _stream())
+    dw = torch.empty(Cc, k, dtype=torch.float32, device=x.device)
+    reduce_many([(ws.view(torch.float32)[:npart.value * Cc * k].view(npart.value, Cc * k), dw.view(-1))])
+    return dw, dx
+
+
 def bn_finalize(stats, gamma, beta, running_mean, running_var, n_rows: int, eps: float = 1e-3, momentum: float = 0.1,
                 training: bool = True):
     Cc = gamma.numel()

@@ -586,3 +586,20 @@ def test_dwconv_bf16_mfma_tile_forms(dev, C, k, T, B):
     dref = torch.stack([(dy.double() * xp[:, j:j + T, :]).sum(dim=(0, 1)) for j in range(k)], dim=1)
     dw = ops.dwconv_wgrad(xg, dy.to(dev), k, 1)
     assert (dw.cpu().double() - dref).abs().max() < 2e-5 * dref.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("C,k,T,B,res", [(512, 63, 501, 32, True), (256, 33, 501, 8, True), (336, 51, 300, 3, False), (64, 5, 40, 2, True)])
+def test_dwconv_bwd_fused_equals_separate_launches(dev, C, k, T, B, res):
+    """lasr_dwconv_bwd_fused (weight-gradient and data-gradient workgroups in one grid) against the two separate launches
+    on the same bf16 inputs: same kernels' bodies, so dx must be bit-identical and dW equal up to the order of the final f64 sum."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(C + k + T)
+    x = torch.randn(B, T, C, generator=g).bfloat16().to(dev)
+    dy = torch.randn(B, T, C, generator=g).bfloat16().to(dev)
+    w = (torch.randn(C, 1, k, generator=g) / math.sqrt(k)).to(dev)
+    add = torch.randn(B, T, C, generator=g).bfloat16().to(dev) if res else None
+    dw_ref = ops.dwconv_wgrad(x, dy, k, 1)
+    dx_ref = ops.dwconv(dy, w, 1, flip=True, addend=add)
+    dw, dx = ops.dwconv_bwd_fused(x, dy, w, add)
+    assert torch.equal(dx, dx_ref)
+    assert max_rel(dw, dw_ref) < 1e-6            # same partials, summed by lasr_reduce_many instead of the kernel's own tail
