@@ -603,3 +603,39 @@ def test_dwconv_bwd_fused_equals_separate_launches(dev, C, k, T, B, res):
     dw, dx = ops.dwconv_bwd_fused(x, dy, w, add)
     assert torch.equal(dx, dx_ref)
     assert max_rel(dw, dw_ref) < 1e-6            # same partials, summed by lasr_reduce_many instead of the kernel's own tail
+
+
+def test_ctc_random_sweep_vs_torch(dev):
+    """Seeded sweep of lattice shapes through both emission paths (LDS rows when C % 4 == 0, register ring otherwise):
+    ragged input / target lengths, repeated labels, empty targets, tight alignments (T = S + repeats), blank-dominated
+    emissions (the finite dead-state sentinel must behave like -inf)."""
+    from lightning_asr_amd import ops
+    rng = np.random.default_rng(7)
+    g = torch.Generator().manual_seed(7)
+    for case in range(24):
+        C = int(rng.choice([5, 8, 28, 29, 40]))
+        B = int(rng.integers(1, 6))
+        S = int(rng.integers(0, 60))
+        T = int(rng.integers(max(2 * S + 2, 4), 2 * S + 80))
+        logits = torch.randn(B, T, C, generator=g) * float(rng.choice([1.0, 4.0]))
+        if case % 3 == 0:
+            logits[..., C - 1] += 12.0                       # blank-dominated: label paths are ~e^-12 per frame
+        lp = F.log_softmax(logits, -1)
+        tg = torch.randint(0, C - 1, (B, max(S, 1)), generator=g)
+        if case % 2 == 0 and S > 1:
+            tg[:, 1::2] = tg[:, 0:-1:2][:, :tg[:, 1::2].shape[1]]     # adjacent repeats
+        tl = torch.randint(0, S + 1, (B,), generator=g, dtype=torch.int32)
+        tl[0] = S
+        reps = [(int((tg[b, 1:tl[b]] == tg[b, :max(tl[b] - 1, 0)]).sum()) if tl[b] > 1 else 0) for b in range(B)]
+        il = torch.tensor([int(rng.integers(int(tl[b]) + reps[b], T + 1)) for b in range(B)], dtype=torch.int32)
+        if case % 4 == 1:
+            il[0] = int(tl[0]) + reps[0]                     # tightest feasible alignment
+        il = il.clamp(min=1)
+        lpr = lp.clone().requires_grad_(True)
+        ref = F.ctc_loss(lpr.transpose(0, 1), tg, il.long(), tl.long(), blank=C - 1, reduction="none")
+        assert torch.isfinite(ref).all(), case
+        ref.sum().backward()
+        nll, grad = ops.ctc_loss(lp.to(dev), tg.to(dev), il.to(dev), tl.to(dev), C - 1, True, torch.ones(B, device=dev))
+        assert ((nll.cpu() - ref.detach()).abs() <= 1e-4 * ref.detach().abs() + 1e-5).all(), (case, nll.cpu(), ref)
+        gref = lpr.grad
+        assert (grad.cpu() - gref).abs().max() < 2e-3 * gref.abs().max() + 1e-6, case
