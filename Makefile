@@ -8,7 +8,7 @@ CXXFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Wall -Wno-unused-functi
 lightning_asr_amd/liblasr.so: $(OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
-build/%.o: lightning_asr_amd/csrc/%.hip lightning_asr_amd/csrc/common.h include/lasr.h
+build/%.o: lightning_asr_amd/csrc/%.hip lightning_asr_amd/csrc/common.h lightning_asr_amd/csrc/ctc_lattice.h include/lasr.h
 	@mkdir -p build
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 

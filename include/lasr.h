@@ -258,6 +258,17 @@ size_t lasr_ctc_workspace_bytes(int64_t B, int64_t T, int64_t S_max);
 int lasr_ctc_loss(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens,
                   int64_t B, int64_t T, int64_t C, int64_t S_max, int blank, float* nll, float* grad,
                   const float* gscale, void* workspace, size_t workspace_bytes, void* stream);
+/* lasr_ctc_loss for one batch and lasr_mel_fwd for ANOTHER batch's waveforms in one launch sequence: the lattice kernel
+ * keeps 32 workgroups busy for ~0.1 ms of dependent steps, the feature transform (2 016 workgroups) fills the other CUs
+ * meanwhile (one grid: lattice workgroups first).  Same results as the two calls; falls back to them for shapes the
+ * fused grid does not take (more than 127 labels, C % 4 != 0, emissions over 78 KB).  This is the data-loader prefetch of
+ * data_module.py's workers: the features of step i+1 are produced while step i computes its loss. */
+int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens,
+                      int64_t B, int64_t T, int64_t C, int64_t S_max, int blank, float* nll, float* grad,
+                      const float* gscale, void* ctc_workspace, size_t ctc_workspace_bytes, const float* wave,
+                      const int32_t* sample_lens, const float* dither, const int32_t* aug, int64_t Bm, int64_t L,
+                      int normalize, float* out_bft, void* out_btf, int dtype, int32_t* frames_out, float* pct_out,
+                      void* mel_workspace, size_t mel_workspace_bytes, void* stream);
 
 /* Greedy CTC collapse of argmax ids (B, T) int32 truncated to lens (B) (NULL = T):
  * tokens (B, T) int32, n_tokens (B) int32.   utils/asr_metrics.py:159-166                      */
@@ -318,6 +329,12 @@ typedef struct {
 
 int lasr_model_create(const lasr_model_config* cfg, lasr_model_t** out);
 void lasr_model_destroy(lasr_model_t* m);
+/* One-shot feature prefetch: the next lasr_model_loss_backward[_partial] call on this model computes its CTC loss through
+ * lasr_ctc_loss_mel with these lasr_mel_fwd arguments (channels-last output only), then forgets the request.  All
+ * pointers are the caller's device buffers and must stay valid until that call has been enqueued. */
+int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
+                            const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
+                            int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes);
 /* Tensors in reference state_dict order.  kind: 0 = parameter (lives in the flat param buffer at
  * `offset` elements), 1 = f32 buffer (running_mean/var, flat buffer array), 2 = num_batches_tracked
  * (int64, kept by the host).  Returns the number of tensors; fills row i when i >= 0.            */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "lasr_log_softmax_bwd": (_i32, [_p, _p, _p, _i64, _i64, _p]),
     "lasr_ctc_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lasr_ctc_loss": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    "lasr_ctc_loss_mel": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _sz,
+                                 _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "lasr_greedy_decode": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p]),
     "lasr_novograd_workspace_bytes": (_sz, [_i64, _i64]),
     "lasr_novograd_step": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p, _sz, _p]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "lasr_prof_overhead_ms": (_i32, [_p, _i32, _p]),
     "lasr_model_create": (_i32, [C.POINTER(ModelConfig), C.POINTER(_p)]),
     "lasr_model_destroy": (None, [_p]),
+    "lasr_model_set_prefetch": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _sz]),
     "lasr_model_tensor_info": (_i64, [_p, _i64, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(_i64)]),
     "lasr_model_param_elems": (_i64, [_p]),

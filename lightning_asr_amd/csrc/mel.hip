@@ -8,6 +8,7 @@
 // (B,64,T) reference-layout store is done from an LDS transpose in 64-byte runs and the
 // channels-last store is a full 256-byte row per wave.
 #include "common.h"
+#include "ctc_lattice.h"
 #include <math.h>
 #include <mutex>
 
@@ -106,20 +107,30 @@ __device__ __forceinline__ void wave_sync() {
 
 // grid: (ceil(T/16), B), block 256.  dB values -> db_out [B][T][64] f32 (workspace); per-block
 // (sum, sumsq) in double -> partials[b][blk][2].
-__global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ wave, const int32_t* __restrict__ sample_lens,
-                                                     const float* __restrict__ dither, const int32_t* __restrict__ aug,
-                                                     int64_t L, int64_t T, float* __restrict__ db_out,
-                                                     double* __restrict__ partials, int32_t* __restrict__ frames_out,
-                                                     float* __restrict__ pct_out) {
-  __shared__ double s_re[kWaves][kNfft];
-  __shared__ double s_im[kWaves][kNfft];
-  __shared__ double s_twr[kNfft];
-  __shared__ double s_twi[kNfft];
-  __shared__ double s_red[kWaves][2];
-  __shared__ double s_win[kWin];
-  __shared__ float s_sig[kSigLen];
+struct MelSmem {
+  double re[kWaves][kNfft];
+  double im[kWaves][kNfft];
+  double twr[kNfft];
+  double twi[kNfft];
+  double red[kWaves][2];
+  double win[kWin];
+  float sig[kSigLen];
+};   // 55 872 bytes
+// (bx, by) of (nbx, B): frame tile and utterance - the kernel's own grid, or a slice of the fused feature + lattice grid
+__device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, const int32_t* __restrict__ sample_lens,
+                                            const float* __restrict__ dither, const int32_t* __restrict__ aug,
+                                            int64_t L, int64_t T, float* __restrict__ db_out,
+                                            double* __restrict__ partials, int32_t* __restrict__ frames_out,
+                                            float* __restrict__ pct_out, int bx, int by, int nbx, MelSmem& sm) {
+  double (&s_re)[kWaves][kNfft] = sm.re;
+  double (&s_im)[kWaves][kNfft] = sm.im;
+  double (&s_twr)[kNfft] = sm.twr;
+  double (&s_twi)[kNfft] = sm.twi;
+  double (&s_red)[kWaves][2] = sm.red;
+  double (&s_win)[kWin] = sm.win;
+  float (&s_sig)[kSigLen] = sm.sig;
 
-  const int b = blockIdx.y;
+  const int b = by;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t Lb = sample_lens ? (int64_t)sample_lens[b] : L;
   const int64_t Lp = Lb + 2 * kPad;
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
     const float w = g_mel.fb[min(fb_lo + k, kFreq - 1) * kMel + lane];
     fbw[k] = (fb_lo + k <= fb_hi) ? w : 0.f;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bx == 0 && threadIdx.x == 0) {
     frames_out[b] = (int32_t)Tb;
     pct_out[b] = (float)Tb / (float)T;
   }
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   // each frame a chain of ~6 exposed memory round trips (the kernel took 136 us for 20 MB).
   {
     constexpr int kSigIt = kSigLen / 256;          // 12
-    const int64_t i0 = (int64_t)blockIdx.x * kFramesPerBlock * kHop - kNfft / 2;   // padded-signal index of s_sig[0]
+    const int64_t i0 = (int64_t)bx * kFramesPerBlock * kHop - kNfft / 2;   // padded-signal index of s_sig[0]
     float cur[kSigIt], prv[kSigIt], ncur[kSigIt], nprv[kSigIt];
 #pragma unroll
     for (int u = 0; u < kSigIt; ++u) {
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   // cross-talk between the two frames is ~1e-16 of the louder one.
   for (int it = 0; it < kFramesPerBlock / kWaves; it += 2) {
     const int flA = it * kWaves + wid, flB = (it + 1) * kWaves + wid;         // frames within the block
-    const int64_t fA = (int64_t)blockIdx.x * kFramesPerBlock + flA, fB = (int64_t)blockIdx.x * kFramesPerBlock + flB;
+    const int64_t fA = (int64_t)bx * kFramesPerBlock + flA, fB = (int64_t)bx * kFramesPerBlock + flB;
     const bool liveA = fA < Tb && fA < T, liveB = fB < Tb && fB < T;          // wave-uniform
     cplx v[8];
     // ---- pass 0 (Ns = 1): lane j loads x[j + 64 r]; only n in [96, 416) is inside the window
@@ -280,8 +291,44 @@ __global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ w
   if (threadIdx.x == 0) {
     double s = 0, q = 0;
     for (int w = 0; w < kWaves; ++w) { s += s_red[w][0]; q += s_red[w][1]; }
-    partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 0] = s;
-    partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 + 1] = q;
+    partials[((int64_t)b * nbx + bx) * 2 + 0] = s;
+    partials[((int64_t)b * nbx + bx) * 2 + 1] = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ wave, const int32_t* __restrict__ sample_lens,
+                                                     const float* __restrict__ dither, const int32_t* __restrict__ aug,
+                                                     int64_t L, int64_t T, float* __restrict__ db_out,
+                                                     double* __restrict__ partials, int32_t* __restrict__ frames_out,
+                                                     float* __restrict__ pct_out) {
+  __shared__ MelSmem sm;
+  mel_db_body(wave, sample_lens, dither, aug, L, T, db_out, partials, frames_out, pct_out, blockIdx.x, blockIdx.y, gridDim.x, sm);
+}
+
+// The CTC lattice (one workgroup of two busy waves per utterance, ~0.1 ms of dependent steps) and the log-mel transform
+// of the NEXT batch in ONE grid: the 32 lattice workgroups come first and run for the whole launch, the 2 016 feature
+// workgroups fill the other 224 CUs meanwhile.  Two queues cannot do this (measured: the second queue's kernels start
+// ~1.7 ms after the event they wait for); one grid can.
+struct MelCtcArgs {
+  // lattice
+  const float* logp; const int64_t* targets; const int32_t* in_lens; const int32_t* tgt_lens;
+  int64_t T, C, S_max; int blank; float* alpha; float* beta; int32_t* next_same; float* nll; int n_ctc;
+  // features
+  const float* wave; const int32_t* sample_lens; const float* dither; const int32_t* aug;
+  int64_t L, Tm; float* db_out; double* partials; int32_t* frames_out; float* pct_out; int nbx;
+};
+template <int NS>
+__global__ __launch_bounds__(256) void mel_ctc_kernel(MelCtcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if ((int)blockIdx.x < a.n_ctc) {                       // workgroup-uniform
+    int32_t* s_tg = reinterpret_cast<int32_t*>(smem_raw);
+    float* s_lp = reinterpret_cast<float*>(smem_raw + kCtcMaxS * sizeof(int32_t));
+    ctc_alpha_beta_body<NS, true, 256>(a.logp, a.targets, a.in_lens, a.tgt_lens, a.T, a.C, a.S_max, a.blank, a.alpha, a.beta, a.next_same,
+                                       a.nll, (int)blockIdx.x, s_tg, s_lp);
+  } else {
+    const int id = (int)blockIdx.x - a.n_ctc;
+    mel_db_body(a.wave, a.sample_lens, a.dither, a.aug, a.L, a.Tm, a.db_out, a.partials, a.frames_out, a.pct_out, id % a.nbx, id / a.nbx,
+                a.nbx, *reinterpret_cast<MelSmem*>(smem_raw));
   }
 }
 
@@ -366,6 +413,59 @@ extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const
   else
     hipLaunchKernelGGL(mel_norm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), db, partials, frames_out, T, nblk,
                        normalize, out_bft, reinterpret_cast<bf16_t*>(out_btf));
+  LASR_LAUNCH_CHECK("mel_norm_kernel");
+  return 0;
+}
+
+extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B,
+                                 int64_t T, int64_t C, int64_t S_max, int blank, float* nll, float* grad, const float* gscale,
+                                 void* ctc_workspace, size_t ctc_workspace_bytes, const float* wave, const int32_t* sample_lens,
+                                 const float* dither, const int32_t* aug, int64_t Bm, int64_t L, int normalize, float* out_bft,
+                                 void* out_btf, int dtype, int32_t* frames_out, float* pct_out, void* mel_workspace,
+                                 size_t mel_workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(logp && targets && in_lens && tgt_lens && nll && ctc_workspace && wave && frames_out && pct_out && mel_workspace,
+                 "lasr_ctc_loss_mel: null pointer");
+  const int64_t sm = S_max > 0 ? S_max : 1;
+  const size_t em_bytes = (size_t)(T + 2) * C * sizeof(float);
+  const size_t lds = std::max(sizeof(MelSmem), kCtcMaxS * sizeof(int32_t) + em_bytes);
+  static const bool no_fused = getenv("LASR_NO_MEL_CTC") != nullptr;     // A/B switch
+  const bool fused = !no_fused && B > 0 && T > 0 && C > 1 && 2 * S_max + 1 <= 256 && lds <= 80 * 1024 && C % 4 == 0 &&
+                     reinterpret_cast<uintptr_t>(logp) % 16 == 0 && !getenv("LASR_CTC_NO_LDS") && (out_bft || out_btf) &&
+                     (dtype == LASR_F32 || dtype == LASR_BF16) && Bm > 0 && Bm < 65536 && L >= 2 && L < (1ll << 30) &&
+                     ctc_workspace_bytes >= lasr_ctc_workspace_bytes(B, T, S_max) &&
+                     mel_workspace_bytes >= lasr_mel_workspace_bytes(Bm, lasr_mel_num_frames(L));
+  if (!fused) {
+    LASR_TRY(lasr_ctc_loss(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, ctc_workspace_bytes, stream));
+    return lasr_mel_fwd(wave, sample_lens, dither, aug, Bm, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, mel_workspace,
+                        mel_workspace_bytes, stream);
+  }
+  LASR_CHECK_SHAPE(blank >= 0 && blank < C, "lasr_ctc_loss_mel: blank");
+  LASR_TRY(init_tables());
+  const int64_t Tm = lasr_mel_num_frames(L);
+  MelCtcArgs a;
+  const size_t ab = (size_t)B * T * 64 * 4;
+  a.logp = logp; a.targets = targets; a.in_lens = in_lens; a.tgt_lens = tgt_lens; a.T = T; a.C = C; a.S_max = sm; a.blank = blank;
+  a.alpha = reinterpret_cast<float*>(ctc_workspace);
+  a.beta = a.alpha + ab;
+  a.next_same = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctc_workspace) + align_up(2 * ab * sizeof(float), 256));
+  a.nll = nll; a.n_ctc = (int)B;
+  a.wave = wave; a.sample_lens = sample_lens; a.dither = dither; a.aug = aug; a.L = L; a.Tm = Tm;
+  a.db_out = reinterpret_cast<float*>(mel_workspace);
+  a.partials = reinterpret_cast<double*>(reinterpret_cast<char*>(mel_workspace) + align_up((size_t)Bm * Tm * kMel * sizeof(float), 256));
+  a.frames_out = frames_out; a.pct_out = pct_out;
+  const int nblk = (int)cdiv(Tm, kFramesPerBlock);
+  a.nbx = nblk;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_ctc_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  hipLaunchKernelGGL(mel_ctc_kernel<4>, dim3((unsigned)(B + (int64_t)nblk * Bm)), dim3(256), lds, as_stream(stream), a);
+  LASR_LAUNCH_CHECK("mel_ctc_kernel");
+  if (grad) LASR_TRY(launch_ctc_grad(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, stream));
+  dim3 grid(nblk, (unsigned)Bm);
+  if (dtype == LASR_F32)
+    hipLaunchKernelGGL(mel_norm_kernel<float>, grid, dim3(256), 0, as_stream(stream), a.db_out, a.partials, frames_out, Tm, nblk, normalize,
+                       out_bft, reinterpret_cast<float*>(out_btf));
+  else
+    hipLaunchKernelGGL(mel_norm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), a.db_out, a.partials, frames_out, Tm, nblk, normalize,
+                       out_bft, reinterpret_cast<bf16_t*>(out_btf));
   LASR_LAUNCH_CHECK("mel_norm_kernel");
   return 0;
 }

@@ -94,6 +94,12 @@ struct lasr_model {
   bool planned = false;
   int bwd_cur = 0;       // ping-pong index of the gradient buffers between partial backward calls
   int bwd_next = -1;     // next unit a lasr_model_backward_continue call would process (-1: nothing pending)
+  // one-shot feature prefetch consumed by the next loss_backward call (lasr_model_set_prefetch)
+  struct Prefetch {
+    bool armed = false;
+    const float* wave; const int32_t* sample_lens; const float* dither; const int32_t* aug;
+    int64_t B, L; int normalize; void* out_btf; int dtype; int32_t* frames_out; float* pct_out; void* ws; size_t ws_bytes;
+  } prefetch;
 
   int64_t add_tensor(const std::string& name, std::initializer_list<int64_t> shape, int kind) {
     TensorInfo t;
@@ -282,6 +288,20 @@ extern "C" int lasr_model_create(const lasr_model_config* cfg, lasr_model_t** ou
 }
 
 extern "C" void lasr_model_destroy(lasr_model_t* m) { delete m; }
+
+extern "C" int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
+                                       const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
+                                       int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes) {
+  LASR_CHECK_ARG(m && wave && out_btf && frames_out && pct_out && mel_workspace, "lasr_model_set_prefetch: null pointer");
+  LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_model_set_prefetch: bad dtype");
+  LASR_CHECK_SHAPE(B > 0 && B < 65536 && L >= 2 && L < (1ll << 30), "lasr_model_set_prefetch: B=%lld L=%lld", (long long)B, (long long)L);
+  if (mel_workspace_bytes < lasr_mel_workspace_bytes(B, lasr_mel_num_frames(L))) return fail(LASR_E_WORKSPACE, "lasr_model_set_prefetch: workspace");
+  m->prefetch.armed = true;
+  m->prefetch.wave = wave; m->prefetch.sample_lens = sample_lens; m->prefetch.dither = dither; m->prefetch.aug = aug;
+  m->prefetch.B = B; m->prefetch.L = L; m->prefetch.normalize = normalize; m->prefetch.out_btf = out_btf; m->prefetch.dtype = dtype;
+  m->prefetch.frames_out = frames_out; m->prefetch.pct_out = pct_out; m->prefetch.ws = mel_workspace; m->prefetch.ws_bytes = mel_workspace_bytes;
+  return 0;
+}
 
 extern "C" int64_t lasr_model_tensor_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap, int64_t shape[4],
                                           int32_t* ndim, int32_t* kind, int64_t* offset) {
@@ -608,8 +628,17 @@ extern "C" int lasr_model_loss_backward(lasr_model_t* m, const float* params, fl
   const int C = m->cfg.n_class;
   // mean_b CTC(blank = C-1) with lengths int(T'*pct) (train.py:76-78); its gradient w.r.t. the
   // log-probs is (softmax - occupancy)/B, which log_softmax backward maps to itself.
-  LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
-                         nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
+  if (m->prefetch.armed) {   // this step's loss and the next step's features in one grid
+    const lasr_model::Prefetch pf = m->prefetch;
+    m->prefetch.armed = false;
+    LASR_TRY(lasr_ctc_loss_mel(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
+                               nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, pf.wave, pf.sample_lens, pf.dither,
+                               pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws,
+                               pf.ws_bytes, stream));
+  } else {
+    LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
+                           nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
+  }
   LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
   return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream);
 }
@@ -634,8 +663,17 @@ extern "C" int lasr_model_loss_backward_partial(lasr_model_t* m, const float* pa
   if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "lasr_model_loss_backward_partial: workspace %zu < %zu", ws_bytes, p.total);
   LASR_TRY(lasr_model_forward(m, params, buffers, feats, pct, B, T_in, 1, logp_out, argmax_out, ws, ws_bytes, stream));
   const int C = m->cfg.n_class;
-  LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
-                         nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
+  if (m->prefetch.armed) {   // this step's loss and the next step's features in one grid
+    const lasr_model::Prefetch pf = m->prefetch;
+    m->prefetch.armed = false;
+    LASR_TRY(lasr_ctc_loss_mel(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
+                               nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, pf.wave, pf.sample_lens, pf.dither,
+                               pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws,
+                               pf.ws_bytes, stream));
+  } else {
+    LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
+                           nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
+  }
   LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
   return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream, true, -1, (int)unit_stop);
 }

@@ -38,6 +38,7 @@ class TrainStep:
         self._reduced = False
         # exercise the staged + async all-reduce path on a 1-rank group too (validation on one GPU)
         self.force_staged = bool(int(__import__("os").environ.get("LASR_FORCE_OVERLAP", "0"))) and torch.distributed.is_initialized()
+        self._prefetched = None    # (key, feats, pct) of the batch announced by the previous step(prefetch_wave=...)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP wrap-time broadcast of parameters and buffers from rank 0."""
@@ -82,6 +83,25 @@ class TrainStep:
         self.optimizer_step()
         return loss, nll, logp, am
 
-    def step(self, wave, targets, tgt_lens, sample_lens=None, dither=None, aug=None):
-        feats, pct = self.features(wave, sample_lens, dither, aug)
-        return self.step_features(feats, pct, targets, tgt_lens)
+    @staticmethod
+    def _prefetch_key(wave, sample_lens, dither, aug):
+        return tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None for t in (wave, sample_lens, dither, aug))
+
+    def step(self, wave, targets, tgt_lens, sample_lens=None, dither=None, aug=None, prefetch_wave=None, prefetch_lens=None,
+             prefetch_dither=None, prefetch_aug=None):
+        """One training step on `wave`.  prefetch_wave: the NEXT step's waveforms (already in HBM): their log-mel features are
+        computed during this step in the grid of the CTC lattice kernel (32 busy workgroups, 224 idle CUs for ~0.1 ms) and
+        picked up by the next call if it passes the same tensors - the data-loader prefetch of the reference's workers;
+        every step still computes exactly one batch of features."""
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None and pf[0] == self._prefetch_key(wave, sample_lens, dither, aug):
+            feats, pct = pf[1], pf[2]
+        else:
+            feats, pct = self.features(wave, sample_lens, dither, aug)
+        nxt = None
+        if prefetch_wave is not None:
+            nf, npct = self.model.arm_prefetch(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug)
+            nxt = (self._prefetch_key(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug), nf, npct)
+        out = self.step_features(feats, pct, targets, tgt_lens)
+        self._prefetched = nxt
+        return out

@@ -85,3 +85,31 @@ def test_two_ranks_match_averaged_gradients(dev):
     assert torch.isfinite(got).all()
     assert ((got - ref).norm() / ref.norm()).item() < 1e-6
     assert (got - ref).abs().max().item() < 1e-5
+
+
+def test_feature_prefetch_is_bit_identical(dev):
+    """TrainStep.step(prefetch_wave=...) computes the next batch's log-mel in the grid of this step's CTC lattice kernel
+    (lasr_ctc_loss_mel); the training trajectory must not change by a bit - also when the next call brings a different
+    batch than announced."""
+    from lightning_asr_amd.engine import NativeModel
+    from lightning_asr_amd.step import TrainStep
+    batches = [tuple(t.to(dev) for t in _batch(0, s)) for s in range(4)]
+
+    def run(prefetch):
+        m = NativeModel("plain", 28, mask=True, act="relu", dtype=torch.bfloat16, device=dev)
+        m.init_parameters(seed=3)
+        ts = TrainStep(m, 1e-2, 1e-3)
+        losses = []
+        for s, (wave, tg, tl) in enumerate(batches):
+            nxt = None
+            if prefetch and s + 1 < len(batches):
+                nxt = batches[s + 1][0] if s != 1 else batches[0][0]      # step 1 announces the WRONG next batch
+            loss, *_ = ts.step(wave, tg, tl, prefetch_wave=nxt)
+            losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        return m.params.clone(), losses
+
+    p0, l0 = run(False)
+    p1, l1 = run(True)
+    assert l0 == l1
+    assert torch.equal(p0, p1)
