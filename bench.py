@@ -4,6 +4,9 @@ audio-seconds/sec of training, asr13x1, bs=32/GPU, 10 s 16 kHz synthetic clips.
 
 A "step" is one full pass of the hot path over one batch already resident in HBM:
     wave -> log-mel -> forward -> mean CTC -> backward -> grad all-reduce (N>1) -> NovoGrad -> LR step.
+By default the log-mel stage is software-pipelined across steps like a data-loader prefetch: step i computes the
+features of step i+1's waveforms inside its CTC launch (one batch of features per step either way; --no-prefetch
+puts them back at the head of the step).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16]
 N>1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
@@ -119,15 +122,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Every step computes the log-mel features of one batch: with the prefetch (default) those of the NEXT step's waveforms,
-    # in the grid of this step's CTC lattice kernel (the data-loader prefetch; same work per step, same results).
-    pf = wave if args.prefetch else None
+    # Two alternating synthetic batches.  Every step computes the log-mel features of exactly one batch: with the prefetch
+    # (default) those of the NEXT step's waveforms, inside this step's CTC launch (lattice + feature workgroups in one grid -
+    # the data-loader prefetch of the reference's workers, on the GPU); the features a step trains on were produced by the
+    # step before it.  --no-prefetch computes them at the head of the step instead.  Same results either way.
+    batches = [(wave, tg, tl), synth_batch(B, int(CLIP_S * SR), S_TGT, 991234 + rank, dev)]
+    step_no = [0]
+
+    def one_step():
+        w, t_, l_ = batches[step_no[0] & 1]
+        nxt = batches[(step_no[0] + 1) & 1][0] if args.prefetch else None
+        step_no[0] += 1
+        return ts.step(w, t_, l_, prefetch_wave=nxt)
+
     for _ in range(args.warmup):
-        loss, *_ = ts.step(wave, tg, tl, prefetch_wave=pf)
+        loss, *_ = one_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, *_ = ts.step(wave, tg, tl, prefetch_wave=pf)
+        loss, *_ = one_step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -147,7 +160,7 @@ def main():
     if rank == 0:
         lib.lasr_prof_enable(1)
     for _ in range(n_prof):
-        ts.step(wave, tg, tl, prefetch_wave=pf)
+        one_step()
     torch.cuda.synchronize()
     if rank == 0:
         lib.lasr_prof_enable(0)
@@ -189,7 +202,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "asr13x1 QuartzNet-CTC train step, bs=%d/GPU, 10 s synthetic 16 kHz clips, labels.txt vocab "
                                "(C=28), HIP mel+conv+CTC+NovoGrad, random-init weights" % B,
-                   "global_batch": B * world, "clip_seconds": CLIP_S, "target_len": S_TGT, "parallelism": "dp%d" % world},
+                   "global_batch": B * world, "clip_seconds": CLIP_S, "target_len": S_TGT, "parallelism": "dp%d" % world,
+                   "feature_prefetch": bool(args.prefetch)},
         "final_loss": final_loss,
         "roofline": roofline,
     }
