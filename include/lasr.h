@@ -157,6 +157,12 @@ int lasr_gemm_batch_partials(const lasr_gemm_problem* probs, int n_probs, int dt
 int lasr_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float* coef, float* saved, int64_t C, int64_t n_rows, float eps,
                      float momentum, int training, void* stream);
+/* Eval mode (training = 0) coefficients of up to 64 BN layers in one launch: coef[c] = gamma*rstd,
+ * coef[C+c] = beta - running_mean*gamma*rstd with rstd = 1/sqrt(running_var + eps); the running statistics are read only. */
+typedef struct {
+  const float* gamma; const float* beta; const float* running_mean; const float* running_var; float* coef; int64_t C;
+} lasr_bn_eval_desc;
+int lasr_bn_eval_coef_many(const lasr_bn_eval_desc* descs, int n_descs, float eps, void* stream);
 
 /* Training-mode lasr_bn_finalize for one or two BN layers of the same width (a unit's main and residual
  * branch) straight from GEMM partial sums: fixed-order f64 column reduction + the same arithmetic, one

@@ -38,6 +38,7 @@ SIGNATURES = {
     "lasr_gemm_batch_workspace_bytes": (_sz, [_p, _i32, _i32]),
     "lasr_gemm_batch": (_i32, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _sz, _p]),
     "lasr_bn_finalize": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f32, _f32, _i32, _p]),
+    "lasr_bn_eval_coef_many": (_i32, [_p, _i32, _f32, _p]),
     "lasr_bn_act_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i64, _i32, _p]),
     "lasr_bn_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "lasr_bn_act_bwd_stats": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _sz, _p]),

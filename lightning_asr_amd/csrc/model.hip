@@ -366,6 +366,17 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
   LASR_TRY(lasr_mask_lengths(pct, B, T, lens, stream));
   if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
   void* scratch = at(ws, p.o_scratch);
+  if (!training) {   // eval: BN coefficients of all layers from the running statistics, one launch
+    std::vector<lasr_bn_eval_desc> descs;
+    for (const Unit& u : m->units) {
+      descs.push_back({params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar, atf(ws, u.o_coef), u.co});
+      if (u.has_res)
+        descs.push_back({params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean, buffers + u.bn_res.rvar,
+                         atf(ws, u.o_coef2), u.co});
+    }
+    for (size_t i = 0; i < descs.size(); i += 64)
+      LASR_TRY(lasr_bn_eval_coef_many(descs.data() + i, (int)std::min<size_t>(64, descs.size() - i), kBnEps, stream));
+  }
   const void* x = feats;
   int64_t Tx = T_in;
   for (const Unit& u : m->units) {
@@ -406,12 +417,14 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
         LASR_TRY(lasr_bn_finalize_partials(br, np, u.co, N, kBnEps, kBnMom, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, np, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
-        LASR_TRY(lasr_bn_finalize(stats, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
-                                  atf(ws, u.o_coef), atf(ws, u.o_saved), u.co, N, kBnEps, kBnMom, training, stream));
-        if (u.has_res)
-          LASR_TRY(lasr_bn_finalize(stats2, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
-                                    buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
-                                    training, stream));
+        if (training) {   // (eval: every layer's coefficients were computed by one launch before the loop)
+          LASR_TRY(lasr_bn_finalize(stats, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
+                                    atf(ws, u.o_coef), atf(ws, u.o_saved), u.co, N, kBnEps, kBnMom, training, stream));
+          if (u.has_res)
+            LASR_TRY(lasr_bn_finalize(stats2, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
+                                      buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), u.co, N, kBnEps, kBnMom,
+                                      training, stream));
+        }
       }
     }
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
