@@ -116,6 +116,19 @@ int lasr_gemm_ld(const void* A, int64_t lda, const void* B, int64_t ldb, void* C
                  int64_t M, int64_t N, int64_t K, int transA, int transB, const float* bias, int split_k, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* Eval-mode BN folded into the 1x1 convs:  for a unit  out = act(BN(mask(W u)) + BN_res(Wr x))  with
+ * eval coefficients (a, b), (a2, b2):   out = act([mask(u) | x] . [a W | a2 Wr]^T + (b + b2)).
+ *   lasr_fold_bn_weights_many: w_out [co][ci (+ci)] bf16 and bias_out [co] f32 for up to 32 units in one launch
+ *       (coef / coef2 = the [a | b] vectors of lasr_bn_eval_coef_many; w_res = coef2 = NULL without a residual branch);
+ *   lasr_gemm_dual: C[M][N] bf16 = act([A1 (rows past row_lens zeroed) | A2] . W^T + bias), A1 [M][K1], A2 [M][K2] bf16,
+ *       W [N][K1+K2] bf16; K1, K2 multiples of 64, everything 16-byte aligned.  One GEMM, no separate BN pass.   */
+typedef struct {
+  const float* w; const float* w_res; const float* coef; const float* coef2; void* w_out; float* bias_out; int64_t co, ci;
+} lasr_fold_desc;
+int lasr_fold_bn_weights_many(const lasr_fold_desc* descs, int n_descs, void* stream);
+int lasr_gemm_dual(const void* A1, int64_t K1, const void* A2, int64_t K2, const void* W, const float* bias, void* C,
+                   int64_t M, int64_t N, const int32_t* row_lens, int64_t rows_per_seq, int act, void* stream);
+
 /* Deferred reductions.  The split-K weight-gradient GEMMs and the depthwise weight gradient end in a small
  * "sum the partial slabs" kernel each; a backward stage can instead leave the slabs where they are and sum all of
  * them with ONE launch at its end:

@@ -72,6 +72,8 @@ SIGNATURES = {
     "lasr_cast_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
     "lasr_cast_pad_f32_to_bf16": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
     "lasr_gemm_ld": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _sz, _p]),
+    "lasr_fold_bn_weights_many": (_i32, [_p, _i32, _p]),
+    "lasr_gemm_dual": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i32, _p]),
     "lasr_colsum_workspace_bytes": (_sz, [_i64, _i64]),
     "lasr_colsum_f32": (_i32, [_p, _p, _i64, _i64, _p, _sz, _p]),
     "lasr_scale_sum_f32": (_i32, [_p, _i64, _f32, _p, _p]),

@@ -521,3 +521,53 @@ extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, in
   prof_end(tok, st);
   return rc;
 }
+
+// ---------------------------------------------------------------- folded eval form ------------------------------------
+namespace lasr {
+struct FoldMany { lasr_fold_desc d[32]; };
+// Wcat[o][0:ci] = bf16(a[o] W[o][i]), Wcat[o][ci:2ci] = bf16(a2[o] Wr[o][i]) (second part only with a residual branch),
+// bias[o] = b[o] (+ b2[o]);  a | b = coef[0:co] | coef[co:2co] of the eval-mode BN (lasr_bn_eval_coef_many)
+__global__ __launch_bounds__(256) void fold_bn_weights_kernel(FoldMany f) {
+  const lasr_fold_desc q = f.d[blockIdx.y];
+  const int64_t ld = q.w_res ? 2 * q.ci : q.ci;
+  const int64_t n = q.co * ld;
+  bf16_t* out = reinterpret_cast<bf16_t*>(q.w_out);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = i / ld, c = i - o * ld;
+    const float v = c < q.ci ? q.coef[o] * q.w[o * q.ci + c] : q.coef2[o] * q.w_res[o * q.ci + (c - q.ci)];
+    out[i] = f32_to_bf16(v);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t o = threadIdx.x; o < q.co; o += 256) q.bias_out[o] = q.coef[q.co + o] + (q.w_res ? q.coef2[q.co + o] : 0.f);
+}
+}  // namespace lasr
+
+extern "C" int lasr_fold_bn_weights_many(const lasr_fold_desc* descs, int n_descs, void* stream) {
+  LASR_CHECK_ARG(descs && n_descs >= 1 && n_descs <= 32, "lasr_fold_bn_weights_many: 1..32 layers");
+  lasr::FoldMany f;
+  for (int i = 0; i < n_descs; ++i) {
+    const lasr_fold_desc& q = descs[i];
+    LASR_CHECK_ARG(q.w && q.coef && q.w_out && q.bias_out && q.co > 0 && q.ci > 0 && (!q.w_res || q.coef2), "lasr_fold_bn_weights_many: bad layer");
+    f.d[i] = q;
+  }
+  hipLaunchKernelGGL(lasr::fold_bn_weights_kernel, dim3(256, (unsigned)n_descs), dim3(256), 0, as_stream(stream), f);
+  LASR_LAUNCH_CHECK("fold_bn_weights_kernel");
+  return 0;
+}
+
+extern "C" int lasr_gemm_dual(const void* A1, int64_t K1, const void* A2, int64_t K2, const void* W, const float* bias, void* C,
+                              int64_t M, int64_t N, const int32_t* row_lens, int64_t rows_per_seq, int act, void* stream) {
+  LASR_CHECK_ARG(A1 && A2 && W && bias && C, "lasr_gemm_dual: null pointer");
+  LASR_CHECK_ARG(!(row_lens && rows_per_seq <= 0), "lasr_gemm_dual: rows_per_seq");
+  LASR_CHECK_ARG(act == LASR_ACT_NONE || act == LASR_ACT_RELU || act == LASR_ACT_SWISH, "lasr_gemm_dual: act");
+  LASR_CHECK_SHAPE(M > 0 && N > 0 && K1 > 0 && K2 > 0, "lasr_gemm_dual: shape");
+  GemmArgs g;
+  g.A = A1; g.B = W; g.C = C; g.M = M; g.N = N; g.K = K1 + K2; g.lda = K1; g.ldb = K1 + K2; g.ldc = N;
+  g.bias = bias; g.addend = nullptr; g.row_lens = row_lens; g.rows_per_seq = rows_per_seq; g.stat_partials = nullptr; g.split_ws = nullptr;
+  g.k_per_split = K1 + K2; g.vecA = 1; g.vecB = 1;
+  hipStream_t st = as_stream(stream);
+  const int tok = prof_begin(LASR_PROF_GEMM, st, 2.0 * (double)M * N * (K1 + K2), (double)(M * (K1 + K2) + N * (K1 + K2) + M * N) * 2);
+  const int rc = launch_gemm_bf16_dual(g, A2, K2, K1, bias, act, st);
+  prof_end(tok, st);
+  return rc;
+}

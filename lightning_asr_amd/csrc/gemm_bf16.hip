@@ -36,6 +36,8 @@ struct Bf16Args {
   int M, N, K, lda, ldb, ldc, rows_per_seq, k_per_split;
   int gm, gn, gz;      // tile grid
   int vecA, vecB, vecC;
+  // folded eval form (DUAL instantiation only): A = [A | A2] along K, rows of the first part masked by row_lens, act in the epilogue
+  const bf16_t* A2; int lda2, K1, act;
 };
 // Up to two independent problems of the same kind in ONE launch (a unit's main + residual 1x1 conv, or
 // their two weight gradients): twice the workgroups per launch keeps two per CU resident for the
@@ -456,11 +458,24 @@ struct Cfg {
 // its chunk ks of the NEXT step from registers into the other LDS image and (re)issues the global load of
 // the step after that into the same registers, so LDS writes and VMEM issue ride in the MFMA shadows
 // instead of forming a separate all-waves staging phase in front of them.
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD>
+// A operand of the folded eval form: K range [0, K1) from A (rows past their utterance's length read as zero: km),
+// [K1, K) from A2; K1 and K - K1 are multiples of the K step, so a step lies in one operand
+__device__ __forceinline__ uint4 load_chunk_dual(const Bf16Args& g, int m0, int k0, int p, const uint32_t (&kma)[4]) {
+  const int c = threadIdx.x + big::NT * p;
+  const bool first = k0 < g.K1;                        // workgroup-uniform
+  const bf16_t* X = first ? g.A : g.A2;
+  const int ld = first ? g.lda : g.lda2;
+  const int kk = (first ? k0 : k0 - g.K1) + ((c & 7) << 3);
+  const uint4 v = *reinterpret_cast<const uint4*>(X + (uint32_t)min(m0 + (c >> 3), g.M - 1) * (uint32_t)ld + (uint32_t)kk);
+  const uint32_t mk = first ? kma[p] : 0xffffffffu;
+  return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
+}
+
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false>
 __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char* __restrict__ sB, char* __restrict__ dA,
                                          char* __restrict__ dB, f32x16 (&acc)[big::Cfg<NARROW>::MI][2], uint4 (&ra)[4],
                                          uint4 (&rb)[big::Cfg<NARROW>::NCB], const Bf16Args& g, int m0, int n0, int k_store,
-                                         int k_load, int kend, int wm, int wn, int lane) {
+                                         int k_load, int kend, int wm, int wn, int lane, const uint32_t (&kma)[4]) {
   using namespace big;
   using CF = Cfg<NARROW>;
   constexpr int MI = CF::MI;
@@ -493,7 +508,8 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
       else if (ks < CF::NCB) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks < CF::NCB ? ks : 0], k_store, kend, ks);
     }
     if constexpr (LOAD) {
-      ra[ks] = load_chunk<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, k_load, kend, ks);
+      if constexpr (DUAL) ra[ks] = load_chunk_dual(g, m0, k_load, ks, kma);
+      else ra[ks] = load_chunk<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, k_load, kend, ks);
       if constexpr (CF::NCB == 4) rb[ks] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
       else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
     }
@@ -511,7 +527,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 
 // one 256 x 256 (256 x 128) output tile `lid` of problem g; SLAB: split-K slice into the f32 slab g.split_ws (no LDS image,
 // no statistics) - shared by the two-problem kernel and the many-problem weight-gradient kernel
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB>
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB, bool DUAL = false>
 __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int lid) {
 #ifdef LASR_GEMM_STAMPS
   unsigned long long* stamps = g_stamps;
@@ -533,7 +549,7 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   if (tid < BTM) {
     const int m = m0 + tid;
     bool keep = m < g.M;
-    if (keep && g.row_lens) {
+    if (!DUAL && keep && g.row_lens) {   // (folded eval form: the mask is on the first A operand's rows instead)
       const int b = m / g.rows_per_seq;
       keep = (m - b * g.rows_per_seq) < g.row_lens[b];
     }
@@ -549,12 +565,31 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   uint4 ra[4], rb[CF::NCB];
-  load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
+  uint32_t kma[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // DUAL: row masks of this thread's four A chunks
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = min(m0 + ((tid + NT * p) >> 3), g.M - 1);
+      if (g.row_lens) {
+        const int b = m / g.rows_per_seq;
+        kma[p] = (m - b * g.rows_per_seq) < g.row_lens[b] ? 0xffffffffu : 0u;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ra[p] = load_chunk_dual(g, m0, kbeg, p, kma);
+  } else {
+    load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
+  }
   load_vec<TRANS_B, BTN, NT, CF::NCB>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
   store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
   store_vec<TRANS_B, BTN, NT, LD_KC, CF::LDRB, CF::NCB>(smem + OPER, rb, kbeg, kend);
   if (nk > 1) {
-    load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
+    if constexpr (DUAL) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) ra[p] = load_chunk_dual(g, m0, kbeg + TK, p, kma);
+    } else {
+      load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
+    }
     load_vec<TRANS_B, BTN, NT, CF::NCB>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
   }
   __syncthreads();
@@ -565,20 +600,20 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     for (; it + 2 < nk; ++it) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, NARROW, true, true>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
-                                             kbeg + (it + 2) * TK, kend, wm, wn, lane);
+      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
+                                             kbeg + (it + 2) * TK, kend, wm, wn, lane, kma);
       __syncthreads();
     }
     if (it + 1 < nk) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, NARROW, true, false>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
-                                              wm, wn, lane);
+      big_step<TRANS_A, TRANS_B, NARROW, true, false, DUAL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
+                                              wm, wn, lane, kma);
       __syncthreads();
       ++it;
     }
     const char* sA = smem + (it & 1) * BUF;
-    big_step<TRANS_A, TRANS_B, NARROW, false, false>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane);
+    big_step<TRANS_A, TRANS_B, NARROW, false, false, DUAL>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane, kma);
     __syncthreads();
   }
   LASR_STAMP(2);
@@ -640,6 +675,13 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
             const int col = nb + ni * 32 + 8 * j + 4 * half;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (col + e < g.N) ? g.bias[min(col + e, g.N - 1)] : 0.f;
+          }
+          if constexpr (DUAL) {                             // folded eval form: activation in the epilogue
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (g.act == LASR_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+              else if (g.act == LASR_ACT_SWISH) v[e] = v[e] / (1.f + __expf(-v[e]));
+            }
           }
           uint2 pk;
           pk.x = pack_bf16x2(v[0], v[1]) & km;
@@ -731,6 +773,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   gemm_bf16_big_tile<TRANS_A, TRANS_B, NARROW, false>(g, second ? lid_all - gb.tiles0 : lid_all);
 }
 
+// Folded eval form of a residual unit: out = act([u_masked | x] . [a W | a2 Wr]^T + (b + b2)), one problem per launch,
+// 256 x 128 tiles (a lone problem fills the chip only with the narrow tile).
+__global__ __launch_bounds__(512, 1) void gemm_bf16_dual_kernel(Bf16Batch gb) {
+  gemm_bf16_big_tile<false, false, true, false, true>(gb.p[0], xcd_remap(blockIdx.x, gb.total));
+}
+
 // The stage-batched 1x1 weight gradients on the 256 x 256 tile: C_i = A_i^T B_i with A_i [K][M_i], B_i [K][N_i]
 // (K = B*T' = 16 032 rows of dy and of the layer input), split-K slices into f32 slabs.  One workgroup per CU and
 // slice; the K loop of this tile runs at ~1.3 PFLOP/s against ~0.7 for the 128 x 128 form.
@@ -754,6 +802,7 @@ static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
   a.gn = (int)gn; a.gm = (int)gm; a.gz = gz;
   a.vecA = g.vecA; a.vecB = g.vecB;
   a.vecC = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0);
+  a.A2 = nullptr; a.lda2 = 0; a.K1 = 0; a.act = 0;
   return 0;
 }
 
@@ -813,6 +862,23 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
 #undef LASR_BF16_TC
 #undef LASR_BF16_CASE
   LASR_LAUNCH_CHECK("gemm_bf16_kernel");
+  return 0;
+}
+
+int launch_gemm_bf16_dual(const GemmArgs& g, const void* A2, int64_t lda2, int64_t K1, const float* bias, int act, hipStream_t st) {
+  if (K1 <= 0 || K1 >= g.K || K1 % TK || (g.K - K1) % TK || lda2 % 8 || g.lda % 8 || g.ldb % 8 || g.ldc % 8 ||
+      reinterpret_cast<uintptr_t>(g.A) % 16 || reinterpret_cast<uintptr_t>(A2) % 16 || reinterpret_cast<uintptr_t>(g.B) % 16 ||
+      reinterpret_cast<uintptr_t>(g.C) % 16 || !bias)
+    return fail(LASR_E_SHAPE, "lasr_gemm_dual: K parts must be multiples of %d, pitches of 8, pointers 16-byte aligned, bias given", TK);
+  Bf16Batch b;
+  LASR_TRY(fill_args(b.p[0], g, big::BTM, 128, 1));
+  b.p[0].A2 = reinterpret_cast<const bf16_t*>(A2); b.p[0].lda2 = (int)lda2; b.p[0].K1 = (int)K1; b.p[0].act = act;
+  b.p[0].bias = bias;
+  b.p[1] = b.p[0];
+  b.tiles0 = b.p[0].gn * b.p[0].gm;
+  b.total = b.tiles0;
+  hipLaunchKernelGGL(gemm_bf16_dual_kernel, dim3((unsigned)b.total), dim3(big::NT), 0, st, b);
+  LASR_LAUNCH_CHECK("gemm_bf16_dual_kernel");
   return 0;
 }
 

@@ -64,6 +64,7 @@ struct Unit {
   // workspace offsets (bytes) filled by plan()
   size_t o_u = 0, o_y = 0, o_y2 = 0, o_out = 0, o_coef = 0, o_saved = 0, o_coef2 = 0, o_saved2 = 0, o_stats = 0, o_stats2 = 0;
   size_t o_se_sum = 0, o_se_pool = 0, o_se_hid = 0, o_se_scale = 0, o_se_grad = 0;   // SE: [B][co] (hid: [B][co/8]) f32
+  size_t o_wfold = 0, o_bfold = 0;   // eval: folded [a W | a2 Wr] bf16 and b + b2 (residual units)
   size_t o_wgp = 0, wgp_bytes = 0, o_dwp = 0, dwp_bytes = 0, o_dy = 0, o_dy2 = 0;   // deferred reductions: split-K slabs of dW / dWr, depthwise-dW partials
 };
 
@@ -243,6 +244,12 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   p.o_logits = take(cur, (size_t)N * C * sizeof(float));
   p.o_glogits = take(cur, (size_t)N * C * sizeof(float));
   p.o_nll = take(cur, (size_t)(B + 1) * sizeof(float));
+  for (Unit& u : m->units) {   // eval-mode folded weights
+    if (u.has_res) {
+      u.o_wfold = take(cur, (size_t)u.co * 2 * u.ci * sizeof(bf16_t));
+      u.o_bfold = take(cur, (size_t)u.co * sizeof(float));
+    }
+  }
   for (Unit& u : m->units) {   // slabs that outlive `scratch`: summed by one lasr_reduce_many per backward stage
     {
       u.wgp_bytes = (u.has_res ? 2 : 1) * lasr_gemm_workspace_bytes(u.co, u.ci, wgrad_split(), 0);
@@ -352,6 +359,13 @@ static inline const void* wptr(const lasr_model* m, const float* params, void* w
   return params + off;
 }
 
+// eval-mode folding (LASR_NO_EVAL_FOLD=1: the unfolded eval path, for A/B runs and the parity test)
+static bool eval_fold(int dtype) {
+  static const bool off = getenv("LASR_NO_EVAL_FOLD") != nullptr;
+  return !off && dtype == LASR_BF16;
+}
+static bool fold_unit(const Unit& u) { return u.has_res && u.has_dw && !u.has_se && !u.ctx_before && u.ci % 64 == 0 && u.co % 8 == 0; }
+
 extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
                                   int64_t B, int64_t T_in, int training, float* logp_out, int32_t* argmax_out, void* ws,
                                   size_t ws_bytes, void* stream) {
@@ -376,6 +390,14 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
     }
     for (size_t i = 0; i < descs.size(); i += 64)
       LASR_TRY(lasr_bn_eval_coef_many(descs.data() + i, (int)std::min<size_t>(64, descs.size() - i), kBnEps, stream));
+    if (eval_fold(m->cfg.dtype)) {   // BN folded into the residual units' 1x1 convs: one launch for all of them
+      std::vector<lasr_fold_desc> fd;
+      for (const Unit& u : m->units)
+        if (fold_unit(u))
+          fd.push_back({params + u.w_pw, params + u.w_res, atf(ws, u.o_coef), atf(ws, u.o_coef2), at(ws, u.o_wfold), atf(ws, u.o_bfold), u.co, u.ci});
+      for (size_t i = 0; i < fd.size(); i += 32)
+        LASR_TRY(lasr_fold_bn_weights_many(fd.data() + i, (int)std::min<size_t>(32, fd.size() - i), stream));
+    }
   }
   const void* x = feats;
   int64_t Tx = T_in;
@@ -395,6 +417,15 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
     if (u.has_dw) {
       LASR_TRY(lasr_dwconv_fwd(x, params + u.w_dw, nullptr, at(ws, u.o_u), dt, B, Tx, u.ci, u.k, u.stride, 0, stream));
       gin = at(ws, u.o_u);
+    }
+    if (!training && eval_fold(dt) && fold_unit(u)) {
+      // out = act([mask(u) | x] . [a W | a2 Wr]^T + (b + b2)): the unit's two 1x1 convs, both BatchNorms, the residual add and
+      // the activation as ONE GEMM (no y / y2 round trip, no BN pass)
+      LASR_TRY(lasr_gemm_dual(gin, u.ci, x, u.ci, at(ws, u.o_wfold), atf(ws, u.o_bfold), at(ws, u.o_out), N, u.co, u.masked ? lens : nullptr,
+                              T, u.act ? m->cfg.act : LASR_ACT_NONE, stream));
+      x = at(ws, u.o_out);
+      Tx = T;
+      continue;
     }
     float* stats = training ? atf(ws, u.o_stats) : nullptr;
     float* stats2 = (training && u.has_res) ? atf(ws, u.o_stats2) : nullptr;

@@ -183,6 +183,34 @@ def dwconv_bwd_fused(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, addend:
     return dw, dx
 
 
+class _FoldDesc(_lib.C.Structure):
+    _fields_ = [("w", _lib.C.c_void_p), ("w_res", _lib.C.c_void_p), ("coef", _lib.C.c_void_p), ("coef2", _lib.C.c_void_p),
+                ("w_out", _lib.C.c_void_p), ("bias_out", _lib.C.c_void_p), ("co", _lib.C.c_int64), ("ci", _lib.C.c_int64)]
+
+
+def fold_bn_weights(w: torch.Tensor, coef: torch.Tensor, w_res: Optional[torch.Tensor] = None, coef2: Optional[torch.Tensor] = None):
+    """Eval-mode BN folded into 1x1 conv weights: ([a W | a2 Wr] bf16 (co, ci (+ci)), b (+ b2) f32 (co)); coef = [a | b]."""
+    co, ci = w.shape[0], w.shape[1]
+    wout = torch.empty(co, ci * (2 if w_res is not None else 1), dtype=torch.bfloat16, device=w.device)
+    bias = torch.empty(co, dtype=torch.float32, device=w.device)
+    d = (_FoldDesc * 1)()
+    d[0].w, d[0].w_res, d[0].coef, d[0].coef2 = _p(w), _p(w_res), _p(coef), _p(coef2)
+    d[0].w_out, d[0].bias_out, d[0].co, d[0].ci = _p(wout), _p(bias), co, ci
+    call("lasr_fold_bn_weights_many", d, 1, _stream())
+    return wout, bias
+
+
+def gemm_dual(a1: torch.Tensor, a2: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, row_lens: Optional[torch.Tensor] = None,
+              rows_per_seq: int = 0, act: str = "relu") -> torch.Tensor:
+    """act([a1 (rows past row_lens zeroed) | a2] @ w.T + bias): a1 (M, K1), a2 (M, K2), w (N, K1 + K2) bf16 -> (M, N) bf16."""
+    M, K1 = a1.shape
+    K2 = a2.shape[1]
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a1.device)
+    call("lasr_gemm_dual", _p(a1), K1, _p(a2), K2, _p(w), _p(bias), _p(out), M, N, _p(row_lens), rows_per_seq, ACT[act], _stream())
+    return out
+
+
 def bn_finalize(stats, gamma, beta, running_mean, running_var, n_rows: int, eps: float = 1e-3, momentum: float = 0.1,
                 training: bool = True):
     Cc = gamma.numel()

@@ -639,3 +639,58 @@ def test_ctc_random_sweep_vs_torch(dev):
         assert ((nll.cpu() - ref.detach()).abs() <= 1e-4 * ref.detach().abs() + 1e-5).all(), (case, nll.cpu(), ref)
         gref = lpr.grad
         assert (grad.cpu() - gref).abs().max() < 2e-3 * gref.abs().max() + 1e-6, case
+
+
+@pytest.mark.parametrize("B,T,ci,co,act", [(32, 501, 256, 256, "relu"), (5, 77, 512, 512, "relu"), (3, 130, 256, 512, "swish"), (2, 40, 64, 72, "none")])
+def test_folded_eval_unit_gemm(dev, B, T, ci, co, act):
+    """Eval-mode BN folded into a residual unit's two 1x1 convs (lasr_fold_bn_weights_many + lasr_gemm_dual):
+    act([mask(u) | x] . [a W | a2 Wr]^T + b + b2) against the same expression in f64 from the folded bf16 weights, and
+    the folded weights against a*W in f32."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(ci + co + T)
+    M = B * T
+    u = torch.randn(M, ci, generator=g).bfloat16()
+    x = torch.randn(M, ci, generator=g).bfloat16()
+    W, Wr = torch.randn(co, ci, generator=g) / math.sqrt(ci), torch.randn(co, ci, generator=g) / math.sqrt(ci)
+    coef = torch.cat([1 + 0.2 * torch.randn(co, generator=g), 0.3 * torch.randn(co, generator=g)])
+    coef2 = torch.cat([1 + 0.2 * torch.randn(co, generator=g), 0.3 * torch.randn(co, generator=g)])
+    lens = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    wcat, bias = ops.fold_bn_weights(W.to(dev), coef.to(dev), Wr.to(dev), coef2.to(dev))
+    ref_w = torch.cat([coef[:co, None] * W, coef2[:co, None] * Wr], 1)
+    assert (wcat.cpu().float() - ref_w).abs().max() <= 4e-3 * ref_w.abs().max()
+    assert torch.allclose(bias.cpu(), coef[co:] + coef2[co:], atol=1e-6)
+    out = ops.gemm_dual(u.to(dev), x.to(dev), wcat, bias, lens.to(dev), T, act)
+    keep = (torch.arange(T).view(1, T) < lens.view(B, 1)).reshape(M, 1).double()
+    z = torch.cat([u.double() * keep, x.double()], 1) @ wcat.cpu().double().t() + bias.cpu().double()
+    ref = {"relu": torch.relu, "swish": lambda v: v * torch.sigmoid(v), "none": lambda v: v}[act](z)
+    assert (out.cpu().double() - ref).abs().max() <= 4e-3 * ref.abs().max() + 1e-6
+
+
+def test_eval_forward_folded_matches_unfolded(dev, tmp_path):
+    """lasr_model_forward(training=0) with the folded units (default) against LASR_NO_EVAL_FOLD=1 in a child process: the
+    same bf16 network up to where the per-channel scale is rounded (into the weights, or after the bf16 pre-activation)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from lightning_asr_amd.engine import NativeModel\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "m = NativeModel('plain', 28, mask=True, act='relu', dtype=torch.bfloat16, device=torch.device('cuda'))\n"
+        "m.init_parameters(seed=1)\n"
+        "m.buffers.copy_((0.5 + torch.rand(m.buffers.shape, generator=g)).to(m.buffers.device))\n"
+        "feats = torch.randn(3, 401, 64, generator=g).bfloat16().cuda(); pct = torch.tensor([1.0, 0.8, 0.35]).cuda()\n"
+        "out = m.forward(feats, pct, training=False)\n"
+        "torch.save((out[0] if isinstance(out, (tuple, list)) else out).float().cpu(), sys.argv[1])\n" % ROOT)
+    outs = []
+    for fold in (True, False):
+        env = dict(os.environ)
+        if not fold:
+            env["LASR_NO_EVAL_FOLD"] = "1"
+        path = str(tmp_path / ("logp_%d.pt" % fold))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+        outs.append(torch.load(path))
+    assert torch.isfinite(outs[0]).all()
+    assert (outs[0] - outs[1]).abs().max() < 0.08              # log-probabilities of a 15-unit bf16 network
+    assert (outs[0].argmax(-1) == outs[1].argmax(-1)).float().mean() > 0.97
