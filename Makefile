@@ -8,9 +8,12 @@ CXXFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Wall -Wno-unused-functi
 lightning_asr_amd/liblasr.so: $(OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
-build/%.o: lightning_asr_amd/csrc/%.hip lightning_asr_amd/csrc/common.h lightning_asr_amd/csrc/ctc_lattice.h include/lasr.h
+# -MMD: every header a source includes (common.h, gemm.h, ctc_lattice.h, include/lasr.h ...) is a prerequisite of its object
+build/%.o: lightning_asr_amd/csrc/%.hip
 	@mkdir -p build
-	$(HIPCC) $(CXXFLAGS) -c $< -o $@
+	$(HIPCC) $(CXXFLAGS) -MMD -MP -MF build/$*.d -c $< -o $@
+
+-include $(OBJ:.o=.d)
 
 clean:
 	rm -rf build lightning_asr_amd/liblasr.so

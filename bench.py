@@ -1,14 +1,20 @@
 #!/usr/bin/env python
-"""Throughput of the QuartzNet-CTC training hot path on MI355X (BASELINE.json metric):
-audio-seconds/sec of training, asr13x1, bs=32/GPU, 10 s 16 kHz synthetic clips.
+"""Throughput of the QuartzNet-CTC training hot path on MI355X (BASELINE.json metric): audio-seconds/sec of training.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg4|cfg5] [--dtype bf16|f32]
+
+  cfg2 (default; the configuration BASELINE.json's metric is quoted on): asr13x1, bs=32/GPU, 10 s 16 kHz clips, labels.txt (C=28)
+  cfg4: QuartNetContextSE (SE + BiLSTM context block), bs=32, 10 s clips, C=28
+  cfg5: asr13x1 with the AISHELL character vocabulary (data/aishell1-vocab.txt, C=4334), bs=32, variable-length 2-16 s clips in
+        length buckets (<= 10 % padding); audio-seconds count the REAL (unpadded) audio
 
 A "step" is one full pass of the hot path over one batch already resident in HBM:
     wave -> log-mel -> forward -> mean CTC -> backward -> grad all-reduce (N>1) -> NovoGrad -> LR step.
-By default the log-mel stage is software-pipelined across steps like a data-loader prefetch: step i computes the
-features of step i+1's waveforms inside its CTC launch (one batch of features per step either way; --no-prefetch
-puts them back at the head of the step).
+Not in the timed step (stated in config.excluded): the H2D copy of the PCM (20 MB/step at cfg2, ~0.35 ms at 63 GB/s) and the
+per-step greedy decode + WER logging that the reference's training_step does for its progress bar (train.py:80).
+By default the log-mel stage is software-pipelined across steps like a data-loader prefetch: step i computes the features of
+step i+1's waveforms inside its CTC launch (one batch of features per step either way; --no-prefetch puts them back at the head).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16]
 N>1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
 Prints ONE JSON line on rank 0.
 """
@@ -16,6 +22,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -26,45 +33,145 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CLIP_S = 10.0
 SR = 16000
-V = 27                       # data/labels.txt
-S_TGT = 100                  # target length for 10 s clips
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_MFMA_TF = 157.3     # dense f32-input MFMA
 PEAK_BF16_MFMA_TF = 2500.0   # dense bf16 MFMA
 
+CONFIGS = {
+    "cfg2": {"variant": "plain", "vocab": "data/labels.txt", "clip_s": 10.0, "ragged": False,
+             "workload": "asr13x1 QuartzNet-CTC train step, bs=%d/GPU, 10 s synthetic 16 kHz clips, labels.txt vocab (C=28)"},
+    "cfg4": {"variant": "context_se", "vocab": "data/labels.txt", "clip_s": 10.0, "ragged": False,
+             "workload": "QuartNetContextSE (SE + BiLSTM context block) train step, bs=%d/GPU, 10 s synthetic 16 kHz clips, labels.txt vocab (C=28)"},
+    "cfg5": {"variant": "plain", "vocab": "data/aishell1-vocab.txt", "clip_s": None, "ragged": True,
+             "workload": "asr13x1 train step, AISHELL char vocab (C=4334), bs=%d/GPU, variable-length 2-16 s synthetic clips in 8 length "
+                         "buckets (<=10%% padding), audio-seconds = unpadded audio"},
+}
 
-def synth_batch(B: int, n_samples: int, S: int, seed: int, device):
-    """wave = 0.1 N(0,1); targets U{0..V-1} without adjacent repeats (always CTC-feasible)."""
-    g = torch.Generator().manual_seed(seed)
-    wave = 0.1 * torch.randn(B, n_samples, generator=g)
+
+def vocab_size(path: str) -> int:
+    with open(os.path.join(ROOT, path), encoding="utf-8") as f:
+        return sum(1 for _ in f)
+
+
+def _targets(B, S, V, g):
     tg = torch.randint(0, V, (B, S), generator=g)
     for s in range(1, S):
         same = tg[:, s] == tg[:, s - 1]
         tg[same, s] = (tg[same, s] + 1) % V
-    return wave.to(device), tg.long().to(device), torch.full((B,), S, dtype=torch.int32, device=device)
+    return tg.long()
 
 
-def cpu_baseline(n_clips: int = 8, steps: int = 3):
-    """The CPU oracle (oracle/ref_cpu.py, a port of the reference's path) timed on this box's host
-    cores on a bounded sample of the same workload: n_clips x 10 s clips, features precomputed,
-    fwd + CTC + bwd + NovoGrad."""
+def synth_batch(B: int, n_samples: int, S: int, seed: int, device, V: int = 27):
+    """wave = 0.1 N(0,1); targets U{0..V-1} without adjacent repeats (always CTC-feasible)."""
+    g = torch.Generator().manual_seed(seed)
+    wave = 0.1 * torch.randn(B, n_samples, generator=g)
+    tg = _targets(B, S, V, g)
+    return wave.to(device), tg.to(device), torch.full((B,), S, dtype=torch.int32, device=device)
+
+
+def synth_buckets(B: int, n_buckets: int, V: int, seed: int, device, lo_s: float = 2.0, hi_s: float = 16.0):
+    """L ~ U{2 s .. 16 s}, sorted into length buckets of B clips; targets S = floor(2.8 * seconds).
+    Returns [(wave (B, Lmax) zero-padded, sample_lens (B) i32, targets (B, Smax), target_lens (B) i32, real_seconds)]."""
+    g = torch.Generator().manual_seed(seed)
+    n = B * n_buckets
+    lens = torch.randint(int(lo_s * SR), int(hi_s * SR) + 1, (n,), generator=g).sort().values
+    out = []
+    for k in range(n_buckets):
+        l = lens[k * B:(k + 1) * B]
+        Lmax = int(l.max())
+        wave = 0.1 * torch.randn(B, Lmax, generator=g)
+        wave *= (torch.arange(Lmax).unsqueeze(0) < l.unsqueeze(1))
+        tl = (l.float() / SR * 2.8).floor().int().clamp(min=1)
+        tg = _targets(B, int(tl.max()), V, g)
+        out.append((wave.to(device), l.int().to(device), tg.to(device), tl.to(device), float(l.sum()) / SR,
+                    1.0 - float(l.sum()) / (B * Lmax)))
+    return out
+
+
+def source_id() -> str:
+    """hash of the kernel sources: ties a PMC traffic file under profiles/ to the build it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lightning_asr_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/lasr.h"]:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name: str, V: int):
+    """The CPU oracle (oracle/ref_cpu.py, the pinned restatement of the reference's path) timed on this box's host cores
+    (SURVEY 8d protocol): f32, features precomputed, fwd / CTC / bwd / NovoGrad timed separately, >= 3 warm-up + >= 5 timed
+    steps on the SAME batch shape as the GPU workload where that fits ~30 s of CPU work (cfg2/cfg4: B=32 x 10 s), thread count
+    chosen by a short sweep over the cores this process may use, CPU model string reported."""
     from oracle import ref_cpu as R
+    cfg = CONFIGS[cfg_name]
     torch.manual_seed(0)
-    wave, tg, tl = R.synth_batch(n_clips, int(CLIP_S * SR), S_TGT, V, 1234)
-    feats = torch.stack([R.parse_wave(wave[i:i + 1])[0] for i in range(n_clips)]).unsqueeze(1)
-    pct = torch.ones(n_clips)
-    model = R.OracleModel("plain", V + 1, mask=True, state=R.random_state("plain", V + 1, 0))
+    if cfg["ragged"]:
+        B, warm, steps = 8, 1, 3
+        bk = synth_buckets(B, 3, V, 4321, "cpu")[1]            # the middle bucket of 24 clips: ~9 s clips
+        wave, slens, tg, tl, real_s = bk[0], bk[1], bk[2], bk[3], bk[4]
+        feats_l = [R.parse_wave(wave[i:i + 1, :int(slens[i])]) for i in range(B)]
+        feats, _, pct, _ = R.collate(feats_l, [tg[i, :int(tl[i])].tolist() for i in range(B)])
+        sample = "%d clips of one length bucket (%.1f s of audio, %.0f %% padding)" % (B, real_s, 100 * bk[5])
+    else:
+        B, warm, steps = 32, 3, 5
+        wave, tg, tl = R.synth_batch(B, int(cfg["clip_s"] * SR), 100, V, 1234)
+        feats = torch.stack([R.parse_wave(wave[i:i + 1])[0] for i in range(B)]).unsqueeze(1)
+        pct = torch.ones(B)
+        real_s = B * cfg["clip_s"]
+        sample = "%d x %.0f s clips (the GPU workload's batch)" % (B, cfg["clip_s"])
+    model = R.OracleModel(cfg["variant"], V + 1, mask=True, state=R.random_state(cfg["variant"], V + 1, 0))
     st = R.NovogradState(len(model.parameters()))
-    R.train_step(model, st, feats, tg, pct, tl, 1e-4)          # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        R.train_step(model, st, feats, tg, pct, tl, 1e-4)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": n_clips * CLIP_S / dt, "unit": "audio-seconds/sec", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": "%d x 10 s clips, %d steps of fwd+CTC+bwd+NovoGrad, f32, features precomputed"
-                                      % (n_clips, steps)}
+    params = model.parameters()
+
+    def step():
+        model.training = True
+        model.requires_grad_(True)
+        for p in params:
+            p.grad = None
+        t0 = time.perf_counter()
+        lp = model.forward(feats, pct)
+        t1 = time.perf_counter()
+        loss = R.training_loss(lp, tg, pct, tl, blank=V)
+        t2 = time.perf_counter()
+        loss.backward()
+        t3 = time.perf_counter()
+        R.novograd_step([p.data for p in params], [p.grad for p in params], st, 1e-4, 0.8, 0.5, 1e-8, 1e-3)
+        t4 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2, t4 - t3
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    sweep = {}
+    for n in sorted({min(avail, n) for n in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(n)
+        step()
+        sweep[n] = sum(step())
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for _ in range(max(0, warm - 2)):
+        step()
+    parts = [step() for _ in range(steps)]
+    dt = sum(sum(p) for p in parts) / steps
+    names = ("fwd", "ctc_fwd", "bwd", "novograd")
+    return {"value": real_s / dt, "unit": "audio-seconds/sec", "cores": best, "kind": "port",
+            "sample": "%s, %d warm-up + %d timed steps of fwd+CTC+bwd+NovoGrad, f32, features precomputed" % (sample, warm, steps),
+            "cpu_model": cpu_model(), "cores_available": avail, "s_per_step": dt,
+            "split_s": {k: sum(p[i] for p in parts) / steps for i, k in enumerate(names)},
+            "thread_sweep_s_per_step": {str(k): v for k, v in sweep.items()}}
 
 
 def main():
@@ -72,6 +179,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)      # >= 10 warm-up, >= 50 timed steps
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default=os.environ.get("LASR_BENCH_CONFIG", "cfg2"), choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default=os.environ.get("LASR_BENCH_DTYPE", "bf16"), choices=["f32", "bf16"],
                     help="activation dtype: bf16 (BASELINE config) or f32 (exact parity mode)")
     ap.add_argument("--batch", type=int, default=32)
@@ -79,6 +187,7 @@ def main():
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="compute each step's features at the head of the step instead of inside the previous step's CTC launch")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,49 +216,64 @@ def main():
     from lightning_asr_amd.schedule import CosineAnnealingWarmupRestarts
     from lightning_asr_amd.step import TrainStep
 
+    V = vocab_size(cfg["vocab"])
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    model = NativeModel("plain", V + 1, mask=True, act="relu", dtype=dtype, device=dev)
+    model = NativeModel(cfg["variant"], V + 1, mask=True, act="relu", dtype=dtype, device=dev)
     model.init_parameters(seed=0)                               # pl.seed_everything(0), train.py:203
     sched = CosineAnnealingWarmupRestarts(None, first_cycle_steps=100 * 1000, cycle_mult=2, max_lr=1e-2, min_lr=1e-4,
                                           warmup_steps=1000, gamma=0.5)
     ts = TrainStep(model, 1e-2, 1e-3, schedule=sched)
     ts.broadcast_parameters()
     B = args.batch
-    wave, tg, tl = synth_batch(B, int(CLIP_S * SR), S_TGT, 1234 + rank, dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Two alternating synthetic batches.  Every step computes the log-mel features of exactly one batch: with the prefetch
-    # (default) those of the NEXT step's waveforms, inside this step's CTC launch (lattice + feature workgroups in one grid -
-    # the data-loader prefetch of the reference's workers, on the GPU); the features a step trains on were produced by the
-    # step before it.  --no-prefetch computes them at the head of the step instead.  Same results either way.
-    batches = [(wave, tg, tl), synth_batch(B, int(CLIP_S * SR), S_TGT, 991234 + rank, dev)]
+    # Synthetic batches, resident in HBM.  Every step computes the log-mel features of exactly one batch: with the
+    # prefetch (default) those of the NEXT step's waveforms, inside this step's CTC launch (lattice + feature workgroups in one
+    # grid - the data-loader prefetch of the reference's workers, on the GPU).  Same results either way.
+    if cfg["ragged"]:
+        batches = synth_buckets(B, 8, V, 1234 + rank, dev)
+        order = torch.randperm(len(batches), generator=torch.Generator().manual_seed(7)).tolist()   # bucket order as a sampler would shuffle it
+        batches = [batches[i] for i in order]
+        Lmax = max(b[0].shape[1] for b in batches)
+        model.workspace(B, int(_lib.load().lasr_mel_num_frames(Lmax)), max(b[2].shape[1] for b in batches))   # size it once for the largest bucket
+    else:
+        n = int(cfg["clip_s"] * SR)
+        batches = []
+        for seed in (1234 + rank, 991234 + rank):
+            w, t_, l_ = synth_batch(B, n, 100, seed, dev, V)
+            batches.append((w, None, t_, l_, B * cfg["clip_s"], 0.0))
     step_no = [0]
+    audio_s = [0.0]
 
     def one_step():
-        w, t_, l_ = batches[step_no[0] & 1]
-        nxt = batches[(step_no[0] + 1) & 1][0] if args.prefetch else None
+        w, sl, t_, l_, secs, _pad = batches[step_no[0] % len(batches)]
+        nxt = batches[(step_no[0] + 1) % len(batches)] if args.prefetch else None
         step_no[0] += 1
-        return ts.step(w, t_, l_, prefetch_wave=nxt)
+        audio_s[0] += secs
+        return ts.step(w, t_, l_, sample_lens=sl, prefetch_wave=None if nxt is None else nxt[0],
+                       prefetch_lens=None if nxt is None else nxt[1])
 
     for _ in range(args.warmup):
         loss, *_ = one_step()
     barrier()
+    audio_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, *_ = one_step()
     barrier()
     dt = time.perf_counter() - t0
+    timed_audio_s = audio_s[0]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
     ms_per_step = 1e3 * dt / args.steps
-    value = B * world * CLIP_S * args.steps / dt
+    value = timed_audio_s * world / dt
 
     # ---- roofline leg: the same steps again with HIP events around every launch of the dominant
     # kernel class (the 1x1-conv GEMMs), recorded on the launch stream inside liblasr.
@@ -157,6 +281,8 @@ def main():
     lib = _lib.load()
     roofline = None
     n_prof = max(2, min(args.steps, 5))
+    if cfg["ragged"]:
+        n_prof = len(batches)
     if rank == 0:
         lib.lasr_prof_enable(1)
     for _ in range(n_prof):
@@ -173,10 +299,16 @@ def main():
         _lib.check(lib.lasr_prof_overhead_ms(C.c_void_p(torch.cuda.current_stream().cuda_stream), 512, C.byref(ovh)),
                    "lasr_prof_overhead_ms")
         gemm_ms = max(gemm_ms_raw - gemm_n * ovh.value, 0.5 * gemm_ms_raw)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "gemm_traffic_%s.json" % args.dtype)
+        # HBM traffic of the same kernel class from rocprofv3 --pmc passes (tools/pmc_pass.sh): only quoted when the file was
+        # measured on THIS build of the kernels (source hash) and this config
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic_%s_%s.json" % (args.config, args.dtype))
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("source_id") == source_id():
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
+            else:
+                traffic_src = "stale: %s was measured on build %s, this is %s" % (os.path.relpath(tpath, ROOT), tj.get("source_id"), source_id())
         if args.dtype == "f32":
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
@@ -184,11 +316,12 @@ def main():
         else:
             ach = gemm_by / (gemm_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
-        roofline.update({"traffic": traffic, "kernel": "gemm (1x1 conv fwd/dgrad/wgrad)", "launches_per_step": gemm_n // n_prof,
+        roofline.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": "gemm (1x1 conv fwd/dgrad/wgrad)",
+                         "launches_per_step": gemm_n // n_prof,
                          "avg_launch_us": 1e3 * gemm_ms / max(gemm_n, 1), "avg_launch_us_raw": 1e3 * gemm_ms_raw / max(gemm_n, 1),
                          "event_overhead_us": 1e3 * ovh.value, "gemm_ms_per_step": gemm_ms / n_prof,
                          "algorithmic_gflop_per_step": gemm_fl / n_prof / 1e9, "algorithmic_mb_per_step": gemm_by / n_prof / 1e6,
-                         "dwconv_ms_per_step": ms[1] / n_prof})
+                         "dwconv_ms_per_step": ms[1] / n_prof, "source_id": source_id()})
     if dist is not None:
         dist.barrier()
 
@@ -196,19 +329,23 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    metric = "audio-seconds/sec training (asr13x1, bs=32, 10 s clips)" if args.config == "cfg2" else \
+        "audio-seconds/sec training (%s)" % args.config
     out = {
-        "metric": "audio-seconds/sec training (asr13x1, bs=32, 10 s clips)", "value": value, "unit": "audio-seconds/sec",
+        "metric": metric, "value": value, "unit": "audio-seconds/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "asr13x1 QuartzNet-CTC train step, bs=%d/GPU, 10 s synthetic 16 kHz clips, labels.txt vocab "
-                               "(C=28), HIP mel+conv+CTC+NovoGrad, random-init weights" % B,
-                   "global_batch": B * world, "clip_seconds": CLIP_S, "target_len": S_TGT, "parallelism": "dp%d" % world,
-                   "feature_prefetch": bool(args.prefetch)},
+        "config": {"workload": (cfg["workload"] % B) + ", HIP mel+conv+CTC+NovoGrad, random-init weights", "name": args.config,
+                   "global_batch": B * world, "clip_seconds": cfg["clip_s"] if cfg["clip_s"] else "2-16 (ragged)",
+                   "audio_seconds_per_step_per_gpu": timed_audio_s / args.steps,
+                   "padding_frac": sum(b[5] for b in batches) / len(batches),
+                   "n_class": V + 1, "parallelism": "dp%d" % world, "feature_prefetch": bool(args.prefetch),
+                   "excluded": "H2D of the PCM (waves resident in HBM); the reference's per-step greedy decode + WER logging (train.py:80)"},
         "final_loss": final_loss,
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(args.config, V)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

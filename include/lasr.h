@@ -363,8 +363,9 @@ int64_t lasr_model_param_elems(const lasr_model_t* m);
 int64_t lasr_model_buffer_elems(const lasr_model_t* m);
 int64_t lasr_model_out_frames(const lasr_model_t* m, int64_t T_in);
 size_t lasr_model_workspace_bytes(lasr_model_t* m, int64_t B, int64_t T_in, int64_t S_max);
-/* Named intermediate ("tap": unit name, "<unit>.y", "<unit>.u", "logits", "grad_logits", "lens")
- * inside the workspace after a forward: returns its byte offset, or -1.                          */
+/* Named intermediate ("tap": unit name, "<unit>.y", "<unit>.y2", "<unit>.u", "ctx_in", "logits", "grad_logits", "lens";
+ * after a staged backward call "bwd.g_cur" = d(input of the last unit processed), "bwd.g_prev" = d(its output), both
+ * [N][c] at the head of an [N][cmax] allocation) inside the workspace: returns its byte offset, or -1.            */
 int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, int64_t T_in, int64_t S_max, int64_t shape[3]);
 
 /* feats: [B][T_in][in_c] channels-last in cfg.dtype (from lasr_mel_fwd / lasr_bct_to_btc).

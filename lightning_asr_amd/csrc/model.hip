@@ -341,7 +341,16 @@ extern "C" int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, 
   for (const Unit& u : m->units) {
     if (n == u.tap) { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_out; }
     if (n == u.tap + ".y") { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_y; }
+    if (n == u.tap + ".y2" && u.has_res) { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_y2; }
     if (n == u.tap + ".u" && u.has_dw) { shape[0] = B; shape[1] = p.T; shape[2] = u.ci; return (int64_t)u.o_u; }
+  }
+  // gradient ping-pong buffers of the (staged) backward: after a stage that ended at unit i, "bwd.g_cur" holds d(input of unit i)
+  // and "bwd.g_prev" still holds d(output of unit i); both are [N][c] tensors at the head of an [N][cmax] allocation
+  if (n == "bwd.g_cur" || n == "bwd.g_prev") {
+    int64_t cmax = 0;
+    for (const Unit& u : m->units) cmax = std::max<int64_t>(cmax, std::max(u.ci, u.co));
+    shape[0] = B; shape[1] = p.T; shape[2] = cmax;
+    return (int64_t)p.o_g[n == "bwd.g_cur" ? m->bwd_cur : (m->bwd_cur ^ 1)];
   }
   if (n == "ctx_in" && m->cfg.variant != LASR_VARIANT_PLAIN) { shape[0] = B; shape[1] = p.T; shape[2] = 336; return (int64_t)p.o_cat; }
   if (n == "logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_logits; }

@@ -76,10 +76,10 @@ class AudioParser:
         input_percentages (B,)) on the GPU; frames past each utterance are zero."""
         B = len(waves)
         L = max(int(w.numel()) for w in waves)
-        host = torch.zeros(B, L)
+        host = torch.zeros(B, L, pin_memory=True)       # pad on the host, ONE H2D copy for the batch
         lens = torch.empty(B, dtype=torch.int32)
         for i, w in enumerate(waves):
-            host[i, :w.numel()] = w
+            host[i, :w.numel()] = w.cpu() if w.is_cuda else w
             lens[i] = w.numel()
         dev = self.device
         wave = host.to(dev, non_blocking=True)

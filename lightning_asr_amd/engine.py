@@ -35,6 +35,8 @@ class NativeModel:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.LasrError("NativeModel runs on the GPU only (hand-written HIP); no CPU fallback exists")
+        if self.device.index is None:              # "cuda" -> the current device, as an indexed device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.cfg = _lib.ModelConfig(_lib.VARIANT[variant], n_class, in_c, int(mask), {"relu": 1, "swish": 2}[act],
                                     _lib.F32 if dtype == torch.float32 else _lib.BF16)
         self.variant, self.n_class, self.act_dtype = variant, n_class, dtype
@@ -197,6 +199,10 @@ class NativeModel:
             dt = torch.float32
         elif name == "lens":
             return self._ws[off:off + 4 * B].view(torch.int32)
+        elif name.startswith("bwd."):
+            # [N][c] gradient at the head of an [N][cmax] allocation: the caller slices the flat view
+            n = shp[0] * shp[1] * shp[2] * (4 if self.act_dtype == torch.float32 else 2)
+            return self._ws[off:off + n].view(self.act_dtype)
         else:
             dt = self.act_dtype
         n = shp[0] * shp[1] * shp[2] * (4 if dt == torch.float32 else 2)
@@ -282,6 +288,32 @@ class NativeModel:
             call("lasr_model_backward_continue", self._h, _p(self.params), _p(feats_btc), B, T_in, _p(self.grads), _p(ws), ws.numel(),
                  stop, _stream())
             on_bucket(lo, hi)
+        for k in self.counters:
+            self.counters[k] += 1
+        self._last_feats, self._last_logp = feats_btc, logp
+        return loss, nll, logp, am
+
+    def loss_backward_units(self, feats_btc, pct, targets, tgt_lens, on_unit):
+        """loss_backward one unit per stage, from the last unit to the first; ``on_unit(i, name)`` runs after the stage of unit i
+        has been enqueued: its parameter gradients are final, tap("bwd.g_prev") is d(output of unit i) and tap("bwd.g_cur")
+        d(input of unit i).  Test hook for the per-unit parity checks (same kernels, same order as loss_backward)."""
+        B, T_in, _ = feats_btc.shape
+        S = targets.shape[1]
+        ws = self.workspace(B, T_in, S)
+        T = self.out_frames(T_in)
+        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        am = torch.empty(B, T, dtype=torch.int32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        nll = torch.empty(B, dtype=torch.float32, device=self.device)
+        names = self.unit_names()
+        last = len(names) - 1
+        call("lasr_model_loss_backward_partial", self._h, _p(self.params), _p(self.buffers), _p(feats_btc), _p(pct), _p(targets),
+             _p(tgt_lens), B, T_in, S, _p(logp), _p(loss), _p(nll), _p(am), _p(self.grads), _p(ws), ws.numel(), last, _stream())
+        on_unit(last, names[last])
+        for i in range(last - 1, -1, -1):
+            call("lasr_model_backward_continue", self._h, _p(self.params), _p(feats_btc), B, T_in, _p(self.grads), _p(ws), ws.numel(),
+                 i, _stream())
+            on_unit(i, names[i])
         for k in self.counters:
             self.counters[k] += 1
         self._last_feats, self._last_logp = feats_btc, logp

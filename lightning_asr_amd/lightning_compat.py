@@ -152,6 +152,11 @@ class Trainer:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = torch.device(device) if device else torch.device("cuda", self.local_rank)
+        n_gpus = len(gpus) if isinstance(gpus, (list, tuple)) else (int(gpus) if isinstance(gpus, (int, str)) and str(gpus).lstrip("-").isdigit() else None)
+        if n_gpus is not None and n_gpus > 1 and self.world == 1:
+            raise RuntimeError("gpus=%s asks for %d data-parallel ranks but WORLD_SIZE is 1: this host runs one process per GPU, "
+                               "launch with `python -m torch.distributed.run --nproc-per-node %d -m lightning_asr_amd.train ...`"
+                               % (gpus, n_gpus, n_gpus))
         self.history: List[Dict[str, Any]] = []
         self._epoch_metrics: Dict[str, List[float]] = {}
         self._best: List[tuple] = []
@@ -182,7 +187,9 @@ class Trainer:
         return dist
 
     def _batch(self, batch, dm, idx=0):
-        batch = _to_device(batch, self.device)
+        from .data_module import WaveBatch
+        if not isinstance(batch, WaveBatch):     # ragged host waveforms go up in ONE pinned copy inside on_after_batch_transfer
+            batch = _to_device(batch, self.device)
         if hasattr(dm, "on_after_batch_transfer"):
             batch = dm.on_after_batch_transfer(batch, idx)
         return batch
@@ -198,7 +205,14 @@ class Trainer:
         torch.save(ckpt, path)
         return path
 
+    def _check_device(self, model):
+        native = getattr(getattr(model, "encoder", None), "native", None)
+        if native is not None and self.device.type == "cuda" and native.device != self.device:
+            raise RuntimeError("model lives on %s but this rank trains on %s: construct it with device=%r (train.main does)"
+                               % (native.device, self.device, str(self.device)))
+
     def fit(self, model, datamodule=None):
+        self._check_device(model)
         dist = self._init_dist()
         self.datamodule = datamodule
         model.trainer = self

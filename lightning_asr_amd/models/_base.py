@@ -65,8 +65,10 @@ class MyModel2Base(nn.Module):
             elif t.kind == 1:
                 mod.register_buffer(leaf, self.native.view(t))
             else:
-                mod.register_buffer(leaf, torch.zeros((), dtype=torch.int64, device=self.native.device))
+                mod.register_buffer(leaf, torch.zeros((), dtype=torch.int64))    # host scalar: bumping it launches nothing
                 self._counters[t.name] = (mod, leaf)
+        # runs whenever this module is loaded, also as a child of LightingModule.load_state_dict / load_from_checkpoint / resume
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._sync_counters())
 
     # nn.Module.to()/cuda() would re-allocate the parameters and break the flat views
     def _apply(self, fn, recurse=True):
@@ -93,8 +95,7 @@ class MyModel2Base(nn.Module):
                 getattr(mod, leaf).add_(1)
         return out
 
-    def load_state_dict(self, state_dict, strict: bool = True):
-        r = super().load_state_dict(state_dict, strict=strict)   # copies INTO the flat views
+    def _sync_counters(self) -> None:
+        """num_batches_tracked: the registered buffers are the source of truth; NativeModel.counters mirrors them"""
         for name, (mod, leaf) in self._counters.items():
-            self.native.counters[name] = getattr(mod, leaf).detach().cpu().clone()
-        return r
+            self.native.counters[name] = getattr(mod, leaf).detach().to("cpu", torch.int64).clone()

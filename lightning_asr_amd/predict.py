@@ -62,6 +62,7 @@ class AsrTranslator:
     def evalute_manifest(self, test_manifest: str, batch_size: int = 32, num_workers: int = 0):
         """WER over a manifest (predict.py:65-74; the reference's spelling kept)."""
         data_module = LibriDataModule(train_manifest=test_manifest, dev_manifest=test_manifest, test_manifest=test_manifest,
-                                      dev_bs=batch_size, num_worker=num_workers, labels=self.labels)
-        trainer = Trainer(gpus=1)
+                                      dev_bs=batch_size, num_worker=num_workers, labels=self.labels,
+                                      device=str(self.model.encoder.native.device), act_dtype=self.model.encoder.native.act_dtype)
+        trainer = Trainer(gpus=1, device=str(self.model.encoder.native.device))
         return trainer.test(self.model, datamodule=data_module)

@@ -151,16 +151,21 @@ def main(argv=None):
         labels = [c.strip() for c in open(labels, "r", encoding="utf-8").readlines()]
         use_cer = True
     dtype = model_cfg.get("dtype", "bf16" if tran_cfg.get("precision") == 16 else "f32")
+    # one process per GPU (torch.distributed.run sets LOCAL_RANK): select this rank's device BEFORE anything allocates, and
+    # hand the indexed device to every component that owns GPU memory (the flat parameter buffers, the mel workspaces)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
     data_module = LibriDataModule(data_cfg.get("train_manifest"), data_cfg.get("val_manifest"), labels=labels,
                                   train_bs=tran_cfg.get("train_batch_size"), dev_bs=tran_cfg.get("dev_batch_size"),
                                   test_manifest=data_cfg.get("test_manifest"), num_worker=data_cfg.get("num_worker"),
                                   train_max_duration=data_cfg.get("train_max_duration"),
                                   dev_max_duration=data_cfg.get("dev_max_duration"),
-                                  act_dtype=torch.float32 if dtype == "f32" else torch.bfloat16)
+                                  act_dtype=torch.float32 if dtype == "f32" else torch.bfloat16, device=device)
     model = LightingModule(learning_rate=tran_cfg.get("learning_rate"), weight_decay=tran_cfg.get("weight_decay"), labels=labels,
                            total_epoch=tran_cfg.get("total_epoch"), drop_rate=model_cfg.get("drop_rate"), mask=model_cfg.get("mask"),
                            use_cer=use_cer, variant=model_cfg.get("variant", "plain"), act=model_cfg.get("act", "relu"), dtype=dtype,
-                           warmup_steps=tran_cfg.get("warmup_steps", 1000))
+                           warmup_steps=tran_cfg.get("warmup_steps", 1000), device=device)
     trainer = Trainer(gpus=tran_cfg.get("gpus"), resume_from_checkpoint=tran_cfg.get("checkpoint"), accelerator=tran_cfg.get("accelerator"),
                       max_epochs=tran_cfg.get("total_epoch"), check_val_every_n_epoch=tran_cfg.get("check_val_every_n_epoch", 1),
                       num_nodes=tran_cfg.get("num_nodes"), default_root_dir=cfg.get("output_dir", "."),

@@ -694,3 +694,79 @@ def test_eval_forward_folded_matches_unfolded(dev, tmp_path):
     assert torch.isfinite(outs[0]).all()
     assert (outs[0] - outs[1]).abs().max() < 0.08              # log-probabilities of a 15-unit bf16 network
     assert (outs[0].argmax(-1) == outs[1].argmax(-1)).float().mean() > 0.97
+
+
+# ----------------------------------------------------------------------------------------- bf16 storage mode of the same kernels
+@pytest.mark.parametrize("C,has_res,act,masked", [(256, True, "relu", True), (512, True, "relu", False), (1024, False, "relu", False),
+                                                  (336, True, "swish", True)])
+def test_bn_act_fwd_bwd_bf16(dev, C, has_res, act, masked):
+    """bn_act_fwd / bn_act_bwd_stats / bn_act_bwd_apply on bf16 tensors (31 % of the bench step) against an f64 torch
+    reference evaluated ON THE SAME bf16-rounded inputs: what may differ is one final bf16 rounding per output element."""
+    from lightning_asr_amd import ops
+    from oracle.ref_bf16 import rb
+    g = torch.Generator().manual_seed(C + 1)
+    B, T = 4, 123
+    lens = torch.tensor([123, 77, 50, 9], dtype=torch.int32)
+    keep = (torch.arange(T).view(1, 1, T) < lens.view(B, 1, 1)).double()
+    y = rb(torch.randn(B, C, T, generator=g)).double()
+    if masked:
+        y = y * keep
+    y.requires_grad_(True)
+    y2 = rb(torch.randn(B, C, T, generator=g)).double().requires_grad_(True) if has_res else None
+    mk = lambda base: (base + 0.1 * torch.randn(C, generator=g)).double().requires_grad_(True)   # noqa: E731
+    gam, bet, gam2, bet2 = mk(1.0), mk(0.0), mk(1.0), mk(0.0)
+    ym = y * keep if masked else y
+    z = F.batch_norm(ym, torch.zeros(C).double(), torch.ones(C).double(), gam, bet, True, 0.1, 1e-3)
+    if has_res:
+        z = z + F.batch_norm(y2, torch.zeros(C).double(), torch.ones(C).double(), gam2, bet2, True, 0.1, 1e-3)
+    out = {"relu": F.relu, "swish": lambda v: v * torch.sigmoid(v)}[act](z)
+    dout = rb(torch.randn(out.shape, generator=g)).double()
+    out.backward(dout)
+
+    def cl(t):
+        return t.detach().transpose(1, 2).contiguous().to(dev, torch.bfloat16)
+    yg, y2g = cl(ym), (cl(y2) if has_res else None)
+    N = B * T
+
+    def stats_of(t):
+        f = t.reshape(N, C).double()
+        return torch.cat([f.sum(0), (f * f).sum(0)]).float()
+    f32 = lambda t: t.detach().float().to(dev)   # noqa: E731
+    coef, saved = ops.bn_finalize(stats_of(yg), f32(gam), f32(bet), torch.zeros(C, device=dev), torch.ones(C, device=dev), N)
+    coef2 = saved2 = None
+    if has_res:
+        coef2, saved2 = ops.bn_finalize(stats_of(y2g), f32(gam2), f32(bet2), torch.zeros(C, device=dev), torch.ones(C, device=dev), N)
+    got = ops.bn_act(yg, coef, y2g, coef2, None, act)
+    assert got.dtype == torch.bfloat16
+    ref_out = rb(out.detach().float())
+    # identical except where the f32 evaluation lands on the other side of a bf16 rounding boundary (1 ulp = 2^-8 relative)
+    assert rel_l2(got.transpose(1, 2).float(), ref_out) < 2e-4
+    assert ((got.transpose(1, 2).float().cpu() - ref_out).abs() <= 2.0 ** -7 * ref_out.abs() + 1e-30).all()
+    dy, dy2, dg, db, dg2, db2 = ops.bn_act_bwd(cl(dout), yg, coef, saved, f32(gam), y2g, coef2, saved2, f32(gam2) if has_res else None,
+                                               row_lens=lens.to(dev) if masked else None, act=act)
+    assert dy.dtype == torch.bfloat16
+    assert rel_l2(dy.transpose(1, 2).float(), rb(y.grad.float())) < 3e-4
+    assert max_rel(dg, gam.grad) < 2e-5 and max_rel(db, bet.grad) < 2e-5
+    if has_res:
+        assert rel_l2(dy2.transpose(1, 2).float(), rb(y2.grad.float())) < 3e-4
+        assert max_rel(dg2, gam2.grad) < 2e-5 and max_rel(db2, bet2.grad) < 2e-5
+
+
+def test_mel_bf16_output_is_the_rounded_f32_output(dev):
+    """the channels-last bf16 feature tensor the model consumes == round-to-nearest-even of the f32 features (parity-checked
+    against the oracle above), and the padded frames are exact zeros"""
+    from lightning_asr_amd import ops
+    from oracle.ref_bf16 import rb
+    g = torch.Generator().manual_seed(9)
+    L = 16000 * 3 + 77
+    wave = 0.1 * torch.randn(3, L, generator=g)
+    lens = torch.tensor([L, L - 5000, 9000], dtype=torch.int32)
+    bft, btf, frames, pct = ops.mel(wave.to(dev), lens.to(dev), None, None, True, torch.bfloat16)
+    assert btf.dtype == torch.bfloat16 and bft.dtype == torch.float32
+    ref = rb(bft.cpu()).transpose(1, 2)
+    got = btf.float().cpu()
+    # both come from one f64 value: f64 -> f32 -> bf16 (reference here) against f64 -> bf16 in the kernel differ only on exact ties
+    assert (got != ref).float().mean() < 1e-4
+    assert ((got - ref).abs() <= 2.0 ** -7 * ref.abs()).all()
+    for b in range(3):
+        assert torch.all(btf[b, int(frames[b]):] == 0)

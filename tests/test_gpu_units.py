@@ -1,0 +1,203 @@
+"""Per-unit ("teacher-forced") parity of the whole training step at the BASELINE sizes, bf16 (the bench dtype) and f32.
+
+One full step runs on the GPU through the C ABI (wave -> mel -> forward -> CTC -> backward, one unit per backward
+stage so that every unit's d(out) / d(in) can be read from the workspace).  Then, for EVERY unit of the plan, the CPU
+oracle (oracle/ref_bf16.py: the pinned f32 arithmetic of oracle/ref_cpu.py plus the plan's bf16 storage points)
+recomputes that unit from the GPU's own stored inputs and every tensor the unit produced is compared: u, y, y2, out,
+dx and all parameter gradients; same for the BiLSTM context branch and the decoder + log-softmax + CTC head.
+
+Why per unit: the end-to-end map is chaotic at bf16 resolution (see the header of oracle/ref_bf16.py: two emulations
+differing only in f32-vs-f64 arithmetic between the stores differ by 0.4 relative L2 in the gradients), so whole-step
+bf16 gradients cannot be compared tightly whatever the kernels do; per unit the only legitimate difference is the f32
+accumulation order and the handful of bf16 rounding flips it causes.  End-to-end the loss is still compared (<= 1e-3).
+
+Configs (BASELINE.json): cfg2 = asr13x1 bf16 bs=32 10 s; cfg4 = QuartNetContextSE bf16 bs=32 10 s; cfg5-shaped = AISHELL
+vocabulary (C=4334), bs=32, one length bucket of ragged 14.5-16 s clips (T' up to 801), bf16.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import ref_bf16 as E
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+# tolerances (relative L2 per tensor unless noted).  bf16: one rounding flip changes an element by 2^-8 relative; with
+# f32 accumulation noise ~1e-6 against a rounding step of 4e-3 about 1 element in 4000 flips -> ~1e-4 relative L2.
+# Measured on MI355X (profiles/r02_unit_parity.json): bf16 act <= 8e-5, grad_act <= 4.5e-4, grad_param <= 4.5e-4;
+# f32 act <= 4e-7, grad_param <= 2e-6, grad_act <= 2e-4 (that one is d(logits): the lattice kernel evaluates lse on the
+# v_exp_f32 / v_log_f32 units, torch's CPU ctc_loss on libm - north_star's gate for the CTC loss itself is 1e-4).
+TOL = {
+    "bf16": {"act": 3e-4, "grad_act": 1.5e-3, "grad_param": 1.5e-3, "logp_abs": 2e-5, "nll": 2e-6, "loss_e2e": 1e-3},
+    "f32": {"act": 5e-6, "grad_act": 6e-4, "grad_param": 2e-5, "logp_abs": 2e-5, "nll": 2e-6, "loss_e2e": 1e-5},
+}
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-300)).item()
+
+
+def _bct(t_btc):
+    return t_btc.float().cpu().transpose(1, 2).contiguous()
+
+
+def _ragged_batch(B, L_max, L_min, V, seed, chars_per_s=2.8):
+    """one length bucket: utterance lengths uniform in [L_min, L_max] (<= 10 % padding), AISHELL-like target lengths"""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(L_min, L_max + 1, (B,), generator=g)
+    lens[0] = L_max
+    wave = 0.1 * torch.randn(B, L_max, generator=g)
+    for b in range(B):
+        wave[b, lens[b]:] = 0
+    tl = (lens.float() / 16000 * chars_per_s).int()
+    S = int(tl.max())
+    tg = torch.randint(0, V, (B, S), generator=g)
+    for s in range(1, S):
+        same = tg[:, s] == tg[:, s - 1]
+        tg[same, s] = (tg[same, s] + 1) % V
+    return wave, lens.int(), tg.long(), tl.int()
+
+
+def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag, oracle_dtype=torch.float32, weights="random"):
+    from lightning_asr_amd import ops
+    from lightning_asr_amd.engine import NativeModel
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    mode = "bf16" if dtype == torch.bfloat16 else "f32"
+    tol = TOL[mode]
+    state = R.random_state(variant, n_class, 0) if weights == "random" else R.formula_state(variant, n_class)
+    m = NativeModel(variant, n_class, mask=True, act="relu", dtype=dtype, device=dev)
+    m.load_state_dict(state)
+    B = wave.shape[0]
+    _, feats, frames, pct = ops.mel(wave.to(dev), None if sample_lens is None else sample_lens.to(dev), None, None, True, dtype,
+                                    want_bft=False, want_btf=True)
+    names = m.unit_names()
+    units = {}
+    T = m.out_frames(feats.shape[1])
+    N = B * T
+
+    def on_unit(i, name):
+        gp, gc = m.tap("bwd.g_prev"), m.tap("bwd.g_cur")
+        units[name] = {"g_prev": gp.clone(), "g_cur": gc.clone()}
+    loss, nll, logp, am = m.loss_backward_units(feats, pct, tg.to(dev), tl.to(dev), on_unit)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all() and torch.isfinite(m.grads).all()
+    gpu_grads = {t.name: m.view(t, m.grads).detach().float().cpu() for t in m.param_infos()}
+    pct_c = pct.cpu()
+    lens = R.mask_lengths(T, pct_c)
+    assert m.tap("lens").cpu().tolist() == lens.tolist()
+    o = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
+                          emulate=(mode == "bf16"))
+    report = {"config": tag, "mode": mode, "B": B, "T_in": int(feats.shape[1]), "T": T, "C": n_class, "units": {}}
+    worst = {"act": 0.0, "grad_act": 0.0, "grad_param": 0.0}
+
+    def note(unit, kind, key, val):
+        report["units"].setdefault(unit, {})[key] = val
+        worst[kind] = max(worst[kind], val)
+        assert val < tol[kind], (tag, unit, key, val, tol[kind])
+
+    def grad_of(name, c):
+        return _bct(units[name]["g_cur"][:N * c].view(B, T, c))
+
+    ctx = variant != "plain"
+    chans = {"first_cnn": (m.cfg.in_c, 256), "last_cnn2": (512, 1024)}
+    for n_, ci, co, _k in R.block_table(variant):
+        chans[n_] = (ci, co)
+    for i, name in enumerate(names):
+        ci, co = chans[name]
+        if i == 0:
+            x_in = _bct(feats)
+        elif ctx and name == "block3":
+            x_in = _bct(m.tap("ctx_in"))
+        else:
+            x_in = _bct(m.tap(names[i - 1]))
+        if i == len(names) - 1:
+            dout = _bct(units[name]["g_prev"][:N * co].view(B, T, co))
+        else:
+            dout = grad_of(names[i + 1], co)
+        out_gpu = _bct(m.tap(name))
+        r = E.run_unit(o, name, x_in, lens, dout, act_mask=out_gpu > 0)
+        note(name, "act", "out", rel_l2(out_gpu, r["out"]))
+        note(name, "act", "y", rel_l2(_bct(m.tap(name + ".y")), r["y"]))
+        if "u" in r:
+            note(name, "act", "u", rel_l2(_bct(m.tap(name + ".u")), r["u"]))
+        if "y2" in r:
+            note(name, "act", "y2", rel_l2(_bct(m.tap(name + ".y2")), r["y2"]))
+        if "dx" in r and i > 0:
+            note(name, "grad_act", "dx", rel_l2(grad_of(name, ci) if not (ctx and name == "block3") else
+                                                _bct(units[name]["g_prev"][:N * ci].view(B, T, ci)), r["dx"]))
+        for k, g in r["grads"].items():
+            note(name, "grad_param", "d." + k.split("encoder.")[-1], rel_l2(gpu_grads[k], g.float()))
+        if ctx and name == "block3":
+            x23 = _bct(m.tap(names[i - 1]))
+            dcat = _bct(units[name]["g_prev"][:N * 336].view(B, T, 336))
+            rc = E.run_context(o, x23, lens, dcat)
+            note("context_rnn", "act", "ctx", rel_l2(x_in[:, 256:], rc["ctx"]))
+            note("context_rnn", "grad_act", "dx", rel_l2(grad_of(name, 256), rc["dx"]))
+            for k, g in rc["grads"].items():
+                note("context_rnn", "grad_param", "d." + k.split("rnn.")[-1], rel_l2(gpu_grads[k], g.float()))
+    # head: decoder + log_softmax + mean CTC from the stored last_cnn2 output
+    rh = E.run_head(o, _bct(m.tap("last_cnn2")), pct_c, tg, tl, glogits_in=m.tap("grad_logits").cpu())
+    lp_err = (logp.cpu().double() - rh["logp"].double()).abs().max().item()
+    report["head"] = {"logp_max_abs": lp_err, "nll_rel": ((nll.cpu().double() - rh["nll"].double()).abs() / rh["nll"].double().abs()).max().item(),
+                      "loss_gpu": loss.item(), "loss_head_oracle": rh["loss"]}
+    assert lp_err < tol["logp_abs"], (tag, "logp", lp_err)
+    assert report["head"]["nll_rel"] < tol["nll"], (tag, "nll", report["head"]["nll_rel"])
+    assert torch.equal(am.cpu().long(), rh["logp"].argmax(-1)) or (am.cpu().long() != rh["logp"].argmax(-1)).float().mean() < 1e-4
+    note("head", "grad_act", "glogits", rel_l2(m.tap("grad_logits").cpu(), rh["glogits"]))
+    note("head", "grad_act", "dx", rel_l2(_bct(units["last_cnn2"]["g_prev"][:N * 1024].view(B, T, 1024)), rh["dx"]))
+    for k, g in rh["grads"].items():
+        note("head", "grad_param", "d." + k, rel_l2(gpu_grads[k], g.float()))
+    report["worst"] = worst
+    # end to end: the emulated oracle's own whole forward from the same features (loss only: see the module docstring)
+    o2 = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
+                           emulate=(mode == "bf16"))
+    o2.training = True
+    with torch.no_grad():
+        lp2 = o2.forward(_bct(feats).unsqueeze(1), pct_c)
+        loss2 = R.training_loss(lp2, tg, pct_c, tl, n_class - 1).item()
+    report["e2e"] = {"loss_gpu": loss.item(), "loss_oracle": loss2, "rel": abs(loss.item() - loss2) / abs(loss2),
+                     "logp_rel_l2": rel_l2(logp.cpu(), lp2), "argmax_agree": (am.cpu().long() == lp2.argmax(-1)).float().mean().item()}
+    assert report["e2e"]["rel"] < tol["loss_e2e"], (tag, report["e2e"])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/unit_parity_%s.json" % tag, "w") as f:
+        json.dump(report, f, indent=1)
+    return report
+
+
+def test_units_f32_small_validates_harness(dev):
+    """f32 parity mode, formula weights, golden-sized batch: the per-unit harness against the pinned plain oracle."""
+    wave, tg, tl = R.synth_batch(4, 32000, 20, 27, seed=5)
+    lens = torch.tensor([32000, 32000, 28000, 16000], dtype=torch.int32)
+    rep = run_units_check(dev, "context_se", 28, torch.float32, wave, lens, tg, tl, "f32_small_context_se", torch.float64, "formula")
+    assert rep["worst"]["act"] < 2e-5
+
+
+def test_units_cfg2_plain_bf16_bs32_10s(dev):
+    wave, tg, tl = R.synth_batch(32, 160000, 100, 27, seed=1234)
+    run_units_check(dev, "plain", 28, torch.bfloat16, wave, None, tg, tl, "cfg2_plain_bf16")
+
+
+def test_units_cfg2_plain_f32_bs32_10s(dev):
+    wave, tg, tl = R.synth_batch(32, 160000, 100, 27, seed=1234)
+    run_units_check(dev, "plain", 28, torch.float32, wave, None, tg, tl, "cfg2_plain_f32")
+
+
+def test_units_cfg4_context_se_bf16_bs32_10s(dev):
+    wave, tg, tl = R.synth_batch(32, 160000, 100, 27, seed=4321)
+    run_units_check(dev, "context_se", 28, torch.bfloat16, wave, None, tg, tl, "cfg4_context_se_bf16")
+
+
+def test_units_context_bf16_ragged(dev):
+    wave, lens, tg, tl = _ragged_batch(8, 96000, 60000, 27, seed=77)
+    run_units_check(dev, "context", 28, torch.bfloat16, wave, lens, tg, tl, "context_bf16_ragged")
+
+
+def test_units_cfg5_aishell_bf16_bs32_ragged_16s(dev):
+    V = 4333
+    wave, lens, tg, tl = _ragged_batch(32, 256000, 232000, V, seed=555)
+    rep = run_units_check(dev, "plain", V + 1, torch.bfloat16, wave, lens, tg, tl, "cfg5_aishell_bf16")
+    assert rep["T"] == 801

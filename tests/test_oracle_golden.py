@@ -127,3 +127,24 @@ def test_mel_front_end_shapes_and_collate():
     # bug-compatible sub-sequence: END index is target_length
     w = torch.arange(100.).view(1, -1)
     assert R.sub_sequence(w, 0.5, 0.5, weight=0.98).shape[1] == 99 - int((100 - 99) * 0.5)
+
+
+@pytest.mark.parametrize("variant", ["plain", "context_se"])
+def test_bf16_oracle_without_rounding_is_the_pinned_oracle(variant):
+    """oracle/ref_bf16.py restates the layers with storage-rounding hooks (and its own BiLSTM loop): with the hooks off it
+    must be the pinned oracle, so what the per-unit GPU tests check in bf16 mode is that arithmetic plus roundings only."""
+    from oracle import ref_bf16 as E
+    from oracle.make_golden import golden_inputs
+    x, tg, pct, tsz = golden_inputs()
+    o = R.OracleModel(variant, 28, state=R.formula_state(variant, 28))
+    l0, nll0, lp0, g0 = E.loss_and_grads(o, x, tg, pct, tsz)
+    e = E.Bf16OracleModel(variant, 28, state=R.formula_state(variant, 28), dtype=torch.float64, emulate=False)
+    l1, nll1, lp1, g1 = E.loss_and_grads(e, x, tg, pct, tsz)
+    assert abs(l0 - l1) / abs(l1) < 1e-5
+    assert (lp0.double() - lp1).abs().max() < 1e-4
+    for a, b in zip(g0, g1):
+        assert ((a.double() - b).norm() / b.norm()).item() < 5e-3      # f32 vs f64 through this BN stack (DESIGN: 100-400x noise gain)
+    # and with the roundings on it stays a small perturbation of the forward (bf16 resolution ~4e-3 per store)
+    eb = E.Bf16OracleModel(variant, 28, state=R.formula_state(variant, 28), dtype=torch.float64, emulate=True)
+    l2, _, lp2, _ = E.loss_and_grads(eb, x, tg, pct, tsz)
+    assert abs(l2 - l1) / abs(l1) < 5e-3
