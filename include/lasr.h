@@ -188,6 +188,18 @@ typedef struct {
 int lasr_bn_finalize_partials(const lasr_bn_branch* branches, int n_branches, int64_t C, int64_t n_rows, float eps,
                               float momentum, void* stream);
 
+/* The forward 1x1 conv(s) of a unit together with their training-mode BatchNorms (models/QuartNet.py:31-35,63-64):
+ * lasr_gemm_batch_partials + lasr_bn_finalize_partials as ONE call.  For bf16 problems that take the 256-row tile form the
+ * coefficients are finalised INSIDE the GEMM launch by the last-arriving row tile of every column tile (bit-identical sums,
+ * one launch less per unit); otherwise the finalize launch follows.  branches[i].partials / n_partials are ignored;
+ * tickets: 16 * n_probs counters that are zero on entry (lasr_mask_lengths_zero clears them) and zero again on exit, or
+ * NULL to force the two-launch form. */
+int lasr_gemm_batch_bn(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, const lasr_bn_branch* branches,
+                       float eps, float momentum, uint32_t* tickets, void* workspace, size_t workspace_bytes, void* stream);
+/* lasr_mask_lengths that also clears n_zero 32-bit words at `zero` (the ticket counters above) in the same launch */
+int lasr_mask_lengths_zero(const float* pct, int64_t B, int64_t T, int32_t* lens, uint32_t* zero, int64_t n_zero, void* stream);
+
+
 /* out = act( (y*coef_a + coef_b) * se_scale[b][c] + (y2*coef2_a + coef2_b) )
  * y2/coef2 (residual branch) and se_scale ([B][C] f32) may be NULL.
  * (BN-apply + SE scale + residual add + ReLU: models/QuartNet.py:35-37,74-77; ContextSE :55) */
@@ -400,6 +412,31 @@ int lasr_model_loss_backward_partial(lasr_model_t* m, const float* params, float
                                      int64_t unit_stop, void* stream);
 int lasr_model_backward_continue(lasr_model_t* m, const float* params, const void* feats, int64_t B, int64_t T_in,
                                  float* grads, void* workspace, size_t workspace_bytes, int64_t unit_stop, void* stream);
+
+/* ---- data-parallel gradient exchange: RCCL over xGMI, called by the library itself ------------------------------
+ * Replaces the NCCL all-reduce the reference gets from Lightning's DDP plugin (conf/conf.yaml:30-31 `accelerator: ddp`,
+ * train.py:239): SUM over ranks of the flat f32 gradient, bucket by bucket while backward is still
+ * running, plus the wrap-time broadcast of parameters and buffers from rank 0.
+ * One communicator per process (one process per GPU).  Collectives run on a library-owned side stream:
+ *   lasr_comm_allreduce / _ranges / lasr_comm_broadcast   wait (event) for everything enqueued on `producer_stream` so far,
+ *                                                         then run in place on the side stream;
+ *   lasr_comm_wait                                        makes `consumer_stream` wait for every collective issued so far.
+ * No call synchronises the host.  Positive return codes 1000+n carry ncclResult_t n.
+ * Bootstrap: rank 0 calls lasr_comm_unique_id and the host carries the LASR_COMM_ID_BYTES bytes to the other ranks by
+ * whatever rendez-vous it has (torch.distributed's store, MPI, a file); every rank then calls lasr_comm_init.        */
+#define LASR_COMM_ID_BYTES 128
+typedef struct lasr_comm lasr_comm_t;
+int lasr_comm_unique_id(void* id_out, size_t id_bytes);
+int lasr_comm_init(lasr_comm_t** out, const void* unique_id, size_t id_bytes, int world, int rank, int device);
+int lasr_comm_destroy(lasr_comm_t* comm);
+int lasr_comm_world(const lasr_comm_t* comm);
+int lasr_comm_rank(const lasr_comm_t* comm);
+int lasr_comm_allreduce(lasr_comm_t* comm, float* buf, int64_t count, void* producer_stream);
+/* one bucket made of several pieces of the flat buffer (ncclGroupStart/End: one fused launch) */
+int lasr_comm_allreduce_ranges(lasr_comm_t* comm, float* base, const int64_t* lo, const int64_t* hi, int n_ranges,
+                               void* producer_stream);
+int lasr_comm_broadcast(lasr_comm_t* comm, float* buf, int64_t count, int root, void* producer_stream);
+int lasr_comm_wait(lasr_comm_t* comm, void* consumer_stream);
 
 #ifdef __cplusplus
 }

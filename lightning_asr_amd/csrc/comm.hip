@@ -1,0 +1,175 @@
+// Data-parallel gradient exchange: RCCL called directly from the library (lasr_comm_init / allreduce / destroy).
+// Replaces what the reference gets implicitly from Lightning's DDP plugin (conf/conf.yaml:30 `accelerator: ddp`,
+// train.py:239): a SUM all-reduce of the gradients over NCCL, overlapped with backward.
+//
+// One communicator per process (one process per GPU).  The collectives run on a LIBRARY-OWNED side stream, ordered
+// against the compute stream by events only:
+//   lasr_comm_allreduce(comm, buf, n, producer)  event on `producer` (everything enqueued so far: the backward stage that
+//                                                finalised this bucket) -> side stream waits -> ncclAllReduce in place
+//   lasr_comm_wait(comm, consumer)               event on the side stream -> `consumer` waits (the optimiser launch)
+// so RCCL's kernels overlap whatever the compute stream runs after the producing stage.  No host synchronisation.
+// librccl.so is loaded on first use (dlopen): single-GPU users never pay for it, and the library has no link-time
+// dependency on RCCL.  The 128-byte unique id is created on rank 0 and carried to the other ranks by the host's own
+// rendez-vous (torch.distributed's store / any broadcast): that bootstrap is the only thing the host framework does.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace lasr {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static int load_rccl() {
+  if (g_rccl.handle) return 0;
+  const char* names[] = {getenv("LASR_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    if (!n) continue;
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(LASR_E_ARG, "lasr_comm: cannot load librccl.so (%s)", dlerror());
+  RcclApi a;
+  a.handle = h;
+#define LASR_SYM(field, sym)                                                               \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, sym));                            \
+  if (!a.field) return fail(LASR_E_ARG, "lasr_comm: librccl.so has no symbol %s", sym);
+  LASR_SYM(GetUniqueId, "ncclGetUniqueId")
+  LASR_SYM(CommInitRank, "ncclCommInitRank")
+  LASR_SYM(CommDestroy, "ncclCommDestroy")
+  LASR_SYM(AllReduce, "ncclAllReduce")
+  LASR_SYM(Broadcast, "ncclBroadcast")
+  LASR_SYM(GroupStart, "ncclGroupStart")
+  LASR_SYM(GroupEnd, "ncclGroupEnd")
+  LASR_SYM(GetErrorString, "ncclGetErrorString")
+#undef LASR_SYM
+  g_rccl = a;
+  return 0;
+}
+
+static int nccl_fail(ncclResult_t r, const char* what) {
+  return fail((int)r > 0 ? 1000 + (int)r : 999, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+}
+#define LASR_NCCL(expr, what)                                  \
+  do {                                                         \
+    ncclResult_t r__ = (expr);                                 \
+    if (r__ != ncclSuccess) return ::lasr::nccl_fail(r__, what); \
+  } while (0)
+#define LASR_HIP(expr, what)                                   \
+  do {                                                         \
+    hipError_t e__ = (expr);                                   \
+    if (e__ != hipSuccess) return ::lasr::hip_fail(e__, what); \
+  } while (0)
+
+}  // namespace lasr
+
+using namespace lasr;
+
+struct lasr_comm {
+  ncclComm_t comm = nullptr;
+  hipStream_t side = nullptr;        // library-owned: every collective of this communicator runs here
+  hipEvent_t ev_in = nullptr;        // producer stream -> side stream
+  hipEvent_t ev_out = nullptr;       // side stream -> consumer stream
+  int world = 1, rank = 0, device = 0;
+  int64_t calls = 0;
+};
+
+extern "C" int lasr_comm_unique_id(void* id_out, size_t id_bytes) {
+  LASR_CHECK_ARG(id_out && id_bytes >= LASR_COMM_ID_BYTES, "lasr_comm_unique_id: need a %d-byte buffer", LASR_COMM_ID_BYTES);
+  static_assert(sizeof(ncclUniqueId) == LASR_COMM_ID_BYTES, "unique id size");
+  LASR_TRY(load_rccl());
+  ncclUniqueId id;
+  LASR_NCCL(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int lasr_comm_init(lasr_comm_t** out, const void* unique_id, size_t id_bytes, int world, int rank, int device) {
+  LASR_CHECK_ARG(out && unique_id && id_bytes >= LASR_COMM_ID_BYTES, "lasr_comm_init: null pointer / short id");
+  LASR_CHECK_ARG(world >= 1 && rank >= 0 && rank < world && device >= 0, "lasr_comm_init: world=%d rank=%d device=%d", world, rank, device);
+  LASR_TRY(load_rccl());
+  LASR_HIP(hipSetDevice(device), "hipSetDevice");
+  lasr_comm* c = new lasr_comm();
+  c->world = world; c->rank = rank; c->device = device;
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { delete c; return nccl_fail(r, "ncclCommInitRank"); }
+  hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
+  if (e != hipSuccess) { lasr_comm_destroy(c); return hip_fail(e, "lasr_comm_init: stream / events"); }
+  *out = c;
+  return 0;
+}
+
+extern "C" int lasr_comm_destroy(lasr_comm_t* c) {
+  if (!c) return 0;
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  delete c;
+  return 0;
+}
+
+extern "C" int lasr_comm_world(const lasr_comm_t* c) { return c ? c->world : -1; }
+extern "C" int lasr_comm_rank(const lasr_comm_t* c) { return c ? c->rank : -1; }
+
+// the side stream picks up after everything enqueued on `producer` so far
+static int order_after(lasr_comm* c, void* producer) {
+  LASR_HIP(hipEventRecord(c->ev_in, as_stream(producer)), "hipEventRecord(producer)");
+  LASR_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0), "hipStreamWaitEvent(side)");
+  return 0;
+}
+
+extern "C" int lasr_comm_allreduce(lasr_comm_t* c, float* buf, int64_t count, void* producer_stream) {
+  LASR_CHECK_ARG(c && buf && count > 0, "lasr_comm_allreduce: null pointer / empty bucket");
+  LASR_TRY(order_after(c, producer_stream));
+  LASR_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->comm, c->side), "ncclAllReduce");
+  c->calls += 1;
+  return 0;
+}
+
+extern "C" int lasr_comm_allreduce_ranges(lasr_comm_t* c, float* base, const int64_t* lo, const int64_t* hi, int n_ranges,
+                                          void* producer_stream) {
+  LASR_CHECK_ARG(c && base && lo && hi && n_ranges > 0 && n_ranges <= 64, "lasr_comm_allreduce_ranges: bad argument");
+  for (int i = 0; i < n_ranges; ++i) LASR_CHECK_ARG(lo[i] >= 0 && hi[i] > lo[i], "lasr_comm_allreduce_ranges: range %d", i);
+  LASR_TRY(order_after(c, producer_stream));
+  LASR_NCCL(g_rccl.GroupStart(), "ncclGroupStart");      // one fused launch for the pieces of a bucket
+  for (int i = 0; i < n_ranges; ++i) {
+    ncclResult_t r = g_rccl.AllReduce(base + lo[i], base + lo[i], (size_t)(hi[i] - lo[i]), ncclFloat32, ncclSum, c->comm, c->side);
+    if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return nccl_fail(r, "ncclAllReduce"); }
+  }
+  LASR_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+  c->calls += 1;
+  return 0;
+}
+
+extern "C" int lasr_comm_broadcast(lasr_comm_t* c, float* buf, int64_t count, int root, void* producer_stream) {
+  LASR_CHECK_ARG(c && buf && count > 0 && root >= 0 && root < c->world, "lasr_comm_broadcast: bad argument");
+  LASR_TRY(order_after(c, producer_stream));
+  LASR_NCCL(g_rccl.Broadcast(buf, buf, (size_t)count, ncclFloat32, root, c->comm, c->side), "ncclBroadcast");
+  return 0;
+}
+
+extern "C" int lasr_comm_wait(lasr_comm_t* c, void* consumer_stream) {
+  LASR_CHECK_ARG(c, "lasr_comm_wait: null communicator");
+  LASR_HIP(hipEventRecord(c->ev_out, c->side), "hipEventRecord(side)");
+  LASR_HIP(hipStreamWaitEvent(as_stream(consumer_stream), c->ev_out, 0), "hipStreamWaitEvent(consumer)");
+  return 0;
+}

@@ -3,6 +3,7 @@
 // Replaces models/QuartNet.py:33-37 (MaskCNN lengths, BatchNorm1d(eps=1e-3), ReLU) and :74-77
 // (residual add + ReLU), plus their autograd backward.  All statistics are f32.
 #include "common.h"
+#include "bn_final.h"
 #include <algorithm>
 
 namespace lasr {
@@ -35,40 +36,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
   }
 }
 
-__global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, float Tf, int32_t* __restrict__ lens) {
+__global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, float Tf, int32_t* __restrict__ lens,
+                                    uint32_t* __restrict__ zero, int64_t n_zero) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < B) lens[i] = (int32_t)(Tf * pct[i]);  // f32 product, truncation toward zero (torch .int())
+  if (i < n_zero) zero[i] = 0u;                 // the plan's ticket counters, cleared by the first launch of a forward
 }
 
-// ------------------------------------------------------------------ BN finalize --------------
-__device__ __forceinline__ void bn_finalize_channel(float s, float q, int64_t c, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, float* __restrict__ rmean,
-                                                    float* __restrict__ rvar, float* __restrict__ coef, float* __restrict__ saved,
-                                                    int64_t C, float n, float eps, float momentum, int training) {
-  float mean, var;
-  if (training) {
-    // sums arrive in f32; the subtraction is done in double to keep E[x^2]-E[x]^2 benign
-    const double m = (double)s / n;
-    double v = (double)q / n - m * m;
-    if (v < 0) v = 0;
-    mean = (float)m;
-    var = (float)v;
-    if (rmean) {
-      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-      const float unbiased = n > 1.f ? (float)(v * (double)n / ((double)n - 1.0)) : var;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
-    }
-  } else {
-    mean = rmean[c];
-    var = rvar[c];
-  }
-  const float rstd = 1.0f / sqrtf(var + eps);
-  const float a = gamma[c] * rstd;
-  coef[c] = a;
-  coef[C + c] = beta[c] - mean * a;
-  if (saved) { saved[c] = mean; saved[C + c] = rstd; }
-}
-
+// ------------------------------------------------------------------ BN finalize (bn_final.h) --
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                    float* __restrict__ coef, float* __restrict__ saved, int64_t C, float n, float eps,
@@ -534,11 +509,16 @@ extern "C" int lasr_btc_to_bct(const void* in, int dtype, float* out, int64_t B,
   return 0;
 }
 
-extern "C" int lasr_mask_lengths(const float* pct, int64_t B, int64_t T_, int32_t* lens, void* stream) {
-  LASR_CHECK_ARG(pct && lens && B > 0 && T_ > 0, "lasr_mask_lengths: bad argument");
-  hipLaunchKernelGGL(mask_lengths_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), pct, B, (float)T_, lens);
+extern "C" int lasr_mask_lengths_zero(const float* pct, int64_t B, int64_t T_, int32_t* lens, uint32_t* zero, int64_t n_zero,
+                                      void* stream) {
+  LASR_CHECK_ARG(pct && lens && B > 0 && T_ > 0 && n_zero >= 0 && (zero || n_zero == 0), "lasr_mask_lengths: bad argument");
+  hipLaunchKernelGGL(mask_lengths_kernel, dim3((unsigned)cdiv(std::max<int64_t>(B, n_zero), 256)), dim3(256), 0, as_stream(stream), pct, B,
+                     (float)T_, lens, zero, n_zero);
   LASR_LAUNCH_CHECK("mask_lengths_kernel");
   return 0;
+}
+extern "C" int lasr_mask_lengths(const float* pct, int64_t B, int64_t T_, int32_t* lens, void* stream) {
+  return lasr_mask_lengths_zero(pct, B, T_, lens, nullptr, 0, stream);
 }
 
 extern "C" int lasr_bn_finalize(const float* stats, const float* gamma, const float* beta, float* running_mean,

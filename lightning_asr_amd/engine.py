@@ -245,32 +245,38 @@ class NativeModel:
         return out
 
     def bucket_schedule(self, n_buckets: Optional[int] = None):
-        """[(unit_stop, lo, hi)] from the LAST bucket to the first: once the backward stage ending at
-        ``unit_stop`` is enqueued, grads[lo:hi] are final and their all-reduce may start.  Only for the plain
-        variant: the context LSTM's parameters sit at the tail of the flat buffer but are differentiated mid-way.
+        """[(unit_stop, [(lo, hi), ...])] from the LAST bucket to the first: once the backward stage ending at ``unit_stop`` is
+        enqueued, those pieces of the flat gradient are final and their all-reduce may start.
 
         n_buckets (default: env LASR_DP_BUCKETS, else 2): 4 = SURVEY 8e's cuts (last_cnn2+decoder | 512-channel blocks |
         256-channel blocks | first_cnn); 2 = the first two and the last two merged.  Every stage ends in its own
         weight-gradient launch + reduction, so fewer stages compute faster (4 stages cost +0.18 ms per step on one GPU,
-        2 stages +0.05 ms) while the big first bucket (17.8 MB) still rides under the second half of backward."""
-        if self.variant != "plain":
-            return [(0, 0, self.n_param)]
+        2 stages +0.05 ms) while the big first bucket (17.8 MB) still rides under the second half of backward.
+        Context / ContextSE: the BiLSTM's parameters sit between last_cnn2 and the decoder in the flat buffer but are
+        differentiated with block3 (models/QuartNetContext.py:171-199), so with 4 buckets they travel with the 512-channel
+        blocks as a second piece of that bucket; with 2 buckets the first stage ends at block3 and covers them anyway."""
         if n_buckets is None:
             n_buckets = int(os.environ.get("LASR_DP_BUCKETS", "2"))
         names = self.unit_names()
         bounds = self.bucket_bounds()                      # [0, |first_cnn|, |256 blocks|, |512 blocks|, n]
         first512 = next(i for i, n in enumerate(names) if n == "block3")
         last = len(names) - 1                              # last_cnn2 (+ decoder head)
-        if n_buckets >= 4:
-            stops = [last, first512, 1, 0]
-            return [(stops[k], bounds[3 - k], bounds[4 - k]) for k in range(4)]
         if n_buckets <= 1:
-            return [(0, 0, self.n_param)]
-        return [(first512, bounds[2], bounds[4]), (0, bounds[0], bounds[2])]
+            return [(0, [(0, self.n_param)])]
+        if n_buckets < 4:
+            return [(first512, [(bounds[2], bounds[4])]), (0, [(bounds[0], bounds[2])])]
+        lstm = [t for t in self.param_infos() if "context_rnn" in t.name]
+        if lstm:
+            l0, l1 = lstm[0].offset, lstm[-1].offset + lstm[-1].numel
+            head = [(bounds[3], l0), (l1, bounds[4])]
+            mid = [(bounds[2], bounds[3]), (l0, l1)]
+        else:
+            head, mid = [(bounds[3], bounds[4])], [(bounds[2], bounds[3])]
+        return [(last, head), (first512, mid), (1, [(bounds[1], bounds[2])]), (0, [(bounds[0], bounds[1])])]
 
     def loss_backward_staged(self, feats_btc, pct, targets, tgt_lens, on_bucket, want_argmax: bool = True, n_buckets: Optional[int] = None):
-        """loss_backward in stages; ``on_bucket(lo, hi)`` is called right after the stage that finalises
-        grads[lo:hi] has been enqueued (the data-parallel host starts that bucket's all-reduce there)."""
+        """loss_backward in stages; ``on_bucket(ranges)`` (ranges = [(lo, hi), ...] of the flat gradient) is called right after
+        the stage that finalises them has been enqueued (the data-parallel host starts that bucket's all-reduce there)."""
         B, T_in, _ = feats_btc.shape
         S = targets.shape[1]
         ws = self.workspace(B, T_in, S)
@@ -280,14 +286,14 @@ class NativeModel:
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         nll = torch.empty(B, dtype=torch.float32, device=self.device)
         sched = self.bucket_schedule(n_buckets)
-        stop0, lo0, hi0 = sched[0]
+        stop0, ranges0 = sched[0]
         call("lasr_model_loss_backward_partial", self._h, _p(self.params), _p(self.buffers), _p(feats_btc), _p(pct), _p(targets),
              _p(tgt_lens), B, T_in, S, _p(logp), _p(loss), _p(nll), _p(am), _p(self.grads), _p(ws), ws.numel(), stop0, _stream())
-        on_bucket(lo0, hi0)
-        for stop, lo, hi in sched[1:]:
+        on_bucket(ranges0)
+        for stop, ranges in sched[1:]:
             call("lasr_model_backward_continue", self._h, _p(self.params), _p(feats_btc), B, T_in, _p(self.grads), _p(ws), ws.numel(),
                  stop, _stream())
-            on_bucket(lo, hi)
+            on_bucket(ranges)
         for k in self.counters:
             self.counters[k] += 1
         self._last_feats, self._last_logp = feats_btc, logp

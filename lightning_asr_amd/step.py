@@ -11,7 +11,10 @@ from typing import Optional
 
 import torch
 
+import os
+
 from . import ops
+from .comm import Communicator
 from .engine import NativeModel
 from .schedule import CosineAnnealingWarmupRestarts
 
@@ -19,7 +22,10 @@ from .schedule import CosineAnnealingWarmupRestarts
 class TrainStep:
     def __init__(self, model: NativeModel, learning_rate: float = 1e-2, weight_decay: float = 1e-3,
                  betas=(0.8, 0.5), eps: float = 1e-8, schedule: Optional[CosineAnnealingWarmupRestarts] = None,
-                 process_group=None):
+                 process_group=None, comm: Optional[Communicator] = None):
+        """comm: the library-owned RCCL communicator (lasr_comm_*).  Default for world > 1 on the nccl backend: one is built
+        from the torch.distributed group (which then only bootstraps the unique id); ``LASR_COMM=torch`` keeps the gradient
+        exchange on torch.distributed (the only choice for gloo groups: CPU rehearsal, two ranks sharing a GPU in the tests)."""
         self.model = model
         self.wd, self.betas, self.eps = weight_decay, betas, eps
         dev = model.device
@@ -36,13 +42,24 @@ class TrainStep:
         self.global_step = 0
         self.overlap = True        # overlap the gradient all-reduce with backward (world > 1)
         self._reduced = False
+        self.comm = comm
+        if comm is not None:
+            self.world = comm.world
+        elif self.world > 1 and os.environ.get("LASR_COMM", "rccl") == "rccl" and \
+                torch.distributed.get_backend(process_group) == "nccl":
+            self.comm = Communicator.from_torch_distributed(dev, process_group)
         # exercise the staged + async all-reduce path on a 1-rank group too (validation on one GPU)
-        self.force_staged = bool(int(__import__("os").environ.get("LASR_FORCE_OVERLAP", "0"))) and torch.distributed.is_initialized()
+        self.force_staged = bool(int(os.environ.get("LASR_FORCE_OVERLAP", "0"))) and \
+            (self.comm is not None or torch.distributed.is_initialized())
         self._prefetched = None    # (key, feats, pct) of the batch announced by the previous step(prefetch_wave=...)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP wrap-time broadcast of parameters and buffers from rank 0."""
-        if self.world > 1:
+        if self.comm is not None:
+            self.comm.broadcast(self.model.params, src)
+            self.comm.broadcast(self.model.buffers, src)
+            self.comm.wait()
+        elif self.world > 1:
             torch.distributed.broadcast(self.model.params, src, group=self.pg)
             torch.distributed.broadcast(self.model.buffers, src, group=self.pg)
 
@@ -55,7 +72,11 @@ class TrainStep:
         m = self.model
         if self.world > 1 and not getattr(self, "_reduced", False):
             # one flat 20 MB SUM all-reduce; the 1/world average is folded into the optimiser's grad scale
-            torch.distributed.all_reduce(m.grads, group=self.pg)
+            if self.comm is not None:
+                self.comm.all_reduce(m.grads)
+                self.comm.wait()
+            else:
+                torch.distributed.all_reduce(m.grads, group=self.pg)
         self._reduced = False
         ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
                           self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
@@ -70,12 +91,18 @@ class TrainStep:
             # bucketed SUM all-reduce, launched bucket by bucket in reverse layer order while the units below
             # are still being differentiated: RCCL runs on its own stream and waits (event) only for the
             # kernels enqueued so far; the optimiser waits for all buckets.
-            works = []
-            loss, nll, logp, am = m.loss_backward_staged(
-                feats, pct, targets, tgt_lens,
-                lambda lo, hi: works.append(torch.distributed.all_reduce(m.grads[lo:hi], group=self.pg, async_op=True)))
-            for w in works:
-                w.wait()
+            if self.comm is not None:       # library-owned communicator and side stream (lasr_comm_*)
+                loss, nll, logp, am = m.loss_backward_staged(feats, pct, targets, tgt_lens,
+                                                             lambda ranges: self.comm.all_reduce_ranges(m.grads, ranges))
+                self.comm.wait()
+            else:
+                works = []
+                loss, nll, logp, am = m.loss_backward_staged(
+                    feats, pct, targets, tgt_lens,
+                    lambda ranges: works.extend(torch.distributed.all_reduce(m.grads[lo:hi], group=self.pg, async_op=True)
+                                                for lo, hi in ranges))
+                for w in works:
+                    w.wait()
             self._reduced = True
         else:
             loss, nll, logp, am = m.loss_backward(feats, pct, targets, tgt_lens)

@@ -113,3 +113,68 @@ def test_feature_prefetch_is_bit_identical(dev):
     p1, l1 = run(True)
     assert l0 == l1
     assert torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize("variant,n_buckets", [("plain", 2), ("plain", 4), ("context_se", 2), ("context_se", 4)])
+def test_native_rccl_communicator_staged_step_one_rank(dev, variant, n_buckets, monkeypatch):
+    """lasr_comm_* (librccl called by the library on its own side stream, ordered by events) on a 1-rank communicator: the
+    staged backward issues every bucket's ncclAllReduce from the stage boundary, the optimiser waits on the side stream.
+    With one rank the all-reduce is the identity, so the trajectory must equal, bit for bit, the same staged step with the
+    collectives left out - for the context variants too, whose BiLSTM parameters form the second piece of a bucket (grouped
+    launch).  (Staged vs single-call backward is compared in test_gpu_model.py; in bf16 they differ in the split-K order.)"""
+    from lightning_asr_amd.comm import Communicator
+    from lightning_asr_amd.engine import NativeModel
+    from lightning_asr_amd.step import TrainStep
+    monkeypatch.setenv("LASR_DP_BUCKETS", str(n_buckets))
+    batches = [tuple(t.to(dev) for t in _batch(0, s)) for s in range(3)]
+
+    class NoComm:                      # same staging, no collectives
+        world, rank = 1, 0
+        calls = 0
+
+        def all_reduce_ranges(self, flat, ranges):
+            NoComm.calls += 1
+
+        def broadcast(self, flat, root=0):
+            pass
+
+        def wait(self):
+            pass
+
+    def run(comm):
+        m = NativeModel(variant, 28, mask=True, act="relu", dtype=torch.bfloat16, device=dev)
+        m.init_parameters(seed=5)
+        ts = TrainStep(m, 1e-2, 1e-3, comm=comm)
+        ts.force_staged = True
+        if not isinstance(comm, NoComm):
+            ts.broadcast_parameters()
+            sched = m.bucket_schedule()
+            assert len(sched) == n_buckets
+            covered = sorted(r for _, ranges in sched for r in ranges)
+            assert covered[0][0] == 0 and covered[-1][1] == m.n_param
+            assert all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:]))       # the pieces tile the flat gradient
+        losses = [float(ts.step(w, tg, tl)[0].item()) for w, tg, tl in batches]
+        torch.cuda.synchronize()
+        return m.params.clone(), losses
+    p0, l0 = run(NoComm())
+    assert NoComm.calls == n_buckets * len(batches)
+    comm = Communicator.single(dev)
+    assert comm.world == 1 and comm.rank == 0
+    p1, l1 = run(comm)
+    comm.close()
+    assert l0 == l1
+    assert torch.equal(p0, p1)
+
+
+def test_native_rccl_allreduce_orders_after_producer_stream(dev):
+    """the side stream must wait for the producer's kernels and the consumer for the collective: fill -> all-reduce -> read
+    on a 64 MB buffer gives the filled value on every element (a missing event edge shows up as stale zeros)"""
+    from lightning_asr_amd.comm import Communicator
+    comm = Communicator.single(dev)
+    buf = torch.zeros(16 << 20, dtype=torch.float32, device=dev)
+    for k in range(1, 4):
+        buf.fill_(float(k))
+        comm.all_reduce_ranges(buf, [(0, 1 << 20), (1 << 20, buf.numel())])
+        comm.wait()
+        assert float(buf.sum().item()) == float(k) * buf.numel()
+    comm.close()

@@ -176,8 +176,10 @@ def test_staged_backward_equals_single_call(dev, n_buckets):
     m2.grads.fill_(float("nan"))
     seen = []
 
-    def on_bucket(lo, hi):
+    def on_bucket(ranges):
         torch.cuda.synchronize()
+        assert len(ranges) == 1                                   # plain variant: every bucket is one contiguous piece
+        lo, hi = ranges[0]
         assert torch.isfinite(m2.grads[lo:hi]).all()             # this bucket is final ...
         seen.append((lo, hi))
     m2.loss_backward_staged(feats, pct.to(dev), tg.to(dev), tsz.to(dev), on_bucket, n_buckets=n_buckets)
