@@ -188,18 +188,6 @@ typedef struct {
 int lasr_bn_finalize_partials(const lasr_bn_branch* branches, int n_branches, int64_t C, int64_t n_rows, float eps,
                               float momentum, void* stream);
 
-/* The forward 1x1 conv(s) of a unit together with their training-mode BatchNorms (models/QuartNet.py:31-35,63-64):
- * lasr_gemm_batch_partials + lasr_bn_finalize_partials as ONE call.  For bf16 problems that take the 256-row tile form the
- * coefficients are finalised INSIDE the GEMM launch by the last-arriving row tile of every column tile (bit-identical sums,
- * one launch less per unit); otherwise the finalize launch follows.  branches[i].partials / n_partials are ignored;
- * tickets: 16 * n_probs counters that are zero on entry (lasr_mask_lengths_zero clears them) and zero again on exit, or
- * NULL to force the two-launch form. */
-int lasr_gemm_batch_bn(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, const lasr_bn_branch* branches,
-                       float eps, float momentum, uint32_t* tickets, void* workspace, size_t workspace_bytes, void* stream);
-/* lasr_mask_lengths that also clears n_zero 32-bit words at `zero` (the ticket counters above) in the same launch */
-int lasr_mask_lengths_zero(const float* pct, int64_t B, int64_t T, int32_t* lens, uint32_t* zero, int64_t n_zero, void* stream);
-
-
 /* out = act( (y*coef_a + coef_b) * se_scale[b][c] + (y2*coef2_a + coef2_b) )
  * y2/coef2 (residual branch) and se_scale ([B][C] f32) may be NULL.
  * (BN-apply + SE scale + residual add + ReLU: models/QuartNet.py:35-37,74-77; ContextSE :55) */
@@ -412,6 +400,16 @@ int lasr_model_loss_backward_partial(lasr_model_t* m, const float* params, float
                                      int64_t unit_stop, void* stream);
 int lasr_model_backward_continue(lasr_model_t* m, const float* params, const void* feats, int64_t B, int64_t T_in,
                                  float* grads, void* workspace, size_t workspace_bytes, int64_t unit_stop, void* stream);
+
+/* Levenshtein distances of a batch ON THE DEVICE (utils/asr_metrics.py:26-59,187-228: editdistance.eval per utterance on
+ * the host): hyp_tokens [B][ld_hyp] i32 / hyp_lens as written by lasr_greedy_decode, ref_tokens [B][ld_ref] i64 / ref_lens
+ * as the collate's targets / target_sizes.  space_id < 0: units are token ids (CER; the reference's file-path
+ * vocabularies); space_id >= 0: units are words = runs of tokens between space tokens (str.split()).
+ * dist[b], ref_units[b] (B) i32; totals (may be NULL): totals[0] += sum dist, totals[1] += sum ref_units (the metric's
+ * `scores` / `words` states).  At most 2048 tokens per utterance and side.                                               */
+int lasr_edit_distance_batch(const int32_t* hyp_tokens, const int32_t* hyp_lens, int64_t ld_hyp, const int64_t* ref_tokens,
+                             const int32_t* ref_lens, int64_t ld_ref, int64_t B, int space_id, int32_t* dist, int32_t* ref_units,
+                             int64_t* totals, void* stream);
 
 /* ---- data-parallel gradient exchange: RCCL over xGMI, called by the library itself ------------------------------
  * Replaces the NCCL all-reduce the reference gets from Lightning's DDP plugin (conf/conf.yaml:30-31 `accelerator: ddp`,

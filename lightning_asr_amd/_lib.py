@@ -98,8 +98,7 @@ SIGNATURES = {
     "lasr_model_unit_info": (_i32, [_p, _i64, C.c_char_p, _sz]),
     "lasr_model_loss_backward_partial": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _i64, _p]),
     "lasr_model_backward_continue": (_i32, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _i64, _p]),
-    "lasr_gemm_batch_bn": (_i32, [_p, _i32, _i32, _i32, _p, _f32, _f32, _p, _p, _sz, _p]),
-    "lasr_mask_lengths_zero": (_i32, [_p, _i64, _i64, _p, _p, _i64, _p]),
+    "lasr_edit_distance_batch": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
     "lasr_comm_unique_id": (_i32, [_p, _sz]),
     "lasr_comm_init": (_i32, [C.POINTER(_p), _p, _sz, _i32, _i32, _i32]),
     "lasr_comm_destroy": (_i32, [_p]),

@@ -1,7 +1,6 @@
 // Shared between the f32-MFMA (gemm.hip) and bf16-MFMA (gemm_bf16.hip) GEMM kernels.
 #pragma once
 #include "common.h"
-#include "bn_final.h"
 
 namespace lasr {
 
@@ -14,7 +13,6 @@ struct GemmArgs {
   float* split_ws;       // [split][M][N] or null
   int64_t k_per_split;
   int vecA, vecB;
-  const BnFinal* fin = nullptr;    // host pointer or null: finalise the BN coefficients in the last-arriving workgroup of each column tile
 };
 
 // bf16-MFMA path (gemm_bf16.hip); returns LASR_E_SHAPE-free 0 on launch, or -100 when the
@@ -22,9 +20,8 @@ struct GemmArgs {
 // gz = split-K slices; the launcher picks the tile (128x128 or 256x256) and reports through stat_tiles
 // how many row tiles wrote BN partial sums ([tile][2][N] in stat_partials).
 int launch_gemm_bf16(const GemmArgs& g, int gz, int dtype_c, int transA, int transB, hipStream_t st, int* stat_tiles);
-// fin_done (may be null) is set when the launch took the tile form that honours GemmArgs::fin
 int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c, int transA, int transB, hipStream_t st,
-                           int* stat_tiles, bool* fin_done = nullptr);
+                           int* stat_tiles);
 
 // up to 32 split-K weight-gradient problems (transA = transB = 1, f32 slabs in g[i].split_ws), one launch
 int launch_gemm_bf16_dual(const GemmArgs& g, const void* A2, int64_t lda2, int64_t K1, const float* bias, int act, hipStream_t st);

@@ -349,7 +349,7 @@ extern "C" size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs
 struct SplitOut { const float* partials; int splits; };
 static int gemm_batch_impl(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, int transA, int transB,
                            int split_k, void* workspace, size_t workspace_bytes, void* stream, StatOut* stat_out,
-                           SplitOut* split_out = nullptr, const BnFinal* fins = nullptr, bool* fin_done = nullptr) {
+                           SplitOut* split_out = nullptr) {
   LASR_CHECK_ARG(probs && n_probs >= 1 && n_probs <= 2, "lasr_gemm_batch: 1 or 2 problems");
   const size_t need = lasr_gemm_batch_workspace_bytes(probs, n_probs, split_k);
   if (need > 0 && (!workspace || workspace_bytes < need)) return fail(LASR_E_WORKSPACE, "lasr_gemm_batch: workspace %zu < %zu", workspace_bytes, need);
@@ -392,7 +392,6 @@ static int gemm_batch_impl(const lasr_gemm_problem* probs, int n_probs, int dtyp
       a.k_per_split = q.K;
     }
     if (q.stats) { a.stat_partials = reinterpret_cast<float*>(wsp); wsp += align_up((size_t)cdiv(q.M, BM) * 2 * q.N * sizeof(float), 256); }
-    a.fin = (fins && q.stats) ? fins + i : nullptr;
     splits[i] = sk;
   }
   hipStream_t st = as_stream(stream);
@@ -402,7 +401,7 @@ static int gemm_batch_impl(const lasr_gemm_problem* probs, int n_probs, int dtyp
     by += (double)(probs[i].M * probs[i].K + probs[i].N * probs[i].K) * 2 + (double)probs[i].M * probs[i].N * dtype_size(dtype_c);
   }
   const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
-  const int rc = launch_gemm_bf16_batch(g, splits, 2, dtype_c, transA, transB, st, stat_tiles, fin_done);
+  const int rc = launch_gemm_bf16_batch(g, splits, 2, dtype_c, transA, transB, st, stat_tiles);
   prof_end(tok, st);
   if (rc) return rc;
   if (split_out) {
@@ -454,31 +453,6 @@ extern "C" int lasr_gemm_batch_partials(const lasr_gemm_problem* probs, int n_pr
   LASR_TRY(gemm_batch_impl(probs, n_probs, dtype_ab, dtype_c, transA, transB, 1, workspace, workspace_bytes, stream, so));
   for (int i = 0; i < n_probs; ++i) { stat_partials[i] = so[i].partials; stat_tiles[i] = so[i].tiles; }
   return 0;
-}
-
-// The unit's two forward 1x1 convs with their training-mode BatchNorms: GEMMs (+ MaskCNN row zeroing), per-tile column sums
-// of the stored outputs, and the BN coefficients / saved statistics / running statistics - finalised inside the GEMM launch
-// by the last-arriving row tile of every column tile when the launch takes the 256-row tile form, by one
-// bn_finalize_partials launch otherwise.  tickets: >= 16 zero-initialised counters per problem (left zero again).
-extern "C" int lasr_gemm_batch_bn(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, const lasr_bn_branch* branches,
-                                  float eps, float momentum, unsigned* tickets, void* workspace, size_t workspace_bytes, void* stream) {
-  LASR_CHECK_ARG(probs && branches && (n_probs == 1 || n_probs == 2) && workspace, "lasr_gemm_batch_bn: bad argument");
-  BnFinal fins[2];
-  for (int i = 0; i < n_probs; ++i) {
-    const lasr_bn_branch& q = branches[i];
-    LASR_CHECK_ARG(probs[i].stats && q.gamma && q.beta && q.coef, "lasr_gemm_batch_bn: every problem needs stats and a BN branch");
-    LASR_CHECK_SHAPE(cdiv(probs[i].N, 128) <= 16, "lasr_gemm_batch_bn: N=%lld has more than 16 column tiles", (long long)probs[i].N);
-    fins[i] = {q.gamma, q.beta, q.running_mean, q.running_var, q.coef, q.saved, q.stats, tickets ? tickets + 16 * i : nullptr,
-               (float)probs[i].M, eps, momentum};
-  }
-  StatOut so[2] = {{nullptr, 0}, {nullptr, 0}};
-  bool done = false;
-  LASR_TRY(gemm_batch_impl(probs, n_probs, dtype_ab, dtype_c, 0, 0, 1, workspace, workspace_bytes, stream, so, nullptr,
-                           tickets ? fins : nullptr, &done));
-  if (done) return 0;
-  lasr_bn_branch br[2];
-  for (int i = 0; i < n_probs; ++i) { br[i] = branches[i]; br[i].partials = so[i].partials; br[i].n_partials = so[i].tiles; }
-  return lasr_bn_finalize_partials(br, n_probs, probs[0].N, probs[0].M, eps, momentum, stream);
 }
 
 extern "C" int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int transA, int transB,

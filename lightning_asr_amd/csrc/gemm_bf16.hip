@@ -42,7 +42,7 @@ struct Bf16Args {
 // Up to two independent problems of the same kind in ONE launch (a unit's main + residual 1x1 conv, or
 // their two weight gradients): twice the workgroups per launch keeps two per CU resident for the
 // split-K weight gradients (256 tiles each) and lets one problem's store tail overlap the other's loads.
-struct Bf16Batch { Bf16Args p[2]; BnFinal fin[2]; int tiles0, total; };
+struct Bf16Batch { Bf16Args p[2]; int tiles0, total; };
 
 // ---- global -> registers -> LDS: 4 x 16 B per thread per operand tile --------------------------------
 // 16-byte chunk c = tid + NT*p of a [ROWS x 64] operand tile.  K-contiguous operand: row c>>3, k (c&7)*8;
@@ -528,7 +528,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 // one 256 x 256 (256 x 128) output tile `lid` of problem g; SLAB: split-K slice into the f32 slab g.split_ws (no LDS image,
 // no statistics) - shared by the two-problem kernel and the many-problem weight-gradient kernel
 template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB, bool DUAL = false>
-__device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int lid, const BnFinal* fin = nullptr) {
+__device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int lid) {
 #ifdef LASR_GEMM_STAMPS
   unsigned long long* stamps = g_stamps;
 #endif
@@ -758,57 +758,6 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
         P[g.N + n] = s1;
       }
     }
-    if constexpr (!SLAB && !DUAL) {
-      if (fin && fin->ticket) {   // workgroup-uniform
-        // The row tile that arrives LAST at this column tile turns the gm rows of partial sums into the BN coefficients
-        // (was a separate ~5 us launch per unit, pure latency).  Release: every thread's partial-sum stores are made
-        // visible at device scope before the ticket is taken; acquire: the finishing workgroup invalidates before it reads
-        // the other tiles' rows (they were written through other XCDs' L2s).
-        __shared__ unsigned s_tk;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) s_tk = atomicAdd(fin->ticket + tn, 1u);
-        __syncthreads();
-        if (s_tk == (unsigned)g.gm - 1u) {
-          __threadfence();
-          if (tid == 0) fin->ticket[tn] = 0u;              // nobody else touches it before the next launch
-          // thread = one column of [sum | sumsq]; the summation order is exactly bn_finalize_partials_kernel's (8 partial
-          // lanes x 4 accumulators in f64, rows strided by 8 and 32), so both paths give the same bits
-          double* s_fin = reinterpret_cast<double*>(smem);   // [2][BTN]
-          const int which = tid / BTN, cc = tid - which * BTN, n = n0 + cc;
-          double tot = 0.0;
-          if (tid < 2 * BTN && n < g.N) {
-            const float* P = g.stat_partials + (size_t)which * g.N + n;
-            const size_t pitch = (size_t)2 * g.N;
-            double a[8][4];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[i][0] = a[i][1] = a[i][2] = a[i][3] = 0.0;
-            for (int r0 = 0; r0 < g.gm; r0 += 32) {
-              float v[32];
-#pragma unroll
-              for (int i = 0; i < 32; ++i) {
-                const float x = P[(size_t)min(r0 + i, g.gm - 1) * pitch];
-                v[i] = r0 + i < g.gm ? x : 0.f;
-              }
-#pragma unroll
-              for (int i = 0; i < 32; ++i) a[i & 7][(i >> 3) & 3] += (double)v[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tot += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
-          }
-          __syncthreads();                                   // the wave-partial rows in smem are dead
-          if (tid < 2 * BTN) s_fin[tid] = tot;
-          __syncthreads();
-          if (tid < BTN && n0 + tid < g.N) {
-            const float s = (float)s_fin[tid], q = (float)s_fin[BTN + tid];
-            const int c = n0 + tid;
-            if (fin->stats) { fin->stats[c] = s; fin->stats[g.N + c] = q; }
-            bn_finalize_channel(s, q, c, fin->gamma, fin->beta, fin->rmean, fin->rvar, fin->coef, fin->saved, g.N, fin->n, fin->eps,
-                                fin->momentum, 1);
-          }
-        }
-      }
-    }
   }
 #ifdef LASR_GEMM_STAMPS
   __builtin_amdgcn_s_waitcnt(0);   // the stores of this wave have been accepted
@@ -821,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   const int lid_all = xcd_remap(blockIdx.x, gb.total);
   const bool second = lid_all >= gb.tiles0;
   const Bf16Args& g = second ? gb.p[1] : gb.p[0];
-  gemm_bf16_big_tile<TRANS_A, TRANS_B, NARROW, false>(g, second ? lid_all - gb.tiles0 : lid_all, second ? &gb.fin[1] : &gb.fin[0]);
+  gemm_bf16_big_tile<TRANS_A, TRANS_B, NARROW, false>(g, second ? lid_all - gb.tiles0 : lid_all);
 }
 
 // Folded eval form of a residual unit: out = act([u_masked | x] . [a W | a2 Wr]^T + (b + b2)), one problem per launch,
@@ -860,7 +809,7 @@ static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
 // g[0..n): problems sharing dtype_c / transposition; gz[i] = split-K slices of problem i.
 // stat_tiles[i] receives the number of row tiles problem i writes BN partial sums for.
 int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c, int transA, int transB, hipStream_t st,
-                           int* stat_tiles, bool* fin_done) {
+                           int* stat_tiles) {
   const bool f32_out = dtype_c == LASR_F32 || g[0].split_ws != nullptr;   // split-K slabs are f32
   // The 256x256 tile pays when its (one per CU) workgroups cover most of the chip.
   static const int big_min = getenv("LASR_GEMM_BIG_MIN_TILES") ? atoi(getenv("LASR_GEMM_BIG_MIN_TILES")) : 120;
@@ -880,15 +829,6 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
   if (n > 1) LASR_TRY(fill_args(b.p[1], g[1], tm, tn, gz[1]));
   b.tiles0 = b.p[0].gn * b.p[0].gm * b.p[0].gz;
   b.total = b.tiles0 + (n > 1 ? b.p[1].gn * b.p[1].gm * b.p[1].gz : 0);
-  memset(b.fin, 0, sizeof(b.fin));
-  if (fin_done) *fin_done = false;
-  if (use_big && !transA && !transB) {      // the forward form: statistics of the outputs, finalised by the last row tile
-    bool all = true;
-    for (int i = 0; i < n; ++i) all = all && g[i].fin && g[i].fin->ticket && g[i].stat_partials && gz[i] == 1;
-    if (all)
-      for (int i = 0; i < n; ++i) b.fin[i] = *g[i].fin;
-    if (fin_done) *fin_done = all;
-  }
   if (stat_tiles)
     for (int i = 0; i < n; ++i) stat_tiles[i] = b.p[i].gm;
   const dim3 grid1((unsigned)b.total);

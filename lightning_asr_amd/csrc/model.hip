@@ -8,8 +8,6 @@
 #include <math.h>
 
 extern "C" size_t lasr_bn_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
-extern "C" int lasr_gemm_batch_bn(const lasr_gemm_problem* probs, int n_probs, int dtype_ab, int dtype_c, const lasr_bn_branch* branches,
-                                  float eps, float momentum, uint32_t* tickets, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" size_t lasr_gemm_workspace_bytes(int64_t M, int64_t N, int split_k, int want_stats);
 extern "C" size_t lasr_dwconv_wgrad_workspace_bytes(int64_t B, int64_t Tout, int64_t C, int k);
 extern "C" int lasr_log_softmax_bwd(const float*, const float*, float*, int64_t, int64_t, void*);
@@ -77,8 +75,7 @@ struct Plan {
   int64_t B = 0, T_in = 0, T = 0, S_max = 0;
   size_t total = 0;
   size_t o_lens = 0, o_logits = 0, o_glogits = 0, o_nll = 0, o_scratch = 0, o_g[2] = {0, 0}, o_d1 = 0, o_d2 = 0, o_du = 0, o_dxr = 0;
-  size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0, o_tickets = 0;
-  int64_t n_tickets = 0;   // 32 counters per unit (16 per branch): last-arriving-workgroup tickets of the fused BN finalize
+  size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0;
   size_t o_cat = 0, o_gx[2] = {0, 0}, o_lstm_saved = 0, o_dg[2] = {0, 0};   // context: [N][336] | [N][160] f32 x2 | saved | [N][160] f32 x2
   size_t scratch_bytes = 0, ctc_bytes = 0;
 };
@@ -203,8 +200,6 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   const int64_t N = B * p.T;
   size_t cur = 0;
   p.o_lens = take(cur, (size_t)B * sizeof(int32_t));
-  p.n_tickets = 32 * (int64_t)m->units.size();
-  p.o_tickets = take(cur, (size_t)p.n_tickets * sizeof(uint32_t));
   size_t scratch = 0;
   int64_t cmax = 0;
   for (Unit& u : m->units) {
@@ -391,7 +386,7 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
   const int dt = m->cfg.dtype;
   const int64_t T = p.T, N = B * T;
   int32_t* lens = reinterpret_cast<int32_t*>(at(ws, p.o_lens));
-  LASR_TRY(lasr_mask_lengths_zero(pct, B, T, lens, reinterpret_cast<uint32_t*>(at(ws, p.o_tickets)), p.n_tickets, stream));
+  LASR_TRY(lasr_mask_lengths(pct, B, T, lens, stream));
   if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
   void* scratch = at(ws, p.o_scratch);
   if (!training) {   // eval: BN coefficients of all layers from the running statistics, one launch
@@ -449,17 +444,17 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
       if (u.has_res) pr[1] = {x, wptr(m, params, ws, u.w_res), at(ws, u.o_y2), N, u.co, u.ci, nullptr, nullptr, 0, stats2};
       const int np = u.has_res ? 2 : 1;
       if (training && !no_fuse()) {
-        // the epilogue's per-tile BN sums are finalised by the last-arriving row tile inside the GEMM launch (bf16, 256-row
-        // tiles) or go straight to ONE reduce+finalize launch for both branches (LASR_NO_FUSED_FINALIZE=1 forces the latter)
-        static const bool no_fin = getenv("LASR_NO_FUSED_FINALIZE") != nullptr;
+        // the epilogue's per-tile BN sums go straight to ONE reduce+finalize launch for both branches
+        const float* parts[2] = {nullptr, nullptr};
+        int tiles[2] = {0, 0};
+        LASR_TRY(lasr_gemm_batch_partials(pr, np, dt, dt, 0, 0, scratch, p.scratch_bytes, parts, tiles, stream));
         lasr_bn_branch br[2];
-        br[0] = {nullptr, 0, params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
+        br[0] = {parts[0], tiles[0], params + u.bn.gamma, params + u.bn.beta, buffers + u.bn.rmean, buffers + u.bn.rvar,
                  atf(ws, u.o_coef), atf(ws, u.o_saved), stats};
         if (u.has_res)
-          br[1] = {nullptr, 0, params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
+          br[1] = {parts[1], tiles[1], params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
                    buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), stats2};
-        uint32_t* tk = no_fin ? nullptr : reinterpret_cast<uint32_t*>(at(ws, p.o_tickets)) + 32 * (&u - m->units.data());
-        LASR_TRY(lasr_gemm_batch_bn(pr, np, dt, dt, br, kBnEps, kBnMom, tk, scratch, p.scratch_bytes, stream));
+        LASR_TRY(lasr_bn_finalize_partials(br, np, u.co, N, kBnEps, kBnMom, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, np, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
         if (training) {   // (eval: every layer's coefficients were computed by one launch before the loop)

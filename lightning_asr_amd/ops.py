@@ -344,3 +344,17 @@ def novograd_step(params, grads, exp_avg, exp_avg_sq, offsets, lr_dev, beta1=0.8
     ws = _ws(nb, params.device)
     call("lasr_novograd_step", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(offsets), n_t, n, _p(lr_dev), beta1,
          beta2, eps, weight_decay, grad_scale, _p(ws), nb, _stream())
+
+
+def edit_distance_batch(tokens: torch.Tensor, n_tokens: torch.Tensor, targets: torch.Tensor, target_lens: torch.Tensor,
+                        space_id: int = -1, totals: Optional[torch.Tensor] = None):
+    """Levenshtein distance of every utterance on the device: tokens (B,T) i32 + n_tokens (B) i32 from greedy_decode,
+    targets (B,S) i64 + target_lens (B) i32.  space_id < 0: per token (CER); >= 0: per word.  Returns (dist (B) i32,
+    ref_units (B) i32); ``totals`` (2) i64, if given, is incremented by their sums (no host synchronisation)."""
+    B = tokens.shape[0]
+    dev = tokens.device
+    dist = torch.empty(B, dtype=torch.int32, device=dev)
+    units = torch.empty(B, dtype=torch.int32, device=dev)
+    call("lasr_edit_distance_batch", _p(tokens), _p(n_tokens), tokens.shape[1], _p(targets), _p(target_lens), targets.shape[1], B,
+         int(space_id), _p(dist), _p(units), _p(totals), _stream())
+    return dist, units

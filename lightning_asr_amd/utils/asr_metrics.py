@@ -1,8 +1,11 @@
 """WER/CER metric with the reference's interface (utils/asr_metrics.py:26-228).
 
-The greedy CTC collapse runs on the GPU (csrc/ctc.hip) when the predictions live there; only the
-collapsed token ids cross to the host.  Levenshtein distances are computed by the library's host
-routine ``lasr_edit_distance`` (editdistance is not a dependency)."""
+``WER.update`` runs entirely on the GPU: greedy CTC collapse (csrc/ctc.hip), then the Levenshtein distance of every
+utterance against its reference (csrc/editdist.hip, token units for CER, word units for WER); ``scores`` / ``words`` stay
+device scalars, so a training step's metric costs no D2H of token ids and no Python loop - only whoever reads the value
+(``self.log`` -> ``.item()``) synchronises.  The string helpers (``ctc_decoder_predictions_tensor``, ``decode_reference``,
+``word_error_rate``) keep the reference's host behaviour; their Levenshtein is the library's host routine
+``lasr_edit_distance`` (editdistance is not a dependency)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -55,6 +58,13 @@ class WER:
         self.log_prediction = log_prediction
         self.scores = torch.tensor(0)
         self.words = torch.tensor(0)
+        # device path: token units need nothing; word units need every label to be one non-space character or ' '
+        labels = [vocabulary[i] for i in range(len(vocabulary))]
+        self.space_id = -1
+        self.device_ok = True
+        if not use_cer:
+            self.device_ok = all(len(s) == 1 and (s == " " or not s.isspace()) for s in labels)
+            self.space_id = labels.index(" ") if " " in labels else len(labels) + 1      # no space label: one word per utterance
 
     def ctc_decoder_predictions_tensor(self, predictions: torch.Tensor, predictions_len: Optional[torch.Tensor] = None) -> List[str]:
         """ids (B,T) [+ lengths] -> greedy-collapsed strings (utils/asr_metrics.py:138-171)."""
@@ -74,6 +84,15 @@ class WER:
     def update(self, predictions, targets, target_lengths, t_lengths=None):
         if not self.ctc_decode:
             raise NotImplementedError("Implement me if you need non-CTC decode on predictions")
+        if self.device_ok and predictions.is_cuda and predictions.shape[1] <= 2048 and targets.shape[1] <= 2048:
+            dev = predictions.device
+            ids = predictions.to(torch.int32).contiguous()
+            lens = None if t_lengths is None else t_lengths.to(dev, torch.int32).contiguous()
+            tokens, n = ops.greedy_decode(ids, lens, self.blank_id)
+            dist, units = ops.edit_distance_batch(tokens, n, targets.to(dev, torch.int64).contiguous(),
+                                                  target_lengths.to(dev, torch.int32).contiguous(), self.space_id)
+            self.scores, self.words = dist.sum(), units.sum()          # device scalars: nothing is copied to the host here
+            return
         references = self.decode_reference(targets, target_lengths)
         hypotheses = self.ctc_decoder_predictions_tensor(predictions, t_lengths)
         words = scores = 0

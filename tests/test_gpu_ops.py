@@ -770,3 +770,84 @@ def test_mel_bf16_output_is_the_rounded_f32_output(dev):
     assert ((got - ref).abs() <= 2.0 ** -7 * ref.abs()).all()
     for b in range(3):
         assert torch.all(btf[b, int(frames[b]):] == 0)
+
+
+# ----------------------------------------------------------------------------------------- on-device edit distance
+@pytest.mark.parametrize("mode", ["cer", "wer"])
+def test_edit_distance_batch_matches_host_levenshtein(dev, mode):
+    """lasr_edit_distance_batch (one wave per utterance, prefix-min rows) against the oracle's plain DP
+    (utils/asr_metrics.py:26-59): token units and str.split() word units, empty / identical / disjoint / long cases."""
+    from lightning_asr_amd import ops
+    rng = random.Random(5)
+    V, space = 28, 0
+    B, T, S = 24, 700, 300
+    hyp = torch.full((B, T), -1, dtype=torch.int32)
+    ref = torch.zeros(B, S, dtype=torch.int64)
+    nh = torch.zeros(B, dtype=torch.int32)
+    nr = torch.zeros(B, dtype=torch.int32)
+    seqs = []
+    for b in range(B):
+        lr = [0, 1, 5, 64, 65, 130, 299, 300][b % 8] if b < 16 else rng.randint(0, S)
+        r = [rng.randint(0, V - 1) for _ in range(lr)]
+        if b == 3:
+            h = list(r)                                   # identical
+        elif b == 4:
+            h = []                                        # empty hypothesis
+        elif b % 3 == 0:
+            h = [x for x in r if rng.random() > 0.2]      # deletions
+            h = [x if rng.random() > 0.1 else rng.randint(0, V - 1) for x in h]
+        else:
+            h = [rng.randint(0, V - 1) for _ in range(rng.randint(0, T))]
+        if mode == "wer" and b == 5:
+            r = [space, space, 3, 4, space, space, 5, space]      # leading / repeated / trailing spaces
+            h = [3, 4, space, 5]
+        hyp[b, :len(h)] = torch.tensor(h, dtype=torch.int32) if h else hyp[b, :0]
+        ref[b, :len(r)] = torch.tensor(r, dtype=torch.int64) if r else ref[b, :0]
+        nh[b], nr[b] = len(h), len(r)
+        seqs.append((h, r))
+    totals = torch.tensor([7, 11], dtype=torch.int64, device=dev)
+    dist, units = ops.edit_distance_batch(hyp.to(dev), nh.to(dev), ref.to(dev), nr.to(dev), space if mode == "wer" else -1, totals)
+
+    def words(x):
+        out, cur = [], []
+        for t in x:
+            if t == space:
+                if cur:
+                    out.append(tuple(cur))
+                cur = []
+            else:
+                cur.append(t)
+        if cur:
+            out.append(tuple(cur))
+        return out
+    exp_d, exp_u = [], []
+    for h, r in seqs:
+        a, b_ = (h, r) if mode == "cer" else (words(h), words(r))
+        exp_d.append(R.levenshtein(a, b_))
+        exp_u.append(len(b_))
+    assert dist.cpu().tolist() == exp_d
+    assert units.cpu().tolist() == exp_u
+    assert totals.cpu().tolist() == [7 + sum(exp_d), 11 + sum(exp_u)]
+
+
+def test_wer_metric_device_path_equals_string_path(dev):
+    """WER.update on the device (greedy collapse + edit distance) gives the reference's scores/words (utils/asr_metrics.py:187-228)"""
+    from lightning_asr_amd.utils.asr_metrics import WER, word_error_rate
+    labels_cer = [c.strip() for c in open("data/labels.txt").readlines()]
+    labels_wer = [" ", "'"] + [chr(ord("a") + i) for i in range(26)]
+    g = torch.Generator().manual_seed(2)
+    for labels, use_cer in ((labels_cer, True), (labels_wer, False)):
+        V = len(labels)
+        B, T, S = 6, 120, 30
+        pred = torch.randint(0, V + 1, (B, T), generator=g)
+        pred[:, ::3] = V                                    # blanks in between
+        tg = torch.randint(0, V, (B, S), generator=g)
+        tl = torch.tensor([30, 12, 1, 25, 7, 30], dtype=torch.int32)
+        t_len = torch.tensor([120, 100, 5, 64, 65, 119], dtype=torch.int32)
+        m = WER(labels, use_cer=use_cer)
+        assert m.device_ok
+        val = m(pred.to(dev), tg.to(dev), tl.to(dev), t_len.to(dev))
+        hyps = m.ctc_decoder_predictions_tensor(pred.to(dev), t_len.to(dev))
+        refs = m.decode_reference(tg, tl)
+        assert float(val) == pytest.approx(word_error_rate(hyps, refs, use_cer=use_cer), rel=1e-6)
+        assert m.scores.is_cuda and m.words.is_cuda
