@@ -255,7 +255,7 @@ def main():
         step_no[0] += 1
         audio_s[0] += secs
         return ts.step(w, t_, l_, sample_lens=sl, prefetch_wave=None if nxt is None else nxt[0],
-                       prefetch_lens=None if nxt is None else nxt[1])
+                       prefetch_lens=None if nxt is None else nxt[1], want_logp=False)   # the training step reads loss + argmax only
 
     for _ in range(args.warmup):
         loss, *_ = one_step()

@@ -401,6 +401,22 @@ int lasr_model_loss_backward_partial(lasr_model_t* m, const float* params, float
 int lasr_model_backward_continue(lasr_model_t* m, const float* params, const void* feats, int64_t B, int64_t T_in,
                                  float* grads, void* workspace, size_t workspace_bytes, int64_t unit_stop, void* stream);
 
+/* ---- large-vocabulary loss head (BASELINE cfg5: C = 4334): decoder 1x1 conv + log_softmax + CTC + their backward without the
+ * (B, T', C) f32 log-prob / gradient tensors of models/QuartNet.py:275-290 and train.py:76-78 (444 MB each at bs = 32).
+ * lasr_gemm_rowstat: C [M][ldc] bf16 = A [M][K] . B [N][K]^T + bias plus, per (row, 256-column tile), the softmax statistics
+ *   of the STORED values: row_stat [M][tiles][2] = (max, sum exp(x - max)), row_arg [M][tiles] = first argmax column.
+ * lasr_ctc_loss_lean: from those, lse and argmax per row, the lattice over the gathered target / blank emissions only, and
+ *   grad [B*T][ldc] bf16 = gscale_b * d nll_b / d logits (1/B when gscale is NULL; zero rows past in_lens, NaN for an
+ *   infeasible utterance like torch), bias_grad (C) f32 = column sums of the unrounded gradient.  ldc = C rounded up to 8. */
+int lasr_gemm_rowstat(const void* A, const void* B, const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      float* row_stat, int32_t* row_arg, int* n_col_tiles, void* stream);
+size_t lasr_gemm_rowstat_bytes(int64_t M, int64_t N);
+size_t lasr_ctc_lean_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t S_max);
+int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* row_stat, const int32_t* row_arg, int n_col_tiles,
+                       const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T, int64_t C,
+                       int64_t S_max, int blank, float* nll, int32_t* argmax, void* grad, float* bias_grad, const float* gscale,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* Levenshtein distances of a batch ON THE DEVICE (utils/asr_metrics.py:26-59,187-228: editdistance.eval per utterance on
  * the host): hyp_tokens [B][ld_hyp] i32 / hyp_lens as written by lasr_greedy_decode, ref_tokens [B][ld_ref] i64 / ref_lens
  * as the collate's targets / target_sizes.  space_id < 0: units are token ids (CER; the reference's file-path

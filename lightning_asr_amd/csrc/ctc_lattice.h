@@ -76,7 +76,10 @@ __device__ __forceinline__ float lse2_fast(float a, float b) {
 // s_rows (EM_LDS): the emission matrix in LDS with one pad row on either side (row t at s_rows + t*C), so the
 // one-step-ahead gather needs no end-of-sequence clamp.  Stored rows hold kDead for unreachable states and
 // unspecified values for s >= 2S+1 (the gradient kernel reads s < 2S+1 only).
-template <int NS, bool EM_LDS, bool BETA>
+// COMPACT: `lp` / `s_rows` is the gathered emission matrix of ctc_lean.hip - row t holds the emission of label POSITION i in
+// column i and the blank's in column `blank` (= S_max): the class of an odd state is its position, the skip rule still
+// compares the labels themselves.
+template <int NS, bool EM_LDS, bool BETA, bool COMPACT = false>
 __device__ __forceinline__ void ctc_lattice(const float* __restrict__ lp, const float* s_rows, const int32_t* s_tg, int lane, int Tb,
                                             int S, int C, int blank, float* __restrict__ out, float* __restrict__ nll_b) {
   constexpr int SP = 64 * NS;
@@ -89,9 +92,10 @@ __device__ __forceinline__ void ctc_lattice(const float* __restrict__ lp, const 
     int c = blank;
     bool sk = false;
     if (s < SS && (s & 1)) {
-      c = s_tg[s >> 1];
-      if (!BETA) sk = s >= 3 ? (s_tg[(s >> 1) - 1] != c) : false;          // from s-2 into s
-      else sk = (s + 2 < SS) ? (s_tg[(s >> 1) + 1] != c) : false;          // from s into s+2
+      const int lab = s_tg[s >> 1];
+      c = COMPACT ? (s >> 1) : lab;
+      if (!BETA) sk = s >= 3 ? (s_tg[(s >> 1) - 1] != lab) : false;        // from s-2 into s
+      else sk = (s + 2 < SS) ? (s_tg[(s >> 1) + 1] != lab) : false;        // from s into s+2
     }
     cls4[i] = c * 4;
     skip_ok[i] = sk;
@@ -205,7 +209,7 @@ __device__ __forceinline__ void ctc_lattice(const float* __restrict__ lp, const 
 static constexpr int kCtcMaxS = 512;
 // b: utterance; NT: threads of the workgroup that take part (128 in the stand-alone kernel, 256 inside the fused
 // mel + CTC grid: the upper waves help with the LDS fill, then leave); s_tg: kCtcMaxS ints, s_lp: (T + 2) * C floats.
-template <int NS, bool EM_LDS, int NT>
+template <int NS, bool EM_LDS, int NT, bool COMPACT = false>
 __device__ __forceinline__ void ctc_alpha_beta_body(const float* __restrict__ logp, const int64_t* __restrict__ targets,
                                                     const int32_t* __restrict__ in_lens, const int32_t* __restrict__ tgt_lens,
                                                     int64_t T, int64_t C, int64_t S_max, int blank, float* __restrict__ alpha,
@@ -255,9 +259,9 @@ __device__ __forceinline__ void ctc_alpha_beta_body(const float* __restrict__ lo
   if (wv >= 2) return;                                                        // helper waves of a wider workgroup
   const bool is_beta = wv != 0;
   if (is_beta)
-    ctc_lattice<NS, EM_LDS, true>(lp, s_lp + C, s_tg, lane, Tb, S, (int)C, blank, beta + (int64_t)b * T * SP, nullptr);
+    ctc_lattice<NS, EM_LDS, true, COMPACT>(lp, s_lp + C, s_tg, lane, Tb, S, (int)C, blank, beta + (int64_t)b * T * SP, nullptr);
   else
-    ctc_lattice<NS, EM_LDS, false>(lp, s_lp + C, s_tg, lane, Tb, S, (int)C, blank, alpha + (int64_t)b * T * SP, nll + b);
+    ctc_lattice<NS, EM_LDS, false, COMPACT>(lp, s_lp + C, s_tg, lane, Tb, S, (int)C, blank, alpha + (int64_t)b * T * SP, nll + b);
 }
 
 

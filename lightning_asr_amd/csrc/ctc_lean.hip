@@ -1,0 +1,280 @@
+// Large-vocabulary loss head (BASELINE cfg5: AISHELL, C = 4334, T' up to 801): log-softmax and CTC WITHOUT the (B, T', C)
+// f32 log-prob / gradient tensors (444 MB each at bs = 32; models/QuartNet.py:275-290, train.py:76-78).
+//
+//   decoder GEMM epilogue (gemm_bf16.hip)   bf16 logits [N][ldc] + per (row, column tile) partial (max, sum exp, argmax)
+//   lse_gather_kernel                       lse[row], argmax[row]; E[row][i] = logit[row][target_i] - lse[row] (i < S),
+//                                           E[row][S_max] = logit[row][blank] - lse[row]  - the only emissions the lattice reads
+//   ctc_alpha_beta_kernel<.., COMPACT>      the same lattice recursion over E (class of an odd state = its label POSITION)
+//   ctc_grad_lean_kernel                    bf16 d(loss)/d(logits) = gs * (exp(logit - lse) - occupancy) straight from the bf16
+//                                           logits (no cast pass), and the decoder-bias gradient's column sums on the way
+// HBM traffic per step at cfg5: 222 MB logits written once and read once, 222 MB gradient written once (+ what the two
+// decoder gradient GEMMs read), against 444 + 888 + 888 + 666 + 444 MB for logits / log_softmax / CTC gradient / cast / colsum.
+// The statistics are taken from the logits AS STORED (bf16), so exp(logit - lse) sums to one over the stored row.
+#include "ctc_lattice.h"
+
+namespace lasr {
+
+// one wave per row.  stat [N][gn][2] = (max, sum exp(x - max)) per column tile, arg [N][gn] = first argmax inside the tile
+__global__ __launch_bounds__(256) void lse_gather_kernel(const bf16_t* __restrict__ logits, int64_t ldc, const float* __restrict__ stat,
+                                                         const int32_t* __restrict__ arg, int gn, const int64_t* __restrict__ targets,
+                                                         const int32_t* __restrict__ tgt_lens, int64_t N, int64_t T, int64_t S_max,
+                                                         int CE, int blank, float* __restrict__ lse, int32_t* __restrict__ argmax,
+                                                         float* __restrict__ E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float m = kNegInf, s = 0.f;
+  int mi = 0x7fffffff;
+  for (int j = lane; j < gn; j += 64) {          // gn <= 64 for C <= 8192 with 128-wide tiles: one trip
+    const float mj = stat[(row * gn + j) * 2], sj = stat[(row * gn + j) * 2 + 1];
+    const int ij = arg[row * gn + j];
+    if (mj > m) { s = s * __expf(m - mj) + sj; m = mj; mi = ij; }
+    else { s += sj * __expf(mj - m); if (mj == m && ij < mi) mi = ij; }
+  }
+  const float M = wave_max(m);
+  float part = (m == kNegInf) ? 0.f : s * __expf(m - M);
+  part = wave_sum(part);
+  int cand = (m == M) ? mi : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+  const float l = M + __logf(part);
+  if (lane == 0) {
+    lse[row] = l;
+    if (argmax) argmax[row] = cand;
+  }
+  const int64_t b = row / T;
+  const int S = tgt_lens[b];
+  const bf16_t* x = logits + row * ldc;
+  float* e = E + row * CE;
+  const int64_t* tg = targets + b * S_max;
+  for (int i = lane; i < CE; i += 64) {
+    float v = 0.f;
+    if (i < S) v = bf16_to_f32(x[tg[i]]) - l;
+    else if (i == (int)S_max) v = bf16_to_f32(x[blank]) - l;
+    e[i] = v;
+  }
+}
+
+// RW rows per workgroup (RW/4 per wave).  grad [N][ldc] bf16 (pad columns written as zeros); bias_partials [grid][C] f32.
+template <int NS>
+__global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __restrict__ logits, int64_t ldc, const float* __restrict__ lse,
+                                                            const float* __restrict__ E, int CE, const int64_t* __restrict__ targets,
+                                                            const int32_t* __restrict__ in_lens, const int32_t* __restrict__ tgt_lens,
+                                                            int64_t B, int64_t T, int64_t C, int64_t S_max, int blank,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                            const int32_t* __restrict__ next_same, const float* __restrict__ nll,
+                                                            const float* __restrict__ gscale, bf16_t* __restrict__ grad,
+                                                            float* __restrict__ bias_partials, int rows_per_wg) {
+  constexpr int SP = 64 * NS;
+  constexpr int kMaxVec = 18;                         // 64 lanes x 8 columns x 18 = 9216 columns
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int cpad = (int)((C + 7) & ~(int64_t)7);      // LDS row: C rounded up to whole 8-column vectors
+  float* s_row = smem + (size_t)wid * (cpad + S_max);
+  float* s_v = s_row + cpad;
+  const int nvec = (int)(ldc >> 3);                   // 16-byte vectors per row (ldc % 8 == 0)
+  float acc[kMaxVec][8];
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+  const int rpw = rows_per_wg >> 2;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg + (int64_t)wid * rpw;
+  for (int k = 0; k < rpw; ++k) {
+    const int64_t row = r_begin + k;
+    if (row >= B * T) break;                          // wave-uniform
+    const int64_t b = row / T, t = row - b * T;
+    const int Tb = in_lens[b];
+    bf16_t* g = grad + row * ldc;
+    if (t >= Tb) {                                    // frames past the utterance: zero gradient
+#pragma unroll
+      for (int j = 0; j < kMaxVec; ++j) {
+        const int v = lane + 64 * j;
+        if (v < nvec) *reinterpret_cast<uint4*>(g + (size_t)v * 8) = make_uint4(0u, 0u, 0u, 0u);
+      }
+      continue;
+    }
+    const int S = tgt_lens[b];
+    const int SS = 2 * S + 1;
+    const float gs = gscale ? gscale[b] : 1.0f / (float)B;
+    const float nl = nll[b];
+    const bool infeasible = isinf(nl);
+    const float l = lse[row];
+    const bf16_t* x = logits + row * ldc;
+    // softmax of the stored row -> LDS
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        float xv[8];
+        Vec<bf16_t>::load(x + (size_t)v * 8, xv);
+        float4 lo, hi;
+        lo.x = __expf(xv[0] - l); lo.y = __expf(xv[1] - l); lo.z = __expf(xv[2] - l); lo.w = __expf(xv[3] - l);
+        hi.x = __expf(xv[4] - l); hi.y = __expf(xv[5] - l); hi.z = __expf(xv[6] - l); hi.w = __expf(xv[7] - l);
+        *reinterpret_cast<float4*>(s_row + (size_t)v * 8) = lo;
+        *reinterpret_cast<float4*>(s_row + (size_t)v * 8 + 4) = hi;
+      }
+    }
+    // occupancy of every lattice state (emissions of the states come from the compact matrix)
+    const float* al = alpha + (b * T + t) * SP;
+    const float* be = beta + (b * T + t) * SP;
+    const float* er = E + row * CE;
+    const int64_t* tg = targets + b * S_max;
+    float blank_occ = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int s = lane * NS + i;
+      if (s < SS) {
+        const float lp = (s & 1) ? er[s >> 1] : er[S_max];
+        const float v = expf(al[s] + be[s] + nl - lp);
+        if (s & 1) s_v[s >> 1] = v;
+        else blank_occ += v;
+      }
+    }
+    blank_occ = wave_sum(blank_occ);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes have landed (single-wave hand-off)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) s_row[blank] -= blank_occ;
+    const int32_t* nx = next_same + b * S_max * 2;
+    for (int i = lane; i < S; i += 64) {
+      if (nx[S_max + i]) {   // first occurrence of its label: sum the chain in target order (deterministic)
+        float a = 0.f;
+        for (int j = i; j >= 0; j = nx[j]) a += s_v[j];
+        s_row[tg[i]] -= a;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+      const int v = lane + 64 * j;
+      if (v < nvec) {
+        const float4 lo = *reinterpret_cast<const float4*>(s_row + (size_t)v * 8);
+        const float4 hi = *reinterpret_cast<const float4*>(s_row + (size_t)v * 8 + 4);
+        float o[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool real = v * 8 + e < C;               // pad columns of the last vector hold exp(0 - lse): not a class
+          o[e] = real ? (infeasible ? __builtin_nanf("") : gs * o[e]) : 0.f;
+          acc[j][e] += o[e];
+        }
+        Vec<bf16_t>::store(g + (size_t)v * 8, o);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row buffer is rewritten by the next row
+    __builtin_amdgcn_wave_barrier();
+  }
+  // column sums of the f32 gradient (decoder.bias): wave partial -> own LDS row -> fixed-order sum over the 4 waves
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kMaxVec; ++j) {
+    const int v = lane + 64 * j;
+    if (v < nvec) {
+      *reinterpret_cast<float4*>(s_row + (size_t)v * 8) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+      *reinterpret_cast<float4*>(s_row + (size_t)v * 8 + 4) = make_float4(acc[j][4], acc[j][5], acc[j][6], acc[j][7]);
+    }
+  }
+  __syncthreads();
+  const size_t pitch = (size_t)cpad + S_max;
+  for (int c = threadIdx.x; c < C; c += 256)
+    bias_partials[(size_t)blockIdx.x * C + c] = (smem[c] + smem[pitch + c]) + (smem[2 * pitch + c] + smem[3 * pitch + c]);
+}
+
+static inline int lean_ns(int64_t S_max) {
+  const int64_t ss = 2 * S_max + 1;
+  if (ss <= 64 * 4) return 4;
+  if (ss <= 64 * 8) return 8;
+  if (ss <= 64 * 16) return 16;
+  return 0;
+}
+static constexpr int kLeanRowsPerWg = 64;
+
+template <int NS, bool EM_LDS>
+__global__ __launch_bounds__(128) void ctc_alpha_beta_compact_kernel(const float* __restrict__ E, const int64_t* __restrict__ targets,
+                                                                     const int32_t* __restrict__ in_lens,
+                                                                     const int32_t* __restrict__ tgt_lens, int64_t T, int64_t CE,
+                                                                     int64_t S_max, int blank_col, float* __restrict__ alpha,
+                                                                     float* __restrict__ beta, int32_t* __restrict__ next_same,
+                                                                     float* __restrict__ nll) {
+  __shared__ int32_t s_tg[kCtcMaxS];
+  extern __shared__ __attribute__((aligned(16))) float s_lp[];
+  ctc_alpha_beta_body<NS, EM_LDS, 128, true>(E, targets, in_lens, tgt_lens, T, CE, S_max, blank_col, alpha, beta, next_same, nll, blockIdx.x,
+                                             s_tg, s_lp);
+}
+
+}  // namespace lasr
+
+using namespace lasr;
+
+extern "C" size_t lasr_ctc_lean_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t S_max) {
+  const int64_t sm = S_max > 0 ? S_max : 1;
+  const int64_t CE = (sm + 1 + 3) & ~(int64_t)3;
+  return align_up(lasr_ctc_workspace_bytes(B, T, S_max), 256) + align_up((size_t)B * T * sizeof(float), 256) +
+         align_up((size_t)B * T * CE * sizeof(float), 256) + align_up((size_t)cdiv(B * T, kLeanRowsPerWg) * C * sizeof(float), 256);
+}
+
+// logits [B*T][ldc] bf16 with row_stat / row_arg from lasr_gemm_rowstat (n_col_tiles column tiles).  Outputs: nll (B),
+// argmax (B*T, may be NULL), grad [B*T][ldc] bf16 = gscale_b * d nll_b / d logits (1/B when gscale is NULL), bias_grad (C) f32.
+extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* row_stat, const int32_t* row_arg, int n_col_tiles,
+                                  const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T, int64_t C,
+                                  int64_t S_max, int blank, float* nll, int32_t* argmax, void* grad, float* bias_grad,
+                                  const float* gscale, void* workspace, size_t workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(logits && row_stat && row_arg && targets && in_lens && tgt_lens && nll && grad && bias_grad && workspace,
+                 "lasr_ctc_loss_lean: null pointer");
+  LASR_CHECK_SHAPE(B > 0 && T > 0 && C > 1 && S_max >= 0 && blank >= 0 && blank < C && ldc == ((C + 7) & ~(int64_t)7) && ldc <= 9216 &&
+                       n_col_tiles >= 1 && n_col_tiles <= 64 && B * T * ldc < ((int64_t)1 << 31),
+                   "lasr_ctc_loss_lean: shape (C=%lld ldc=%lld tiles=%d)", (long long)C, (long long)ldc, n_col_tiles);
+  const int ns = lean_ns(S_max);
+  LASR_CHECK_SHAPE(ns != 0, "lasr_ctc_loss_lean: S_max=%lld exceeds the 511-label lattice the kernels are built for", (long long)S_max);
+  if (workspace_bytes < lasr_ctc_lean_workspace_bytes(B, T, C, S_max)) return fail(LASR_E_WORKSPACE, "lasr_ctc_loss_lean: workspace");
+  const int64_t sm = S_max > 0 ? S_max : 1, N = B * T;
+  const int CE = (int)((sm + 1 + 3) & ~(int64_t)3);
+  char* w = reinterpret_cast<char*>(workspace);
+  void* lattice_ws = w;
+  w += align_up(lasr_ctc_workspace_bytes(B, T, S_max), 256);
+  float* lse = reinterpret_cast<float*>(w);
+  w += align_up((size_t)N * sizeof(float), 256);
+  float* E = reinterpret_cast<float*>(w);
+  w += align_up((size_t)N * CE * sizeof(float), 256);
+  float* bias_partials = reinterpret_cast<float*>(w);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(lse_gather_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(logits), ldc, row_stat,
+                     row_arg, n_col_tiles, targets, tgt_lens, N, T, sm, CE, blank, lse, argmax, E);
+  LASR_LAUNCH_CHECK("lse_gather_kernel");
+  const size_t ab = (size_t)B * T * 64 * ns;
+  float* alpha = reinterpret_cast<float*>(lattice_ws);
+  float* beta = alpha + ab;
+  int32_t* next_same = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lattice_ws) + align_up(2 * ab * sizeof(float), 256));
+  const size_t em_bytes = (size_t)(T + 2) * CE * sizeof(float);
+  const bool em_lds = em_bytes <= 144 * 1024 && !getenv("LASR_CTC_NO_LDS");
+#define LASR_CTC_AB(NS_)                                                                                                       \
+  do {                                                                                                                         \
+    if (em_lds) {                                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_alpha_beta_compact_kernel<NS_, true>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                                       \
+      hipLaunchKernelGGL((ctc_alpha_beta_compact_kernel<NS_, true>), dim3((unsigned)B), dim3(128), em_bytes, st, E, targets, in_lens, \
+                         tgt_lens, T, (int64_t)CE, sm, (int)sm, alpha, beta, next_same, nll);                                  \
+    } else {                                                                                                                   \
+      hipLaunchKernelGGL((ctc_alpha_beta_compact_kernel<NS_, false>), dim3((unsigned)B), dim3(128), 0, st, E, targets, in_lens, \
+                         tgt_lens, T, (int64_t)CE, sm, (int)sm, alpha, beta, next_same, nll);                                  \
+    }                                                                                                                          \
+  } while (0)
+  if (ns == 4) LASR_CTC_AB(4); else if (ns == 8) LASR_CTC_AB(8); else LASR_CTC_AB(16);
+#undef LASR_CTC_AB
+  LASR_LAUNCH_CHECK("ctc_alpha_beta_compact_kernel");
+  const int cpad = (int)((C + 7) & ~(int64_t)7);
+  const size_t shmem = 4 * (size_t)(cpad + sm) * sizeof(float);
+  LASR_CHECK_SHAPE(shmem <= 160 * 1024, "lasr_ctc_loss_lean: C=%lld too large for the LDS row buffers", (long long)C);
+  const int nwg = (int)cdiv(N, kLeanRowsPerWg);
+#define LASR_CTC_G(NS_)                                                                                                        \
+  do {                                                                                                                         \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_grad_lean_kernel<NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL(ctc_grad_lean_kernel<NS_>, dim3((unsigned)nwg), dim3(256), shmem, st, reinterpret_cast<const bf16_t*>(logits), ldc, lse, \
+                       E, CE, targets, in_lens, tgt_lens, B, T, C, sm, blank, alpha, beta, next_same, nll, gscale,                \
+                       reinterpret_cast<bf16_t*>(grad), bias_partials, kLeanRowsPerWg);                                       \
+  } while (0)
+  if (ns == 4) LASR_CTC_G(4); else if (ns == 8) LASR_CTC_G(8); else LASR_CTC_G(16);
+#undef LASR_CTC_G
+  LASR_LAUNCH_CHECK("ctc_grad_lean_kernel");
+  return launch_reduce_partials(bias_partials, nwg, C, bias_grad, C, nullptr, st);   // f64, fixed order
+}

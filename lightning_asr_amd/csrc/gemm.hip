@@ -338,6 +338,27 @@ extern "C" int lasr_gemm(const void* A, const void* B, void* C, int dtype_ab, in
                    workspace, workspace_bytes, stream, nullptr);
 }
 
+// C [M][ldc] bf16 = A [M][K] . B [N][K]^T + bias, with per (row, 256-column tile) softmax statistics of the stored values
+// (the decoder of a large-vocabulary model feeding lasr_ctc_loss_lean).  row_stat [M][tiles][2] f32, row_arg [M][tiles] i32
+// with tiles = ceil(N / 256) (returned through n_col_tiles).
+extern "C" int lasr_gemm_rowstat(const void* A, const void* B, const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                 float* row_stat, int32_t* row_arg, int* n_col_tiles, void* stream) {
+  LASR_CHECK_ARG(A && B && C && row_stat && row_arg, "lasr_gemm_rowstat: null pointer");
+  LASR_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && ldc >= N && ldc % 8 == 0, "lasr_gemm_rowstat: M=%lld N=%lld K=%lld ldc=%lld",
+                   (long long)M, (long long)N, (long long)K, (long long)ldc);
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = ldc;
+  g.bias = bias; g.addend = nullptr; g.row_lens = nullptr; g.rows_per_seq = 0; g.stat_partials = nullptr; g.split_ws = nullptr;
+  g.k_per_split = K;
+  g.vecA = reinterpret_cast<uintptr_t>(A) % 16 == 0; g.vecB = reinterpret_cast<uintptr_t>(B) % 16 == 0;
+  hipStream_t st = as_stream(stream);
+  const int tok = prof_begin(LASR_PROF_GEMM, st, 2.0 * (double)M * N * K, (double)(M * K + N * K) * 2 + (double)M * N * 2);
+  const int rc = launch_gemm_bf16_rowstat(g, row_stat, row_arg, n_col_tiles, st);
+  prof_end(tok, st);
+  return rc;
+}
+extern "C" size_t lasr_gemm_rowstat_bytes(int64_t M, int64_t N) { return (size_t)M * cdiv(N, 256) * (2 * sizeof(float) + sizeof(int32_t)); }
+
 // ---- two independent problems in one launch (bf16 operands); anything else runs them one by one ----
 extern "C" size_t lasr_gemm_batch_workspace_bytes(const lasr_gemm_problem* probs, int n_probs, int split_k) {
   size_t b = 0;

@@ -38,6 +38,9 @@ struct Bf16Args {
   int vecA, vecB, vecC;
   // folded eval form (DUAL instantiation only): A = [A | A2] along K, rows of the first part masked by row_lens, act in the epilogue
   const bf16_t* A2; int lda2, K1, act;
+  // large-vocabulary decoder (256-row tile form, bf16 C): per (row, column tile) softmax statistics of the STORED values -
+  // row_stat [M][gn][2] = (max, sum exp(x - max)), row_arg [M][gn] = first argmax column - so log_softmax never reads the logits
+  float* row_stat; int32_t* row_arg;
 };
 // Up to two independent problems of the same kind in ONE launch (a unit's main + residual 1x1 conv, or
 // their two weight gradients): twice the workgroups per launch keeps two per CU resident for the
@@ -699,6 +702,7 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   const int nst = n0 + lc * 8;
   const bool full_n = g.vecC && nst + 7 < g.N;
   const bool want_stats = g.stat_partials != nullptr;      // workgroup-uniform
+  const bool want_rowstat = g.row_stat != nullptr;         // workgroup-uniform
   float cs[8], cq[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cs[i] = 0.f; cq[i] = 0.f; }
@@ -707,6 +711,35 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     const int lr = wid * 32 + it * RPI + lrow;   // (orders that put a block's waves on adjacent rows at the same time measured 1.8x slower)
     const int m = m0 + lr;
     const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + lc * 16);
+    if (want_rowstat) {
+      // this row's 8 stored values per lane -> (max, first argmax, sum exp(x - max)) over the tile's valid columns: the LPR lanes
+      // of a row are contiguous, so xor-shuffles below LPR stay inside the row
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[2 * i] = __uint_as_float(w[i] << 16); x[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+      float mx = -INFINITY;
+      int mi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (nst + i < g.N && x[i] > mx) { mx = x[i]; mi = nst + i; }
+#pragma unroll
+      for (int d = 1; d < LPR; d <<= 1) {
+        const float om = __shfl_xor(mx, d, 64);
+        const int oi = __shfl_xor(mi, d, 64);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (nst + i < g.N) se += __expf(x[i] - mx);
+#pragma unroll
+      for (int d = 1; d < LPR; d <<= 1) se += __shfl_xor(se, d, 64);
+      if (lc == 0 && m < g.M) {
+        const size_t o = (size_t)m * g.gn + tn;
+        g.row_stat[2 * o] = mx; g.row_stat[2 * o + 1] = se; g.row_arg[o] = mi;
+      }
+    }
     if (want_stats) {                            // rows past M / past the utterance hold zeros
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -803,6 +836,7 @@ static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
   a.vecA = g.vecA; a.vecB = g.vecB;
   a.vecC = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0);
   a.A2 = nullptr; a.lda2 = 0; a.K1 = 0; a.act = 0;
+  a.row_stat = nullptr; a.row_arg = nullptr;
   return 0;
 }
 
@@ -879,6 +913,23 @@ int launch_gemm_bf16_dual(const GemmArgs& g, const void* A2, int64_t lda2, int64
   b.total = b.tiles0;
   hipLaunchKernelGGL(gemm_bf16_dual_kernel, dim3((unsigned)b.total), dim3(big::NT), 0, st, b);
   LASR_LAUNCH_CHECK("gemm_bf16_dual_kernel");
+  return 0;
+}
+
+// One problem C = A B^T (+bias) with bf16 output and the softmax row statistics, on the 256 x 256 tile (the decoder of a
+// large-vocabulary model: M = B*T' rows, N = classes, K = 1024).  Returns the number of column tiles through n_col_tiles.
+int launch_gemm_bf16_rowstat(const GemmArgs& g, float* row_stat, int32_t* row_arg, int* n_col_tiles, hipStream_t st) {
+  if (!g.vecA || !g.vecB || g.ldc % 8 || reinterpret_cast<uintptr_t>(g.C) % 16 || !row_stat || !row_arg)
+    return fail(LASR_E_SHAPE, "lasr_gemm_rowstat: operands must be 16-byte aligned with pitches that are multiples of 8");
+  Bf16Batch b;
+  LASR_TRY(fill_args(b.p[0], g, big::BTM, 256, 1));
+  b.p[0].row_stat = row_stat; b.p[0].row_arg = row_arg;
+  b.p[1] = b.p[0];
+  b.tiles0 = b.p[0].gn * b.p[0].gm;
+  b.total = b.tiles0;
+  if (n_col_tiles) *n_col_tiles = b.p[0].gn;
+  hipLaunchKernelGGL((gemm_bf16_big_kernel<false, false, false>), dim3((unsigned)b.total), dim3(big::NT), 0, st, b);
+  LASR_LAUNCH_CHECK("gemm_bf16_big_kernel(rowstat)");
   return 0;
 }
 

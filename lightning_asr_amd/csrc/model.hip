@@ -30,6 +30,14 @@ extern "C" size_t lasr_bilstm_bwd_workspace_bytes(int64_t B);
 extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f, const float* whh_r,
                                const int32_t* lens, int64_t B, int64_t T, const float* saved, float* dg_f, float* dg_r, float* dwhh_f,
                                float* dwhh_r, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" int lasr_gemm_rowstat(const void* A, const void* B, const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                 float* row_stat, int32_t* row_arg, int* n_col_tiles, void* stream);
+extern "C" size_t lasr_gemm_rowstat_bytes(int64_t M, int64_t N);
+extern "C" size_t lasr_ctc_lean_workspace_bytes(int64_t B, int64_t T, int64_t C, int64_t S_max);
+extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* row_stat, const int32_t* row_arg, int n_col_tiles,
+                                  const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T, int64_t C,
+                                  int64_t S_max, int blank, float* nll, int32_t* argmax, void* grad, float* bias_grad, const float* gscale,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int lasr_copy_cols(const void* src, int src_dtype, int64_t ld_src, int64_t scol0, void* dst, int dst_dtype, int64_t ld_dst,
                               int64_t dcol0, int64_t rows, int64_t ncols, int accumulate, void* stream);
 
@@ -78,6 +86,7 @@ struct Plan {
   size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0;
   size_t o_cat = 0, o_gx[2] = {0, 0}, o_lstm_saved = 0, o_dg[2] = {0, 0};   // context: [N][336] | [N][160] f32 x2 | saved | [N][160] f32 x2
   size_t scratch_bytes = 0, ctc_bytes = 0;
+  size_t o_rowstat = 0, o_lean = 0, lean_bytes = 0;   // large-vocabulary head: softmax row statistics, lasr_ctc_loss_lean workspace
 };
 
 }  // namespace lasr
@@ -93,6 +102,8 @@ struct lasr_model {
   LstmRef lstm;
   Plan plan;
   bool planned = false;
+  bool lean_active = false;   // the last loss ran the large-vocabulary head: d(logits) is the bf16 [N][ldc] tensor at o_d1, db is done
+  int lean_tiles = 0;
   int bwd_cur = 0;       // ping-pong index of the gradient buffers between partial backward calls
   int bwd_next = -1;     // next unit a lasr_model_backward_continue call would process (-1: nothing pending)
   // one-shot feature prefetch consumed by the next loss_backward call (lasr_model_set_prefetch)
@@ -182,6 +193,14 @@ static int build_model(lasr_model* m) {
   m->b_dec = m->add_tensor("decoder.bias", {c.n_class}, 0);
   return 0;
 }
+
+// The large-vocabulary head (bf16 logits + row statistics instead of f32 logits / log-probs / gradients) pays when the class
+// axis dwarfs the label axis: C >= 256 (AISHELL: 4334).  LASR_NO_LEAN_HEAD=1 keeps the dense head for A/B runs.
+static bool lean_capable(const lasr_model* m) {
+  static const bool off = getenv("LASR_NO_LEAN_HEAD") != nullptr;
+  return !off && m->cfg.dtype == LASR_BF16 && m->cfg.n_class >= 256 && m->cfg.n_class <= 9216;
+}
+static int64_t lean_ldc(const lasr_model* m) { return ((int64_t)m->cfg.n_class + 7) / 8 * 8; }
 
 static int64_t out_frames(int64_t T_in) { return (T_in + 2 * 16 - 33) / 2 + 1; }
 
@@ -275,6 +294,11 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
   p.o_sums2 = take(cur, 2 * cmax * sizeof(float));
   p.ctc_bytes = lasr_ctc_workspace_bytes(B, p.T, S_max);
   p.o_ctc = take(cur, p.ctc_bytes);
+  if (lean_capable(m)) {
+    p.o_rowstat = take(cur, lasr_gemm_rowstat_bytes(N, C));
+    p.lean_bytes = lasr_ctc_lean_workspace_bytes(B, p.T, C, S_max);
+    p.o_lean = take(cur, p.lean_bytes);
+  }
   if (m->cfg.dtype == LASR_BF16) p.o_wbf16 = take(cur, (size_t)m->n_param * sizeof(bf16_t));
   p.total = cur;
   m->planned = true;
@@ -356,6 +380,13 @@ extern "C" int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, 
   if (n == "logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_logits; }
   if (n == "grad_logits") { shape[0] = B; shape[1] = p.T; shape[2] = m->cfg.n_class; return (int64_t)p.o_glogits; }
   if (n == "lens") { shape[0] = B; shape[1] = 1; shape[2] = 1; return (int64_t)p.o_lens; }
+  // large-vocabulary head: bf16 logits / gradient with rows padded to 8 classes, and the per-row log-sum-exp
+  if (n == "logits_bf16" && lean_capable(m)) { shape[0] = B; shape[1] = p.T; shape[2] = lean_ldc(m); return (int64_t)p.o_logits; }
+  if (n == "grad_logits_bf16" && lean_capable(m)) { shape[0] = B; shape[1] = p.T; shape[2] = lean_ldc(m); return (int64_t)p.o_d1; }
+  if (n == "lse" && lean_capable(m)) {
+    shape[0] = B; shape[1] = p.T; shape[2] = 1;
+    return (int64_t)(p.o_lean + align_up(lasr_ctc_workspace_bytes(B, p.T, p.S_max), 256));
+  }
   return -1;
 }
 
@@ -375,10 +406,21 @@ static bool eval_fold(int dtype) {
 }
 static bool fold_unit(const Unit& u) { return u.has_res && u.has_dw && !u.has_se && !u.ctx_before && u.ci % 64 == 0 && u.co % 8 == 0; }
 
+static int forward_impl(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
+                        int64_t B, int64_t T_in, int training, float* logp_out, int32_t* argmax_out, void* ws,
+                        size_t ws_bytes, void* stream, bool lean);
+
 extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
                                   int64_t B, int64_t T_in, int training, float* logp_out, int32_t* argmax_out, void* ws,
                                   size_t ws_bytes, void* stream) {
-  LASR_CHECK_ARG(m && params && buffers && feats && pct && logp_out && ws, "lasr_model_forward: null pointer");
+  LASR_CHECK_ARG(logp_out, "lasr_model_forward: null pointer");
+  return forward_impl(m, params, buffers, feats, pct, B, T_in, training, logp_out, argmax_out, ws, ws_bytes, stream, false);
+}
+
+static int forward_impl(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
+                        int64_t B, int64_t T_in, int training, float* logp_out, int32_t* argmax_out, void* ws,
+                        size_t ws_bytes, void* stream, bool lean) {
+  LASR_CHECK_ARG(m && params && buffers && feats && pct && (logp_out || lean) && ws, "lasr_model_forward: null pointer");
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && T_in >= 33, "lasr_model_forward: B=%lld T_in=%lld", (long long)B, (long long)T_in);
   make_plan(m, B, T_in, m->planned ? m->plan.S_max : 1);
   const Plan& p = m->plan;
@@ -482,6 +524,12 @@ extern "C" int lasr_model_forward(lasr_model_t* m, const float* params, float* b
   const int64_t C = m->cfg.n_class;
   // a narrow vocabulary leaves N/128 = 1 tile column: split K so that the 32 MB of activations are streamed by
   // 4 x 126 workgroups instead of 126 (the split partials are C/1024 of the input: negligible)
+  if (lean) {   // bf16 logits + per-tile softmax statistics; lse / emissions / gradient follow in lasr_ctc_loss_lean
+    float* rs = atf(ws, p.o_rowstat);
+    int32_t* ra = reinterpret_cast<int32_t*>(rs + (size_t)N * cdiv(C, 256) * 2);
+    return lasr_gemm_rowstat(x, wptr(m, params, ws, m->w_dec), params + m->b_dec, at(ws, p.o_logits), lean_ldc(m), N, C, 1024, rs, ra,
+                             &m->lean_tiles, stream);
+  }
   const int dec_split = (dt == LASR_BF16 && C <= 128) ? dec_split_k() : 1;
   LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->w_dec), atf(ws, p.o_logits), dt, LASR_F32, N, C, 1024, 0, 0, params + m->b_dec,
                      nullptr, nullptr, 0, nullptr, dec_split, scratch, p.scratch_bytes, stream));
@@ -523,14 +571,17 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   // decoder (models/QuartNet.py:275): dW = gl^T h, db = colsum(gl), dh = gl W
   const void* gl_ab = gl;
   int64_t ld_gl = C;
-  if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient, rows padded to 16-byte multiples
+  if (m->lean_active) {   // lasr_ctc_loss_lean wrote the bf16 gradient (rows padded to 8) and the bias gradient
+    ld_gl = lean_ldc(m);
+    gl_ab = at(ws, p.o_d1);
+  } else if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient, rows padded to 16-byte multiples
     ld_gl = (C + 7) / 8 * 8;
     LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
     gl_ab = at(ws, p.o_d1);
   }
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr, 16,
                         scratch, sb, stream));
-  LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
+  if (!m->lean_active) LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, wptr(m, params, ws, m->w_dec), 1024, at(ws, p.o_g[cur]), 1024, dt, dt, N, 1024, C, 0, 1, nullptr,
                         1, scratch, sb, stream));
   }
@@ -665,34 +716,57 @@ extern "C" int lasr_model_backward(lasr_model_t* m, const float* params, const v
   LASR_CHECK_ARG(m->planned && m->plan.B == B && m->plan.T_in == T_in, "lasr_model_backward: no matching forward in this workspace");
   if (ws_bytes < m->plan.total) return fail(LASR_E_WORKSPACE, "lasr_model_backward: workspace");
   const int64_t N = B * m->plan.T;
+  m->lean_active = false;
   LASR_TRY(lasr_log_softmax_bwd(logp, grad_logp, atf(ws, m->plan.o_glogits), N, m->cfg.n_class, stream));
   return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream);
+}
+
+// forward + mean CTC + d(loss)/d(logits): the dense head (f32 logits, log_softmax, lasr_ctc_loss[_mel]) or, for a large
+// vocabulary in bf16 when the caller does not ask for the log-probs (logp_out == NULL), the lean head of ctc_lean.hip
+static int forward_and_loss(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
+                            const int64_t* targets, const int32_t* tgt_lens, int64_t B, int64_t T_in, int64_t S_max, float* logp_out,
+                            float* loss_out, float* nll_out, int32_t* argmax_out, float* grads, void* ws, size_t ws_bytes, void* stream,
+                            const char* who) {
+  LASR_CHECK_ARG(m && targets && tgt_lens && loss_out && nll_out && grads, "%s: null pointer", who);
+  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
+  const Plan& p = m->plan;
+  if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, p.total);
+  const bool lean = logp_out == nullptr;
+  LASR_CHECK_ARG(!lean || lean_capable(m), "%s: logp_out may be NULL only for the large-vocabulary bf16 head (C >= 256)", who);
+  m->lean_active = lean;
+  LASR_TRY(forward_impl(m, params, buffers, feats, pct, B, T_in, 1, logp_out, argmax_out, ws, ws_bytes, stream, lean));
+  const int C = m->cfg.n_class;
+  const int32_t* lens = reinterpret_cast<const int32_t*>(at(ws, p.o_lens));
+  // mean_b CTC(blank = C-1) with lengths int(T'*pct) (train.py:76-78); its gradient w.r.t. the
+  // log-probs is (softmax - occupancy)/B, which log_softmax backward maps to itself.
+  const lasr_model::Prefetch pf = m->prefetch;
+  m->prefetch.armed = false;
+  if (lean) {
+    const int64_t N = B * p.T;
+    const float* rs = atf(ws, p.o_rowstat);
+    const int32_t* ra = reinterpret_cast<const int32_t*>(rs + (size_t)N * cdiv(C, 256) * 2);
+    LASR_TRY(lasr_ctc_loss_lean(at(ws, p.o_logits), lean_ldc(m), rs, ra, m->lean_tiles, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1,
+                                nll_out, argmax_out, at(ws, p.o_d1), grads + m->b_dec, nullptr, at(ws, p.o_lean), p.lean_bytes, stream));
+    if (pf.armed)   // (the lattice of a large vocabulary does not share a grid with the feature transform)
+      LASR_TRY(lasr_mel_fwd(pf.wave, pf.sample_lens, pf.dither, pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out,
+                            pf.pct_out, pf.ws, pf.ws_bytes, stream));
+  } else if (pf.armed) {   // this step's loss and the next step's features in one grid
+    LASR_TRY(lasr_ctc_loss_mel(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
+                               at(ws, p.o_ctc), p.ctc_bytes, pf.wave, pf.sample_lens, pf.dither, pf.aug, pf.B, pf.L, pf.normalize, nullptr,
+                               pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws, pf.ws_bytes, stream));
+  } else {
+    LASR_TRY(lasr_ctc_loss(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
+                           at(ws, p.o_ctc), p.ctc_bytes, stream));
+  }
+  return lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream);
 }
 
 extern "C" int lasr_model_loss_backward(lasr_model_t* m, const float* params, float* buffers, const void* feats, const float* pct,
                                         const int64_t* targets, const int32_t* tgt_lens, int64_t B, int64_t T_in, int64_t S_max,
                                         float* logp_out, float* loss_out, float* nll_out, int32_t* argmax_out, float* grads,
                                         void* ws, size_t ws_bytes, void* stream) {
-  LASR_CHECK_ARG(m && targets && tgt_lens && logp_out && loss_out && nll_out && grads, "lasr_model_loss_backward: null pointer");
-  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
-  const Plan& p = m->plan;
-  if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "lasr_model_loss_backward: workspace %zu < %zu", ws_bytes, p.total);
-  LASR_TRY(lasr_model_forward(m, params, buffers, feats, pct, B, T_in, 1, logp_out, argmax_out, ws, ws_bytes, stream));
-  const int C = m->cfg.n_class;
-  // mean_b CTC(blank = C-1) with lengths int(T'*pct) (train.py:76-78); its gradient w.r.t. the
-  // log-probs is (softmax - occupancy)/B, which log_softmax backward maps to itself.
-  if (m->prefetch.armed) {   // this step's loss and the next step's features in one grid
-    const lasr_model::Prefetch pf = m->prefetch;
-    m->prefetch.armed = false;
-    LASR_TRY(lasr_ctc_loss_mel(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
-                               nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, pf.wave, pf.sample_lens, pf.dither,
-                               pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws,
-                               pf.ws_bytes, stream));
-  } else {
-    LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
-                           nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
-  }
-  LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
+  LASR_TRY(forward_and_loss(m, params, buffers, feats, pct, targets, tgt_lens, B, T_in, S_max, logp_out, loss_out, nll_out, argmax_out, grads,
+                            ws, ws_bytes, stream, "lasr_model_loss_backward"));
   return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream);
 }
 
@@ -709,25 +783,9 @@ extern "C" int lasr_model_loss_backward_partial(lasr_model_t* m, const float* pa
                                                 const int64_t* targets, const int32_t* tgt_lens, int64_t B, int64_t T_in, int64_t S_max,
                                                 float* logp_out, float* loss_out, float* nll_out, int32_t* argmax_out, float* grads,
                                                 void* ws, size_t ws_bytes, int64_t unit_stop, void* stream) {
-  LASR_CHECK_ARG(m && targets && tgt_lens && logp_out && loss_out && nll_out && grads, "lasr_model_loss_backward_partial: null pointer");
-  LASR_CHECK_ARG(unit_stop >= 0 && unit_stop < (int64_t)m->units.size(), "lasr_model_loss_backward_partial: unit_stop");
-  make_plan(m, B, T_in, S_max < 1 ? 1 : S_max);
-  const Plan& p = m->plan;
-  if (ws_bytes < p.total) return fail(LASR_E_WORKSPACE, "lasr_model_loss_backward_partial: workspace %zu < %zu", ws_bytes, p.total);
-  LASR_TRY(lasr_model_forward(m, params, buffers, feats, pct, B, T_in, 1, logp_out, argmax_out, ws, ws_bytes, stream));
-  const int C = m->cfg.n_class;
-  if (m->prefetch.armed) {   // this step's loss and the next step's features in one grid
-    const lasr_model::Prefetch pf = m->prefetch;
-    m->prefetch.armed = false;
-    LASR_TRY(lasr_ctc_loss_mel(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
-                               nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, pf.wave, pf.sample_lens, pf.dither,
-                               pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws,
-                               pf.ws_bytes, stream));
-  } else {
-    LASR_TRY(lasr_ctc_loss(logp_out, targets, reinterpret_cast<const int32_t*>(at(ws, p.o_lens)), tgt_lens, B, p.T, C, p.S_max, C - 1,
-                           nll_out, atf(ws, p.o_glogits), nullptr, at(ws, p.o_ctc), p.ctc_bytes, stream));
-  }
-  LASR_TRY(lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream));
+  LASR_CHECK_ARG(m && unit_stop >= 0 && unit_stop < (int64_t)m->units.size(), "lasr_model_loss_backward_partial: unit_stop");
+  LASR_TRY(forward_and_loss(m, params, buffers, feats, pct, targets, tgt_lens, B, T_in, S_max, logp_out, loss_out, nll_out, argmax_out, grads,
+                            ws, ws_bytes, stream, "lasr_model_loss_backward_partial"));
   return backward_from_glogits(m, params, feats, B, T_in, grads, ws, stream, true, -1, (int)unit_stop);
 }
 

@@ -174,6 +174,16 @@ class NativeModel:
         return torch.tensor(offs, dtype=torch.int64, device=self.device)
 
     # ---- execution ------------------------------------------------------------------------------
+    @property
+    def lean_head(self) -> bool:
+        """large-vocabulary bf16 head available (bf16 logits + row statistics instead of f32 log-probs; csrc/ctc_lean.hip)"""
+        return self.act_dtype == torch.bfloat16 and 256 <= self.n_class <= 9216 and not os.environ.get("LASR_NO_LEAN_HEAD")
+
+    def _logp_buffer(self, B: int, T: int, want_logp: bool):
+        if not want_logp and self.lean_head:
+            return None                      # the library then runs the lean head: no (B, T', C) f32 tensor exists anywhere
+        return torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+
     def out_frames(self, T_in: int) -> int:
         return int(self._lib.lasr_model_out_frames(self._h, T_in))
 
@@ -195,7 +205,7 @@ class NativeModel:
         if off < 0:
             raise KeyError(name)
         shp = tuple(shape[i] for i in range(3))
-        if name in ("logits", "grad_logits"):
+        if name in ("logits", "grad_logits", "lse"):
             dt = torch.float32
         elif name == "lens":
             return self._ws[off:off + 4 * B].view(torch.int32)
@@ -274,14 +284,15 @@ class NativeModel:
             head, mid = [(bounds[3], bounds[4])], [(bounds[2], bounds[3])]
         return [(last, head), (first512, mid), (1, [(bounds[1], bounds[2])]), (0, [(bounds[0], bounds[1])])]
 
-    def loss_backward_staged(self, feats_btc, pct, targets, tgt_lens, on_bucket, want_argmax: bool = True, n_buckets: Optional[int] = None):
+    def loss_backward_staged(self, feats_btc, pct, targets, tgt_lens, on_bucket, want_argmax: bool = True, n_buckets: Optional[int] = None,
+                             want_logp: bool = True):
         """loss_backward in stages; ``on_bucket(ranges)`` (ranges = [(lo, hi), ...] of the flat gradient) is called right after
         the stage that finalises them has been enqueued (the data-parallel host starts that bucket's all-reduce there)."""
         B, T_in, _ = feats_btc.shape
         S = targets.shape[1]
         ws = self.workspace(B, T_in, S)
         T = self.out_frames(T_in)
-        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        logp = self._logp_buffer(B, T, want_logp)
         am = torch.empty(B, T, dtype=torch.int32, device=self.device) if want_argmax else None
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         nll = torch.empty(B, dtype=torch.float32, device=self.device)
@@ -299,7 +310,7 @@ class NativeModel:
         self._last_feats, self._last_logp = feats_btc, logp
         return loss, nll, logp, am
 
-    def loss_backward_units(self, feats_btc, pct, targets, tgt_lens, on_unit):
+    def loss_backward_units(self, feats_btc, pct, targets, tgt_lens, on_unit, want_logp: bool = True):
         """loss_backward one unit per stage, from the last unit to the first; ``on_unit(i, name)`` runs after the stage of unit i
         has been enqueued: its parameter gradients are final, tap("bwd.g_prev") is d(output of unit i) and tap("bwd.g_cur")
         d(input of unit i).  Test hook for the per-unit parity checks (same kernels, same order as loss_backward)."""
@@ -307,7 +318,7 @@ class NativeModel:
         S = targets.shape[1]
         ws = self.workspace(B, T_in, S)
         T = self.out_frames(T_in)
-        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        logp = self._logp_buffer(B, T, want_logp)
         am = torch.empty(B, T, dtype=torch.int32, device=self.device)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         nll = torch.empty(B, dtype=torch.float32, device=self.device)
@@ -325,13 +336,14 @@ class NativeModel:
         self._last_feats, self._last_logp = feats_btc, logp
         return loss, nll, logp, am
 
-    def loss_backward(self, feats_btc, pct, targets, tgt_lens, want_argmax: bool = True):
-        """forward + mean CTC + backward.  Returns (loss (1), nll (B), logp, argmax)."""
+    def loss_backward(self, feats_btc, pct, targets, tgt_lens, want_argmax: bool = True, want_logp: bool = True):
+        """forward + mean CTC + backward.  Returns (loss (1), nll (B), logp, argmax).  want_logp=False: logp is None when the
+        large-vocabulary head applies (bf16, C >= 256): no (B, T', C) f32 tensor is materialised."""
         B, T_in, _ = feats_btc.shape
         S = targets.shape[1]
         ws = self.workspace(B, T_in, S)
         T = self.out_frames(T_in)
-        logp = torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
+        logp = self._logp_buffer(B, T, want_logp)
         am = torch.empty(B, T, dtype=torch.int32, device=self.device) if want_argmax else None
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         nll = torch.empty(B, dtype=torch.float32, device=self.device)

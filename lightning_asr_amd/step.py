@@ -85,7 +85,7 @@ class TrainStep:
             self.lr_dev.fill_(self.lr)
         self.global_step += 1
 
-    def step_features(self, feats, pct, targets, tgt_lens):
+    def step_features(self, feats, pct, targets, tgt_lens, want_logp: bool = True):
         m = self.model
         if self.overlap and (self.world > 1 or self.force_staged):
             # bucketed SUM all-reduce, launched bucket by bucket in reverse layer order while the units below
@@ -93,19 +93,19 @@ class TrainStep:
             # kernels enqueued so far; the optimiser waits for all buckets.
             if self.comm is not None:       # library-owned communicator and side stream (lasr_comm_*)
                 loss, nll, logp, am = m.loss_backward_staged(feats, pct, targets, tgt_lens,
-                                                             lambda ranges: self.comm.all_reduce_ranges(m.grads, ranges))
+                                                             lambda ranges: self.comm.all_reduce_ranges(m.grads, ranges), want_logp=want_logp)
                 self.comm.wait()
             else:
                 works = []
                 loss, nll, logp, am = m.loss_backward_staged(
                     feats, pct, targets, tgt_lens,
                     lambda ranges: works.extend(torch.distributed.all_reduce(m.grads[lo:hi], group=self.pg, async_op=True)
-                                                for lo, hi in ranges))
+                                                for lo, hi in ranges), want_logp=want_logp)
                 for w in works:
                     w.wait()
             self._reduced = True
         else:
-            loss, nll, logp, am = m.loss_backward(feats, pct, targets, tgt_lens)
+            loss, nll, logp, am = m.loss_backward(feats, pct, targets, tgt_lens, want_logp=want_logp)
             self._reduced = False
         self.optimizer_step()
         return loss, nll, logp, am
@@ -115,7 +115,7 @@ class TrainStep:
         return tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None for t in (wave, sample_lens, dither, aug))
 
     def step(self, wave, targets, tgt_lens, sample_lens=None, dither=None, aug=None, prefetch_wave=None, prefetch_lens=None,
-             prefetch_dither=None, prefetch_aug=None):
+             prefetch_dither=None, prefetch_aug=None, want_logp: bool = True):
         """One training step on `wave`.  prefetch_wave: the NEXT step's waveforms (already in HBM): their log-mel features are
         computed during this step in the grid of the CTC lattice kernel (32 busy workgroups, 224 idle CUs for ~0.1 ms) and
         picked up by the next call if it passes the same tensors - the data-loader prefetch of the reference's workers;
@@ -129,6 +129,6 @@ class TrainStep:
         if prefetch_wave is not None:
             nf, npct = self.model.arm_prefetch(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug)
             nxt = (self._prefetch_key(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug), nf, npct)
-        out = self.step_features(feats, pct, targets, tgt_lens)
+        out = self.step_features(feats, pct, targets, tgt_lens, want_logp=want_logp)
         self._prefetched = nxt
         return out

@@ -77,6 +77,17 @@ class _GradStore(torch.autograd.Function):
         return rb(g)
 
 
+class _RoundFwd(torch.autograd.Function):
+    """value stored in bf16, gradient passed through unchanged (the roundings of ITS consumers are modelled where they happen)"""
+    @staticmethod
+    def forward(ctx, x):
+        return rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class _ActForcedMask(torch.autograd.Function):
     """ReLU whose derivative mask is given (the GPU's own `out > 0`): an element with |z| ~ 1e-7 may take either sign
     under two f32 evaluation orders, and ONE flipped element of 8.2 M is 3.5e-4 of the gradient's L2 norm and ~1e-2 of
@@ -101,6 +112,7 @@ class Bf16OracleModel(R.OracleModel):
                  state: Optional[Dict[str, torch.Tensor]] = None, in_c: int = 64, dtype=torch.float64, emulate: bool = True):
         super().__init__(variant, n_class, mask, act, state, in_c)
         self.dtype, self.emulate = dtype, emulate
+        self.lean_head = False        # large-vocabulary head of csrc/ctc_lean.hip: the logits themselves are a bf16 tensor
         self.forced_mask: Optional[torch.Tensor] = None      # consumed by the next activation (run_unit)
         for k, v in self.state.items():
             if v.is_floating_point():
@@ -225,6 +237,8 @@ class Bf16OracleModel(R.OracleModel):
         """decoder 1x1 + log_softmax: f32 logits from bf16 operands; backward casts d(logits) to bf16 for both
         decoder GEMMs while the bias gradient sums the f32 one"""
         logits = self.gs(F.conv1d(x, self.sh(self.state["decoder.weight"]))) + self.state["decoder.bias"].view(1, -1, 1)
+        if self.lean_head and self.emulate:
+            logits = _RoundFwd.apply(logits)      # stored bf16 (bias added in the GEMM epilogue before the rounding); softmax of the stored row
         if self.keep_taps:
             self.taps["logits"] = logits
         return F.log_softmax(logits.transpose(1, 2), dim=-1)

@@ -62,7 +62,8 @@ def _ragged_batch(B, L_max, L_min, V, seed, chars_per_s=2.8):
     return wave, lens.int(), tg.long(), tl.int()
 
 
-def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag, oracle_dtype=torch.float32, weights="random"):
+def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag, oracle_dtype=torch.float32, weights="random",
+                    lean=False):
     from lightning_asr_amd import ops
     from lightning_asr_amd.engine import NativeModel
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -82,8 +83,15 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     def on_unit(i, name):
         gp, gc = m.tap("bwd.g_prev"), m.tap("bwd.g_cur")
         units[name] = {"g_prev": gp.clone(), "g_cur": gc.clone()}
-    loss, nll, logp, am = m.loss_backward_units(feats, pct, tg.to(dev), tl.to(dev), on_unit)
+    loss, nll, logp, am = m.loss_backward_units(feats, pct, tg.to(dev), tl.to(dev), on_unit, want_logp=not lean)
     torch.cuda.synchronize()
+    if lean:        # large-vocabulary head: no f32 log-probs exist; rebuild them from the stored bf16 logits and the per-row lse
+        assert logp is None and m.lean_head
+        logp = m.tap("logits_bf16")[:, :, :n_class].float() - m.tap("lse").view(B, T, 1)
+        assert bool((m.tap("grad_logits_bf16")[:, :, n_class:] == 0).all())
+        glogits_gpu = m.tap("grad_logits_bf16")[:, :, :n_class].float().cpu()
+    else:
+        glogits_gpu = m.tap("grad_logits").cpu()
     assert torch.isfinite(loss).all() and torch.isfinite(m.grads).all()
     gpu_grads = {t.name: m.view(t, m.grads).detach().float().cpu() for t in m.param_infos()}
     pct_c = pct.cpu()
@@ -91,6 +99,7 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     assert m.tap("lens").cpu().tolist() == lens.tolist()
     o = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
                           emulate=(mode == "bf16"))
+    o.lean_head = lean
     report = {"config": tag, "mode": mode, "B": B, "T_in": int(feats.shape[1]), "T": T, "C": n_class, "units": {}}
     worst = {"act": 0.0, "grad_act": 0.0, "grad_param": 0.0}
 
@@ -140,14 +149,14 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
             for k, g in rc["grads"].items():
                 note("context_rnn", "grad_param", "d." + k.split("rnn.")[-1], rel_l2(gpu_grads[k], g.float()))
     # head: decoder + log_softmax + mean CTC from the stored last_cnn2 output
-    rh = E.run_head(o, _bct(m.tap("last_cnn2")), pct_c, tg, tl, glogits_in=m.tap("grad_logits").cpu())
+    rh = E.run_head(o, _bct(m.tap("last_cnn2")), pct_c, tg, tl, glogits_in=glogits_gpu)
     lp_err = (logp.cpu().double() - rh["logp"].double()).abs().max().item()
     report["head"] = {"logp_max_abs": lp_err, "nll_rel": ((nll.cpu().double() - rh["nll"].double()).abs() / rh["nll"].double().abs()).max().item(),
                       "loss_gpu": loss.item(), "loss_head_oracle": rh["loss"]}
     assert lp_err < tol["logp_abs"], (tag, "logp", lp_err)
     assert report["head"]["nll_rel"] < tol["nll"], (tag, "nll", report["head"]["nll_rel"])
     assert torch.equal(am.cpu().long(), rh["logp"].argmax(-1)) or (am.cpu().long() != rh["logp"].argmax(-1)).float().mean() < 1e-4
-    note("head", "grad_act", "glogits", rel_l2(m.tap("grad_logits").cpu(), rh["glogits"]))
+    note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(rh["glogits"].float()) if lean else rh["glogits"]))
     note("head", "grad_act", "dx", rel_l2(_bct(units["last_cnn2"]["g_prev"][:N * 1024].view(B, T, 1024)), rh["dx"]))
     for k, g in rh["grads"].items():
         note("head", "grad_param", "d." + k, rel_l2(gpu_grads[k], g.float()))
@@ -156,6 +165,7 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     o2 = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
                            emulate=(mode == "bf16"))
     o2.training = True
+    o2.lean_head = lean
     with torch.no_grad():
         lp2 = o2.forward(_bct(feats).unsqueeze(1), pct_c)
         loss2 = R.training_loss(lp2, tg, pct_c, tl, n_class - 1).item()
@@ -201,3 +211,75 @@ def test_units_cfg5_aishell_bf16_bs32_ragged_16s(dev):
     wave, lens, tg, tl = _ragged_batch(32, 256000, 232000, V, seed=555)
     rep = run_units_check(dev, "plain", V + 1, torch.bfloat16, wave, lens, tg, tl, "cfg5_aishell_bf16")
     assert rep["T"] == 801
+
+
+def test_units_cfg5_aishell_bf16_lean_head(dev):
+    """the same cfg5-shaped step through the large-vocabulary head (csrc/ctc_lean.hip): bf16 logits + softmax row statistics from
+    the decoder GEMM's epilogue, the lattice over the gathered emissions, bf16 d(logits) straight from the stored logits -
+    no (B, T', C) f32 tensor.  Same per-unit checks; the head's log-probs are rebuilt from the stored logits and lse."""
+    V = 4333
+    wave, lens, tg, tl = _ragged_batch(32, 256000, 232000, V, seed=555)
+    rep = run_units_check(dev, "plain", V + 1, torch.bfloat16, wave, lens, tg, tl, "cfg5_aishell_bf16_lean", lean=True)
+    assert rep["T"] == 801
+
+
+def test_lean_head_small_cases(dev):
+    """lasr_gemm_rowstat + lasr_ctc_loss_lean against torch on small ragged cases: repeated labels, an utterance shorter than the
+    batch, a class count that is not a multiple of 8 or of the 256-column tile, an infeasible utterance (inf / NaN like torch)."""
+    import torch.nn.functional as F
+    from lightning_asr_amd import _lib
+    from lightning_asr_amd.ops import _p, _stream
+    from lightning_asr_amd._lib import call
+    import ctypes as C
+    g = torch.Generator().manual_seed(11)
+    for (B, T, Cc, S, K) in [(3, 40, 300, 7, 64), (2, 33, 777, 12, 128), (4, 50, 4334, 9, 64)]:
+        x = E.rb(torch.randn(B * T, K, generator=g))
+        W = E.rb(torch.randn(Cc, K, generator=g) * 0.3)
+        bias = torch.randn(Cc, generator=g) * 0.1
+        tgt = torch.randint(0, Cc - 1, (B, S), generator=g)
+        tgt[0, 1] = tgt[0, 0]                                       # a repeat
+        il = torch.tensor([T, T - 7, T, 5][:B], dtype=torch.int32)  # the last of 4 is infeasible (5 frames for 9 labels)
+        tl = torch.tensor([S, S - 2, 1, S][:B], dtype=torch.int32)
+        ldc = (Cc + 7) // 8 * 8
+        N = B * T
+        logits = torch.empty(N, ldc, dtype=torch.bfloat16, device=dev)
+        nb = _lib.load().lasr_gemm_rowstat_bytes(N, Cc)
+        tiles = (Cc + 255) // 256
+        rs = torch.empty(N * tiles * 2, dtype=torch.float32, device=dev)
+        ra = torch.empty(N * tiles, dtype=torch.int32, device=dev)
+        assert nb == rs.numel() * 4 + ra.numel() * 4
+        nt = C.c_int(0)
+        xb, Wb = x.to(dev, torch.bfloat16), W.to(dev, torch.bfloat16)
+        call("lasr_gemm_rowstat", _p(xb), _p(Wb), _p(bias.to(dev)), _p(logits), ldc, N, Cc, K, _p(rs), _p(ra), C.byref(nt), _stream())
+        assert nt.value == tiles
+        ref_logits = E.rb((x.double() @ W.double().t() + bias.double()).float())
+        got = logits[:, :Cc].float().cpu()
+        assert ((got - ref_logits).abs() <= 2.0 ** -7 * ref_logits.abs() + 1e-6).all()
+        wsb = _lib.load().lasr_ctc_lean_workspace_bytes(B, T, Cc, S)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        nll = torch.empty(B, dtype=torch.float32, device=dev)
+        am = torch.empty(N, dtype=torch.int32, device=dev)
+        grad = torch.empty(N, ldc, dtype=torch.bfloat16, device=dev)
+        db = torch.empty(Cc, dtype=torch.float32, device=dev)
+        call("lasr_ctc_loss_lean", _p(logits), ldc, _p(rs), _p(ra), tiles, _p(tgt.to(dev)), _p(il.to(dev)), _p(tl.to(dev)), B, T, Cc, S,
+             Cc - 1, _p(nll), _p(am), _p(grad), _p(db), None, _p(ws), wsb, _stream())
+        # torch on the SAME stored logits
+        lg = got.double().view(B, T, Cc).requires_grad_(True)
+        lp = F.log_softmax(lg, -1)
+        ref_nll = F.ctc_loss(lp.transpose(0, 1), tgt, il, tl, blank=Cc - 1, reduction="none")
+        ok = torch.isfinite(ref_nll)
+        (ref_nll[ok].sum() / B).backward()
+        assert torch.equal(torch.isfinite(nll.cpu()), ok)
+        assert ((nll.cpu().double()[ok] - ref_nll[ok]).abs() / ref_nll[ok].abs()).max() < 1e-5
+        assert torch.equal(am.cpu().long().view(B, T), got.view(B, T, Cc).argmax(-1))
+        gg = grad[:, :Cc].float().cpu().view(B, T, Cc)
+        assert bool((grad[:, Cc:] == 0).all())
+        for b in range(B):
+            if ok[b]:
+                ref_g = E.rb(lg.grad[b].float())
+                assert rel_l2(gg[b], ref_g) < 2e-3, (B, T, Cc, b, rel_l2(gg[b], ref_g))
+                assert bool((gg[b, int(il[b]):] == 0).all())
+            else:
+                assert bool(torch.isnan(gg[b, :int(il[b])]).all())
+        if bool(ok.all()):
+            assert rel_l2(db.cpu(), lg.grad.sum((0, 1)).float()) < 2e-4
