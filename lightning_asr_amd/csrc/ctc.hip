@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     for (int i = 0; i < NS; ++i) {
       const int s = lane * NS + i;
       if (s < SS) {
-        const int c = (s & 1) ? (int)tg[s >> 1] : blank;
+        const int c = (s & 1) ? (int)min(max(tg[s >> 1], (int64_t)0), C - 1) : blank;
         const float v = expf(al[s] + be[s] + nl - lp[c]);
         if (s & 1) s_v[s >> 1] = v;
         else blank_occ += v;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
       if (nx[S_max + i]) {  // first occurrence of its label: sum the chain in target order
         float acc = 0.f;
         for (int j = i; j >= 0; j = nx[j]) acc += s_v[j];
-        s_row[tg[i]] -= acc;
+        s_row[min(max(tg[i], (int64_t)0), C - 1)] -= acc;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -221,7 +221,8 @@ __device__ __forceinline__ void ctc_alpha_beta_body(const float* __restrict__ lo
   const int S = tgt_lens[b];
   const int64_t* tg = targets + (int64_t)b * S_max;
   const float* lp = logp + (int64_t)b * T * C;
-  for (int i = threadIdx.x; i < S; i += NT) s_tg[i] = (int32_t)tg[i];
+  // (labels clamped into the emission row: invalid user data must not become an out-of-bounds device access)
+  for (int i = threadIdx.x; i < S; i += NT) s_tg[i] = (int32_t)min(max(tg[i], (int64_t)0), (int64_t)(COMPACT ? 0x7fffffff : C - 1));
   if (EM_LDS && Tb > 0) {
     // emission rows 0..Tb-1 behind one pad row; 4 x 16-byte loads in flight per thread
     const int n4 = (int)(((int64_t)Tb * C) >> 2);   // the host checked C % 4 == 0 and the 16-byte alignment of logp

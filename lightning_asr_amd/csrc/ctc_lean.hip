@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void lse_gather_kernel(const bf16_t* __restric
   const int64_t* tg = targets + b * S_max;
   for (int i = lane; i < CE; i += 64) {
     float v = 0.f;
-    if (i < S) v = bf16_to_f32(x[tg[i]]) - l;
+    if (i < S) v = bf16_to_f32(x[min(max(tg[i], (int64_t)0), (int64_t)blank)]) - l;   // (blank = C-1: the last class; bad labels stay in bounds)
     else if (i == (int)S_max) v = bf16_to_f32(x[blank]) - l;
     e[i] = v;
   }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __rest
       if (nx[S_max + i]) {   // first occurrence of its label: sum the chain in target order (deterministic)
         float a = 0.f;
         for (int j = i; j >= 0; j = nx[j]) a += s_v[j];
-        s_row[tg[i]] -= a;
+        s_row[min(max(tg[i], (int64_t)0), C - 1)] -= a;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -231,9 +231,15 @@ __device__ __forceinline__ void tab_vec(const float* row, int c, int C, float (&
   o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
 }
 
+// V consecutive f32 of a per-(utterance, channel) table (the SE scale / SE gradient) as 16-byte loads, issued together with the
+// activation loads (eight scalar loads per vector in the middle of the arithmetic made the SE variants of these kernels 2-3x
+// slower: 18.5 / 31.7 / 42.5 us against 8.5 / 14.1 / 15.4 for forward / statistics / apply)
+__device__ __forceinline__ void ld_tab(const float* p, float (&o)[8]) { lds_vec8(p, o); }
+__device__ __forceinline__ void ld_tab(const float* p, float (&o)[4]) { lds_vec8(p, o); }
+
 // out = act((a*y + b)*se + a2*y2 + b2);  s_tab = [a | b | a2 | b2][C].  Two items per thread in flight, no branch
 // around a load (HAS2 is a template parameter, the second item's index is clamped and only its store predicated).
-template <typename T, bool HAS2>
+template <typename T, bool HAS2, bool SE>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                          const T* __restrict__ y2, const float* __restrict__ coef2,
                                                          const float* __restrict__ se, T* __restrict__ out,
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     uint4 rv[2], rw[2];
     uint32_t off[2];
     int cc[2], rr[2];
+    float sev[2][V];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int it = min(it0 + 256 * u, n_items - 1);
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       off[u] = (uint32_t)rr[u] * (uint32_t)C + (uint32_t)cc[u];
       rv[u] = Vec<T>::raw(y + off[u]);
       if (HAS2) rw[u] = Vec<T>::raw(y2 + off[u]);
+      if (SE) ld_tab(se + (uint32_t)(rr[u] / Tt) * (uint32_t)C + (uint32_t)cc[u], sev[u]);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -268,11 +276,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       float v[V], w[V], a[V], b[V], o[V];
       Vec<T>::unpack(rv[u], v);
       tab_vec(s_tab, c, C, a); tab_vec(s_tab + C, c, C, b);
-      const float* sp = se ? se + (uint32_t)(rr[u] / Tt) * (uint32_t)C + (uint32_t)c : nullptr;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         o[j] = fmaf(v[j], a[j], b[j]);
-        if (sp) o[j] *= sp[j];
+        if (SE) o[j] *= sev[u][j];
       }
       if (HAS2) {
         Vec<T>::unpack(rw[u], w);
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 // no branch around a load; a thread's rows are taken two at a time with all six 16-byte loads issued before the
 // first is unpacked (four at a time, or the constants streamed from LDS, cost the second wave per SIMD:
 // measured 34 us against 11).  The kernel was a chain of eight exposed memory round trips per slab.
-template <typename T, bool HAS2>
+template <typename T, bool HAS2, bool SE>
 __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                               const float* __restrict__ coef, const float* __restrict__ saved,
                                                               const T* __restrict__ y2, const float* __restrict__ coef2,
@@ -323,12 +330,19 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restric
         for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
       for (int rb = r0 + g.rl; rb < r1; rb += RB * g.row_lanes) {
         uint4 rd[RB], ry[RB], rr[RB];
+        float sev[RB][V], sgv[RB][V];
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-          const uint32_t off = (uint32_t)min(rb + i * g.row_lanes, rows - 1) * (uint32_t)C + (uint32_t)c;
+          const uint32_t rowc = (uint32_t)min(rb + i * g.row_lanes, rows - 1);
+          const uint32_t off = rowc * (uint32_t)C + (uint32_t)c;
           rd[i] = Vec<T>::raw(dout + off);
           ry[i] = Vec<T>::raw(y + off);
           if (HAS2) rr[i] = Vec<T>::raw(y2 + off);
+          if (SE) {
+            const uint32_t so = (rowc / (uint32_t)Tt) * (uint32_t)C + (uint32_t)c;
+            ld_tab(se + so, sev[i]);
+            if (seg) ld_tab(seg + so, sgv[i]);
+          }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -338,15 +352,12 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restric
           if (HAS2) Vec<T>::unpack(rr[i], rvi);
           const int r = rb + i * g.row_lanes;
           const float live = r < r1 ? 1.f : 0.f;                  // rows past the slab contribute nothing
-          const int ub = min(r, rows - 1) / Tt;
-          const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-          const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
 #pragma unroll
           for (int j = 0; j < V; ++j) {
-            const float sej = sp ? sp[j] : 1.f;
+            const float sej = SE ? sev[i][j] : 1.f;
             const float z = fmaf(yvi[j], a1[j], b1[j]) * sej + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
             const float d = dvi[j] * act_grad(z, act) * live;
-            const float d1 = fmaf(d, sej, gp ? gp[j] * live : 0.f);
+            const float d1 = fmaf(d, sej, (SE && seg) ? sgv[i][j] * live : 0.f);
             acc[0][j] += d1;
             acc[1][j] = fmaf(d1, (yvi[j] - m1[j]) * q1[j], acc[1][j]);
             if (HAS2) {
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(256) void bn_bwd_table_partials_kernel(const float*
 
 // pass 2b: dy = G1*d1 + B1*y + C1 (rows past the utterance length zeroed), dy2 = G2*d + B2*y2 + C2.
 // Two items per thread in flight, HAS2 a template parameter: no branch around a load.
-template <typename T, bool HAS2>
+template <typename T, bool HAS2, bool SE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const T* __restrict__ y2, const float* __restrict__ tab,
                                                            const float* __restrict__ se, const float* __restrict__ seg,
@@ -457,6 +468,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     uint4 rd[2], ry[2], rr2[2];
     uint32_t off[2];
     int cc[2], rr[2];
+    float sev[2][V], sgv[2][V];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int it = min(it0 + 256 * u, n_items - 1);
@@ -466,6 +478,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       rd[u] = Vec<T>::raw(dout + off[u]);
       ry[u] = Vec<T>::raw(y + off[u]);
       if (HAS2) rr2[u] = Vec<T>::raw(y2 + off[u]);
+      if (SE) {
+        const uint32_t so = (uint32_t)(rr[u] / Tt) * (uint32_t)C + (uint32_t)cc[u];
+        ld_tab(se + so, sev[u]);
+        if (seg) ld_tab(seg + so, sgv[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -477,13 +494,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       if (HAS2) Vec<T>::unpack(rr2[u], rv);
       const int ub = r / Tt;
       const bool masked = row_lens && (r - ub * Tt) >= row_lens[ub];
-      const float* sp = se ? se + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
-      const float* gp = (se && seg) ? seg + (uint32_t)ub * (uint32_t)C + (uint32_t)c : nullptr;
       float a1[V], b1[V], G[V], Bc[V], Cc[V];
       tab_vec(s_tab, c, C, a1); tab_vec(s_tab + C, c, C, b1);
       float z[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (sp ? sp[j] : 1.f);
+      for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (SE ? sev[u][j] : 1.f);
       if (HAS2) {
         tab_vec(s_tab + 5 * C, c, C, a1); tab_vec(s_tab + 6 * C, c, C, b1);
 #pragma unroll
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       tab_vec(s_tab + 2 * C, c, C, G); tab_vec(s_tab + 3 * C, c, C, Bc); tab_vec(s_tab + 4 * C, c, C, Cc);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const float d1 = fmaf(d[j], sp ? sp[j] : 1.f, gp ? gp[j] : 0.f);
+        const float d1 = fmaf(d[j], SE ? sev[u][j] : 1.f, (SE && seg) ? sgv[u][j] : 0.f);
         o1[j] = masked ? 0.f : fmaf(G[j], d1, fmaf(Bc[j], yv[j], Cc[j]));
       }
       if (live) Vec<T>::store(dy + off[u], o1);
@@ -583,13 +598,17 @@ extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2,
   const int64_t rows = B * T_;
   const size_t shmem = (size_t)4 * C * sizeof(float);
   if (y2) {
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
                                              as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
-                                             (int)T_, (int)C, act));
+                                             (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act)); }
   } else {
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
                                              as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
-                                             (int)T_, (int)C, act));
+                                             (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act)); }
   }
   LASR_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
@@ -617,13 +636,17 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_stats: C too large for LDS staging");
   float* partials = reinterpret_cast<float*>(workspace);
   if (y2) {
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act));
+                                             partials, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act)); }
   } else {
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act));
+                                             partials, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act)); }
   }
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
   if (!sums) return 0;   // partials stay in the workspace for lasr_bn_act_bwd_apply(sums = NULL)
@@ -663,13 +686,17 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
   const size_t shmem = (size_t)10 * C * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_apply: C too large for the LDS coefficient table");
   if (y2) {
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
-                                             (T*)dy2, (int)rows, (int)T_, (int)C, act));
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); }
   } else {
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
-                                             (T*)dy2, (int)rows, (int)T_, (int)C, act));
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); }
   }
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;

@@ -87,12 +87,16 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// One workgroup per utterance.  pooled = a*sums/T + b ; hidden = relu(W1 pooled) ; scale = sigmoid(W2 hidden)
+// One workgroup per utterance.  pooled = a*sums/T + b ; hidden = relu(W1 pooled) ; scale = sigmoid(W2 hidden).
+// The two mat-vecs are latency-, not bandwidth-work (256 KB of weights per utterance out of L2): what matters is how many
+// loads are in flight.  W1 [H][C]: one wave per group of 4 hidden units, lanes along C (coalesced), the 4 x C/64 loads of a
+// group issued before the first reduction (one unit at a time = 16 dependent trips per wave: 36 us per launch);
+// W2 [C][H]: one thread per output channel reads its own row as H/4 16-byte loads, all in flight.
 __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ sums, const float* __restrict__ coef,
                                                          const float* __restrict__ W1, const float* __restrict__ W2, int C, int H,
                                                          float inv_T, float* __restrict__ pooled, float* __restrict__ hidden,
                                                          float* __restrict__ scale) {
-  extern __shared__ float sm[];  // pooled[C] | hidden[H]
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C] | hidden[H]
   float* s_p = sm;
   float* s_h = sm + C;
   const int b = blockIdx.x;
@@ -103,63 +107,130 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int h = wid; h < H; h += 4) {  // one wave per hidden unit: dot over C
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(W1[(int64_t)h * C + c], s_p[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float v = fmaxf(acc, 0.f);
-      s_h[h] = v;
-      hidden[(int64_t)b * H + h] = v;
+  for (int h0 = wid * 4; h0 < H; h0 += 16) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < C; c += 64) {
+      const float pv = s_p[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fmaf(W1[(int64_t)min(h0 + u, H - 1) * C + c], pv, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = fmaxf(wave_sum(acc[u]), 0.f);
+      if (lane == 0 && h0 + u < H) {
+        s_h[h0 + u] = v;
+        hidden[(int64_t)b * H + h0 + u] = v;
+      }
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
+    const float4* w = reinterpret_cast<const float4*>(W2 + (int64_t)c * H);   // H % 4 == 0 (H = C/8, C % 32 == 0 checked on the host)
     float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc = fmaf(W2[(int64_t)c * H + h], s_h[h], acc);
+    for (int h4 = 0; h4 < H / 4; h4 += 8) {
+      float4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = w[min(h4 + u, H / 4 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (h4 + u < H / 4) {
+          const float4 hv = *reinterpret_cast<const float4*>(s_h + 4 * (h4 + u));
+          acc = fmaf(wv[u].x, hv.x, acc); acc = fmaf(wv[u].y, hv.y, acc); acc = fmaf(wv[u].z, hv.z, acc); acc = fmaf(wv[u].w, hv.w, acc);
+        }
+      }
+    }
     scale[(int64_t)b * C + c] = 1.f / (1.f + expf(-acc));
   }
 }
 
 // One workgroup per utterance: back through sigmoid, W2, relu, W1, the mean over T.
-// Writes seg[b][c] = d(loss)/d(BN output z1[b,t,c]) through the pooled path (same for every t), and the
-// per-utterance weight-gradient contributions pW1[b][H][C], pW2[b][C][H] (summed over b afterwards).
+// Writes seg[b][c] = d(loss)/d(BN output z1[b,t,c]) through the pooled path (same for every t) and the two small per-utterance
+// vectors the batched weight-gradient kernel below needs: d2[b][c] = d(pre-sigmoid), dh[b][h] = d(pre-relu).
+//   dh[h] = relu'(.) sum_c W2[c][h] d2[c]: lanes along h (a row of W2 is one coalesced 4*H-byte read), each wave walks C/4 rows
+//   with 8 row loads in flight, the four waves' partial vectors meet in LDS;
+//   seg[c] = sum_h W1[h][c] dh[h] / T: one thread per c, rows of W1 read coalesced across c, 8 in flight.
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ scale,
-                                                         const float* __restrict__ hidden, const float* __restrict__ pooled,
-                                                         const float* __restrict__ W1, const float* __restrict__ W2, int C, int H,
-                                                         float inv_T, float* __restrict__ seg, float* __restrict__ pW1,
-                                                         float* __restrict__ pW2) {
-  extern __shared__ float sm[];  // dpre2[C] | dh[H] | hid[H]
+                                                         const float* __restrict__ hidden, const float* __restrict__ W1,
+                                                         const float* __restrict__ W2, int C, int H, float inv_T,
+                                                         float* __restrict__ seg, float* __restrict__ d2_out, float* __restrict__ dh_out) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // d2[C] | part[4][H] | dh[H]
   float* s_d2 = sm;
-  float* s_dh = sm + C;
-  float* s_hid = s_dh + H;
+  float* s_part = sm + C;
+  float* s_dh = s_part + 4 * H;
   const int b = blockIdx.x;
-  for (int h = threadIdx.x; h < H; h += 256) s_hid[h] = hidden[(int64_t)b * H + h];
   for (int c = threadIdx.x; c < C; c += 256) {
     const float s = scale[(int64_t)b * C + c];
-    s_d2[c] = ds[(int64_t)b * C + c] * s * (1.f - s);
+    const float v = ds[(int64_t)b * C + c] * s * (1.f - s);
+    s_d2[c] = v;
+    d2_out[(int64_t)b * C + c] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C * H; i += 256) {  // dW2[c][h] = dpre2[c] * hidden[h]
-    const int c = i / H, h = i - c * H;
-    pW2[(int64_t)b * C * H + i] = s_d2[c] * s_hid[h];
-  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int h = wid; h < H; h += 4) {  // dhidden[h] = relu'(.) * sum_c W2[c][h] dpre2[c]
+  {
+    const int rows = C / 4, c0 = wid * rows;       // this wave's rows of W2
     float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(W2[(int64_t)c * H + h], s_d2[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) s_dh[h] = s_hid[h] > 0.f ? acc : 0.f;
+    const int hl = min(lane, H - 1);
+    for (int r = 0; r < rows; r += 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = W2[(int64_t)(c0 + min(r + u, rows - 1)) * H + hl];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + u < rows) acc = fmaf(wv[u], s_d2[c0 + r + u], acc);
+    }
+    if (lane < H) s_part[wid * H + lane] = acc;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < H * C; i += 256) {  // dW1[h][c] = dhidden[h] * pooled[c]
-    const int h = i / C, c = i - h * C;
-    pW1[(int64_t)b * H * C + i] = s_dh[h] * pooled[(int64_t)b * C + c];
+  if (threadIdx.x < H) {
+    const int h = threadIdx.x;
+    const float a = (s_part[h] + s_part[H + h]) + (s_part[2 * H + h] + s_part[3 * H + h]);
+    const float v = hidden[(int64_t)b * H + h] > 0.f ? a : 0.f;
+    s_dh[h] = v;
+    dh_out[(int64_t)b * H + h] = v;
   }
+  __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc = fmaf(W1[(int64_t)h * C + c], s_dh[h], acc);
+    for (int h = 0; h < H; h += 8) {
+      float wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[u] = W1[(int64_t)min(h + u, H - 1) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (h + u < H) acc = fmaf(wv[u], s_dh[h + u], acc);
+    }
     seg[(int64_t)b * C + c] = acc * inv_T;
+  }
+}
+
+// dW2[c][h] = sum_b d2[b][c] * hidden[b][h],  dW1[h][c] = sum_b dh[b][h] * pooled[b][c]: two 32-term outer-product sums per
+// weight, for all utterances in ONE launch (was: per-utterance [C][H] slabs, 2 x 4 MB written and re-read by two reductions).
+// grid (ceil(C/64), 2): blockIdx.y = 0 -> dW2 tile [64 c][H], 1 -> dW1 tile [H][64 c].  The batch's four small matrices sit in LDS.
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ d2, const float* __restrict__ hidden,
+                                                       const float* __restrict__ dh, const float* __restrict__ pooled, int B, int C, int H,
+                                                       float* __restrict__ dW1, float* __restrict__ dW2) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // a[B][64] | v[B][H]
+  float* s_a = sm;
+  float* s_v = sm + (size_t)B * 64;
+  const int c0 = blockIdx.x * 64;
+  const bool w2 = blockIdx.y == 0;
+  const float* A = w2 ? d2 : pooled;      // [B][C], the 64-channel slice
+  const float* V = w2 ? hidden : dh;      // [B][H]
+  for (int i = threadIdx.x; i < B * 64; i += 256) {
+    const int bb = i >> 6, cc = i & 63;
+    s_a[i] = c0 + cc < C ? A[(int64_t)bb * C + c0 + cc] : 0.f;
+  }
+  for (int i = threadIdx.x; i < B * H; i += 256) s_v[i] = V[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * H; i += 256) {
+    // dW2 is [C][H]: consecutive threads along h;  dW1 is [H][C]: consecutive threads along c  (coalesced stores either way)
+    const int cc = w2 ? i / H : i & 63;
+    const int h = w2 ? i - cc * H : i >> 6;
+    if (c0 + cc >= C) continue;
+    float acc = 0.f;
+    for (int bb = 0; bb < B; ++bb) acc = fmaf(s_a[bb * 64 + cc], s_v[bb * H + h], acc);
+    if (w2) dW2[(int64_t)(c0 + cc) * H + h] = acc;
+    else dW1[(int64_t)h * C + c0 + cc] = acc;
   }
 }
 
@@ -180,7 +251,7 @@ extern "C" int lasr_seqsum(const void* x, int dtype, int64_t B, int64_t T_, int6
 extern "C" int lasr_se_fwd(const float* sums, const float* coef, const float* W1, const float* W2, int64_t B, int64_t T_, int64_t C,
                            float* pooled, float* hidden, float* scale, void* stream) {
   LASR_CHECK_ARG(sums && coef && W1 && W2 && pooled && hidden && scale, "lasr_se_fwd: null pointer");
-  LASR_CHECK_SHAPE(B > 0 && T_ > 0 && C >= 8 && C % 8 == 0 && C <= 8192, "lasr_se_fwd: C=%lld", (long long)C);
+  LASR_CHECK_SHAPE(B > 0 && T_ > 0 && C >= 32 && C % 32 == 0 && C <= 8192, "lasr_se_fwd: C=%lld", (long long)C);
   const int H = (int)(C / 8);
   hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + H) * sizeof(float), as_stream(stream), sums, coef, W1,
                      W2, (int)C, H, 1.0f / (float)T_, pooled, hidden, scale);
@@ -189,7 +260,8 @@ extern "C" int lasr_se_fwd(const float* sums, const float* coef, const float* W1
 }
 
 extern "C" size_t lasr_se_bwd_workspace_bytes(int64_t B, int64_t C) {
-  return align_up((size_t)B * C * sizeof(float), 256) + 2 * align_up((size_t)B * C * (C / 8) * sizeof(float), 256);
+  // ds [B][C] | d2 [B][C] | dh [B][C/8]
+  return 2 * align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)B * (C / 8) * sizeof(float), 256);
 }
 
 extern "C" int lasr_se_bwd(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
@@ -202,10 +274,12 @@ extern "C" int lasr_se_bwd(const void* dout, const void* y, const float* coef, c
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && T_ > 0 && C >= 8 && C % 8 == 0 && C <= 8192, "lasr_se_bwd: C=%lld", (long long)C);
   if (workspace_bytes < lasr_se_bwd_workspace_bytes(B, C)) return fail(LASR_E_WORKSPACE, "lasr_se_bwd: workspace");
   const int H = (int)(C / 8);
+  LASR_CHECK_SHAPE(C % 32 == 0 && H <= 64 && (size_t)B * (64 + H) * sizeof(float) <= 64 * 1024,
+                   "lasr_se_bwd: C=%lld B=%lld (the kernels are built for C <= 512 in multiples of 32)", (long long)C, (long long)B);
   char* w = reinterpret_cast<char*>(workspace);
   float* ds = reinterpret_cast<float*>(w);
-  float* pW1 = reinterpret_cast<float*>(w + align_up((size_t)B * C * sizeof(float), 256));
-  float* pW2 = reinterpret_cast<float*>(w + align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)B * C * H * sizeof(float), 256));
+  float* d2 = reinterpret_cast<float*>(w + align_up((size_t)B * C * sizeof(float), 256));
+  float* dh = reinterpret_cast<float*>(w + 2 * align_up((size_t)B * C * sizeof(float), 256));
   dim3 grid((unsigned)cdiv(C, 64), (unsigned)B);
   hipStream_t st = as_stream(stream);
   if (dtype == LASR_F32)
@@ -215,9 +289,11 @@ extern "C" int lasr_se_bwd(const void* dout, const void* y, const float* coef, c
     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, coef,
                        (const bf16_t*)y2, coef2, scale, T_, C, act, ds);
   LASR_LAUNCH_CHECK("se_bwd_reduce_kernel");
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + 2 * H) * sizeof(float), st, ds, scale, hidden, pooled, W1,
-                     W2, (int)C, H, 1.0f / (float)T_, seg, pW1, pW2);
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + 5 * H) * sizeof(float), st, ds, scale, hidden, W1, W2,
+                     (int)C, H, 1.0f / (float)T_, seg, d2, dh);
   LASR_LAUNCH_CHECK("se_mlp_bwd_kernel");
-  LASR_TRY(launch_reduce_partials(pW1, (int)B, (int64_t)H * C, dW1, (int64_t)H * C, nullptr, st));
-  return launch_reduce_partials(pW2, (int)B, (int64_t)C * H, dW2, (int64_t)C * H, nullptr, st);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((unsigned)cdiv(C, 64), 2), dim3(256), (size_t)B * (64 + H) * sizeof(float), st, d2, hidden, dh,
+                     pooled, (int)B, (int)C, H, dW1, dW2);
+  LASR_LAUNCH_CHECK("se_wgrad_kernel");
+  return 0;
 }

@@ -153,7 +153,14 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     lp_err = (logp.cpu().double() - rh["logp"].double()).abs().max().item()
     report["head"] = {"logp_max_abs": lp_err, "nll_rel": ((nll.cpu().double() - rh["nll"].double()).abs() / rh["nll"].double().abs()).max().item(),
                       "loss_gpu": loss.item(), "loss_head_oracle": rh["loss"]}
-    assert lp_err < tol["logp_abs"], (tag, "logp", lp_err)
+    if lean:
+        # the logits are a bf16 tensor here: where the GPU's f32 accumulation and the oracle land on different sides of a rounding
+        # boundary one logit (and its log-prob) moves by one bf16 ulp (2^-7 at |x| in [1, 2)); everything else agrees to f32 noise
+        lp_diff = (logp.cpu().double() - rh["logp"].double()).abs()
+        report["head"]["logp_flipped_frac"] = (lp_diff > tol["logp_abs"]).double().mean().item()
+        assert report["head"]["logp_flipped_frac"] < 2e-3 and lp_err < 0.04, (tag, "logp", lp_err, report["head"]["logp_flipped_frac"])
+    else:
+        assert lp_err < tol["logp_abs"], (tag, "logp", lp_err)
     assert report["head"]["nll_rel"] < tol["nll"], (tag, "nll", report["head"]["nll_rel"])
     assert torch.equal(am.cpu().long(), rh["logp"].argmax(-1)) or (am.cpu().long() != rh["logp"].argmax(-1)).float().mean() < 1e-4
     note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(rh["glogits"].float()) if lean else rh["glogits"]))
@@ -249,8 +256,11 @@ def test_lean_head_small_cases(dev):
         ra = torch.empty(N * tiles, dtype=torch.int32, device=dev)
         assert nb == rs.numel() * 4 + ra.numel() * 4
         nt = C.c_int(0)
-        xb, Wb = x.to(dev, torch.bfloat16), W.to(dev, torch.bfloat16)
-        call("lasr_gemm_rowstat", _p(xb), _p(Wb), _p(bias.to(dev)), _p(logits), ldc, N, Cc, K, _p(rs), _p(ra), C.byref(nt), _stream())
+        # (every device operand is held in a variable: a temporary passed as _p(t.to(dev)) is freed - and its block reused by the
+        #  next temporary - before the kernel runs)
+        xb, Wb, bias_d = x.to(dev, torch.bfloat16), W.to(dev, torch.bfloat16), bias.to(dev)
+        tgt_d, il_d, tl_d = tgt.to(dev), il.to(dev), tl.to(dev)
+        call("lasr_gemm_rowstat", _p(xb), _p(Wb), _p(bias_d), _p(logits), ldc, N, Cc, K, _p(rs), _p(ra), C.byref(nt), _stream())
         assert nt.value == tiles
         ref_logits = E.rb((x.double() @ W.double().t() + bias.double()).float())
         got = logits[:, :Cc].float().cpu()
@@ -261,8 +271,9 @@ def test_lean_head_small_cases(dev):
         am = torch.empty(N, dtype=torch.int32, device=dev)
         grad = torch.empty(N, ldc, dtype=torch.bfloat16, device=dev)
         db = torch.empty(Cc, dtype=torch.float32, device=dev)
-        call("lasr_ctc_loss_lean", _p(logits), ldc, _p(rs), _p(ra), tiles, _p(tgt.to(dev)), _p(il.to(dev)), _p(tl.to(dev)), B, T, Cc, S,
+        call("lasr_ctc_loss_lean", _p(logits), ldc, _p(rs), _p(ra), tiles, _p(tgt_d), _p(il_d), _p(tl_d), B, T, Cc, S,
              Cc - 1, _p(nll), _p(am), _p(grad), _p(db), None, _p(ws), wsb, _stream())
+        torch.cuda.synchronize()
         # torch on the SAME stored logits
         lg = got.double().view(B, T, Cc).requires_grad_(True)
         lp = F.log_softmax(lg, -1)
