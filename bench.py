@@ -184,6 +184,9 @@ def main():
                     help="activation dtype: bf16 (BASELINE config) or f32 (exact parity mode)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=os.environ.get("LASR_BENCH_GRAPH", "1") == "1",
+                    help="replay the step from a captured hipGraph (default for one GPU; LASR_BENCH_GRAPH=0 / --no-graph: eager launches)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--no-prefetch", dest="prefetch", action="store_false",
                     help="compute each step's features at the head of the step instead of inside the previous step's CTC launch")
     args = ap.parse_args()
@@ -214,7 +217,7 @@ def main():
     from lightning_asr_amd import _lib
     from lightning_asr_amd.engine import NativeModel
     from lightning_asr_amd.schedule import CosineAnnealingWarmupRestarts
-    from lightning_asr_amd.step import TrainStep
+    from lightning_asr_amd.step import GraphedTrainStep, TrainStep
 
     V = vocab_size(cfg["vocab"])
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
@@ -248,14 +251,33 @@ def main():
             batches.append((w, None, t_, l_, B * cfg["clip_s"], 0.0))
     step_no = [0]
     audio_s = [0.0]
+    use_graph = args.graph and world == 1           # (RCCL inside a captured graph is opt-in: LASR_GRAPH_DP=1)
+    graphs = {}
+    if use_graph:
+        # hipGraph replay: the ~200 launches of a step become one graph launch (host-enqueue time no longer bounds the step)
+        if cfg["ragged"]:                            # one graph per bucket shape, features + step of the same batch
+            for bk in batches:
+                key = (bk[0].shape[1], bk[2].shape[1])
+                if key not in graphs:
+                    graphs[key] = GraphedTrainStep(ts, B, key[0], key[1], ragged=True, prefetch=False)
+                    graphs[key].capture(bk[0], bk[1])
+        else:
+            g0 = GraphedTrainStep(ts, B, batches[0][0].shape[1], batches[0][2].shape[1], ragged=False, prefetch=args.prefetch)
+            g0.capture(batches[0][0])
+            graphs[None] = g0
 
-    def one_step():
-        w, sl, t_, l_, secs, _pad = batches[step_no[0] % len(batches)]
-        nxt = batches[(step_no[0] + 1) % len(batches)] if args.prefetch else None
+    def one_step(eager=False):
+        i = step_no[0]
+        w, sl, t_, l_, secs, _pad = batches[i % len(batches)]
+        nxt = batches[(i + 1) % len(batches)] if args.prefetch else None
         step_no[0] += 1
         audio_s[0] += secs
-        return ts.step(w, t_, l_, sample_lens=sl, prefetch_wave=None if nxt is None else nxt[0],
-                       prefetch_lens=None if nxt is None else nxt[1], want_logp=False)   # the training step reads loss + argmax only
+        if eager or not use_graph:
+            return ts.step(w, t_, l_, sample_lens=sl, prefetch_wave=None if nxt is None else nxt[0],
+                           prefetch_lens=None if nxt is None else nxt[1], want_logp=False)   # the training step reads loss + argmax only
+        if cfg["ragged"]:
+            return graphs[(w.shape[1], t_.shape[1])].step(w, t_, l_, lens=sl)
+        return graphs[None].step(nxt[0] if nxt is not None else w, t_, l_)
 
     for _ in range(args.warmup):
         loss, *_ = one_step()
@@ -286,7 +308,7 @@ def main():
     if rank == 0:
         lib.lasr_prof_enable(1)
     for _ in range(n_prof):
-        one_step()
+        one_step(eager=True)       # (the in-library event brackets live in the launch path: a graph replay does not pass through it)
     torch.cuda.synchronize()
     if rank == 0:
         lib.lasr_prof_enable(0)
@@ -339,7 +361,7 @@ def main():
                    "global_batch": B * world, "clip_seconds": cfg["clip_s"] if cfg["clip_s"] else "2-16 (ragged)",
                    "audio_seconds_per_step_per_gpu": timed_audio_s / args.steps,
                    "padding_frac": sum(b[5] for b in batches) / len(batches),
-                   "n_class": V + 1, "parallelism": "dp%d" % world, "feature_prefetch": bool(args.prefetch),
+                   "n_class": V + 1, "parallelism": "dp%d" % world, "feature_prefetch": bool(args.prefetch), "hip_graph": bool(use_graph),
                    "excluded": "H2D of the PCM (waves resident in HBM); the reference's per-step greedy decode + WER logging (train.py:80)"},
         "final_loss": final_loss,
         "roofline": roofline,

@@ -401,6 +401,17 @@ int lasr_model_loss_backward_partial(lasr_model_t* m, const float* params, float
 int lasr_model_backward_continue(lasr_model_t* m, const float* params, const void* feats, int64_t B, int64_t T_in,
                                  float* grads, void* workspace, size_t workspace_bytes, int64_t unit_stop, void* stream);
 
+/* ---- learning-rate schedule on the device -------------------------------------------------------------------------------
+ * CosineAnnealingWarmupRestarts (scheduler/cosine_annearing_with_warmup.py:53-89; stepped per batch, train.py:57-61) as one
+ * device-side state + a one-thread kernel: lasr_lr_schedule_init fills a HOST image of the state (the caller uploads it),
+ * lasr_lr_schedule_step advances it and writes the rate lasr_novograd_step reads.  No host scalar enters a training step,
+ * so the step can be captured into a hipGraph and replayed.                                                               */
+size_t lasr_lr_schedule_state_bytes(void);
+int lasr_lr_schedule_init(void* state_host_out, size_t bytes, int64_t first_cycle_steps, double cycle_mult, double max_lr,
+                          double min_lr, int64_t warmup_steps, double gamma, int64_t cycle, int64_t step_in_cycle,
+                          int64_t cur_cycle_steps, int64_t last_epoch);
+int lasr_lr_schedule_step(void* state_dev, float* lr_dev, void* stream);
+
 /* ---- large-vocabulary loss head (BASELINE cfg5: C = 4334): decoder 1x1 conv + log_softmax + CTC + their backward without the
  * (B, T', C) f32 log-prob / gradient tensors of models/QuartNet.py:275-290 and train.py:76-78 (444 MB each at bs = 32).
  * lasr_gemm_rowstat: C [M][ldc] bf16 = A [M][K] . B [N][K]^T + bias plus, per (row, 256-column tile), the softmax statistics

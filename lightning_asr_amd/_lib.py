@@ -98,6 +98,9 @@ SIGNATURES = {
     "lasr_model_unit_info": (_i32, [_p, _i64, C.c_char_p, _sz]),
     "lasr_model_loss_backward_partial": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _i64, _p]),
     "lasr_model_backward_continue": (_i32, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _i64, _p]),
+    "lasr_lr_schedule_state_bytes": (_sz, []),
+    "lasr_lr_schedule_init": (_i32, [_p, _sz, _i64, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _i64, _i64, _i64, _i64]),
+    "lasr_lr_schedule_step": (_i32, [_p, _p, _p]),
     "lasr_gemm_rowstat": (_i32, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p]),
     "lasr_gemm_rowstat_bytes": (_sz, [_i64, _i64]),
     "lasr_ctc_lean_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),

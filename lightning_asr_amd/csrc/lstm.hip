@@ -6,7 +6,7 @@
 // The input projection x W_ih^T is one MFMA GEMM per direction (lasr_gemm, f32 out); what is left is
 // a latency-bound recurrence of len_b dependent steps, run by one persistent workgroup per
 // (utterance, direction): thread j owns gate row j with its 40 recurrent weights in registers, the
-// hidden state lives in LDS, two barriers per step.  All LSTM arithmetic is f32.
+// hidden state lives in LDS.  All LSTM arithmetic is f32.
 #include "common.h"
 #include <math.h>
 
@@ -14,69 +14,89 @@ namespace lasr {
 
 static constexpr int H = 40, G = 4 * H;  // hidden size, gate rows
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Latency work: a time step is ~200 dependent instructions per wave, so the kernels are built around what sits ON that chain.
+//   * thread (u, q) = (tid >> 2, tid & 3) owns gate row q*H + u: the four gates of a hidden unit live in one quad and meet
+//     through DPP quad broadcasts (no LDS round trip, no barrier), every lane of the quad keeps the unit's cell state;
+//   * ONE barrier per forward step (the new h vector, double-buffered in LDS), two per backward step - LDS-only barriers
+//     (lds_barrier): __syncthreads() would drain the prefetched global loads and the step's stores at every step;
+//   * v_exp_f32 / v_rcp_f32 sigmoid and tanh (libm expf / tanhf: ~3x the instructions);
+//   * the per-step global operands (gx; the saved gates, cell states and d(out) in backward) come through a register ring
+//     fetched kPre steps ahead: s_waitcnt vmcnt counts loads AND the step's stores in issue order, so a one-step prefetch
+//     made every step wait for the previous step's stores to retire (forward 352 us, backward 525 us for T' = 501).
+static constexpr int kLstmThreads = 192;   // 160 gate rows + 32 lanes that only keep the barriers company
+static constexpr int kPre = 8;
+
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {   // lane Q of every quad -> the whole quad
+  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
+}
 
 // gx [B][T][G] f32 per direction (x W_ih^T, no bias); saved [B][T][2][G + 2H]: gates(i,f,g,o) | c | h
 // out: columns [col0 + dir*H, +H) of a [B][T][ldo] tensor in T (zeros for t >= len).
 template <typename T>
-__global__ __launch_bounds__(256) void bilstm_fwd_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
-                                                         const float* __restrict__ whh_f, const float* __restrict__ whh_r,
-                                                         const float* __restrict__ bih_f, const float* __restrict__ bhh_f,
-                                                         const float* __restrict__ bih_r, const float* __restrict__ bhh_r,
-                                                         const int32_t* __restrict__ lens, int64_t Tt, T* __restrict__ out,
-                                                         int64_t ldo, int64_t col0, float* __restrict__ saved) {
-  __shared__ __attribute__((aligned(16))) float s_h[H];
-  __shared__ float s_g[G];
-  const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+__global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
+                                                                  const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                  const float* __restrict__ bih_f, const float* __restrict__ bhh_f,
+                                                                  const float* __restrict__ bih_r, const float* __restrict__ bhh_r,
+                                                                  const int32_t* __restrict__ lens, int64_t Tt, T* __restrict__ out,
+                                                                  int64_t ldo, int64_t col0, float* __restrict__ saved) {
+  __shared__ __attribute__((aligned(16))) float s_h[2][H];
+  const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+  const bool live = tid < G;
+  const int u = live ? tid >> 2 : 0, q = tid & 3, j = q * H + u;
   const float* gx = (dir ? gx_r : gx_f) + (int64_t)b * Tt * G;
   const float* whh = dir ? whh_r : whh_f;
   int len = lens[b];
   if (len > Tt) len = (int)Tt;
   float w[H];
-  float bias = 0.f;
-  if (j < G) {
 #pragma unroll
-    for (int k = 0; k < H; ++k) w[k] = whh[j * H + k];
-    bias = (dir ? bih_r : bih_f)[j] + (dir ? bhh_r : bhh_f)[j];
-  }
-  if (j < H) s_h[j] = 0.f;
-  float c = 0.f;
+  for (int k = 0; k < H; ++k) w[k] = whh[j * H + k];
+  const float bias = (dir ? bih_r : bih_f)[j] + (dir ? bhh_r : bhh_f)[j];
+  if (tid < H) { s_h[0][tid] = 0.f; s_h[1][tid] = 0.f; }
   // zero the padded frames of this direction's output slice
-  for (int64_t i = (int64_t)len * H + j; i < Tt * H; i += 256) {
+  for (int64_t i = (int64_t)len * H + tid; i < Tt * H; i += kLstmThreads) {
     const int64_t t = i / H;
     const int k = (int)(i - t * H);
     Elem<T>::st(out + ((int64_t)b * Tt + t) * ldo + col0 + dir * H + k, 0.f);
   }
-  __syncthreads();
-  float gnext = (j < G && len > 0) ? gx[(int64_t)(dir ? len - 1 : 0) * G + j] : 0.f;
-  for (int s = 0; s < len; ++s) {
-    const int t = dir ? len - 1 - s : s;
-    const float gcur = gnext;
-    if (j < G && s + 1 < len) gnext = gx[(int64_t)(dir ? len - 2 - s : s + 1) * G + j];
-    if (j < G) {
-      float acc = gcur + bias;
+  float ring[kPre];
 #pragma unroll
-      for (int k4 = 0; k4 < H; k4 += 4) {
-        const float4 hv = *reinterpret_cast<const float4*>(s_h + k4);
-        acc = fmaf(w[k4], hv.x, acc); acc = fmaf(w[k4 + 1], hv.y, acc);
-        acc = fmaf(w[k4 + 2], hv.z, acc); acc = fmaf(w[k4 + 3], hv.w, acc);
+  for (int k = 0; k < kPre; ++k) ring[k] = k < len ? gx[(int64_t)(dir ? len - 1 - k : k) * G + j] : 0.f;
+  float c = 0.f;
+  __syncthreads();
+  for (int s0 = 0; s0 < len; s0 += kPre) {
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+      const int s = s0 + k;
+      if (s < len) {   // workgroup-uniform
+        const int t = dir ? len - 1 - s : s;
+        float a0 = ring[k] + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (s + kPre < len) ring[k] = gx[(int64_t)(dir ? len - 1 - (s + kPre) : s + kPre) * G + j];
+        const float* hp = s_h[s & 1];
+#pragma unroll
+        for (int k4 = 0; k4 < H; k4 += 4) {
+          const float4 hv = *reinterpret_cast<const float4*>(hp + k4);
+          a0 = fmaf(w[k4], hv.x, a0); a1 = fmaf(w[k4 + 1], hv.y, a1); a2 = fmaf(w[k4 + 2], hv.z, a2); a3 = fmaf(w[k4 + 3], hv.w, a3);
+        }
+        const float pre = (a0 + a1) + (a2 + a3);
+        const float a = q == 2 ? tanh_fast(pre) : sigmoid_fast(pre);
+        float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
+        if (live) sv[j] = a;
+        const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
+        c = fmaf(fg, c, ig * gg);
+        const float h = og * tanh_fast(c);
+        if (live && q == 0) {
+          s_h[(s + 1) & 1][u] = h;
+          sv[G + u] = c;
+          sv[G + H + u] = h;
+          Elem<T>::st(out + ((int64_t)b * Tt + t) * ldo + col0 + dir * H + u, h);
+        }
+        lds_barrier();
       }
-      const float a = (j >= 2 * H && j < 3 * H) ? tanhf(acc) : sigmoidf_(acc);
-      s_g[j] = a;
-      saved[(((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H) + j] = a;
     }
-    __syncthreads();
-    if (j < H) {
-      const float ig = s_g[j], fg = s_g[H + j], gg = s_g[2 * H + j], og = s_g[3 * H + j];
-      c = fmaf(fg, c, ig * gg);
-      const float h = og * tanhf(c);
-      s_h[j] = h;
-      float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
-      sv[G + j] = c;
-      sv[G + H + j] = h;
-      Elem<T>::st(out + ((int64_t)b * Tt + t) * ldo + col0 + dir * H + j, h);
-    }
-    __syncthreads();
   }
 }
 
@@ -84,74 +104,96 @@ __global__ __launch_bounds__(256) void bilstm_fwd_kernel(const float* __restrict
 // dg [B][T][G] f32 per direction = gradient w.r.t. the gate pre-activations (zero rows for t >= len);
 // pwhh [B][2][G][H] = this utterance's contribution to dW_hh.
 template <typename T>
-__global__ __launch_bounds__(256) void bilstm_bwd_kernel(const T* __restrict__ dout, int64_t ldd, int64_t col0,
-                                                         const float* __restrict__ whh_f, const float* __restrict__ whh_r,
-                                                         const int32_t* __restrict__ lens, int64_t Tt, const float* __restrict__ saved,
-                                                         float* __restrict__ dg_f, float* __restrict__ dg_r, float* __restrict__ pwhh) {
+__global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __restrict__ dout, int64_t ldd, int64_t col0,
+                                                                  const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                  const int32_t* __restrict__ lens, int64_t Tt, const float* __restrict__ saved,
+                                                                  float* __restrict__ dg_f, float* __restrict__ dg_r, float* __restrict__ pwhh) {
   __shared__ __attribute__((aligned(16))) float s_dg[G];
   __shared__ __attribute__((aligned(16))) float s_hprev[H];
   __shared__ float s_part[4][H];
-  const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+  const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+  const bool live = tid < G;
+  const int u = live ? tid >> 2 : 0, q = tid & 3, j = q * H + u;        // gate-gradient role
+  const int kk = live ? tid % H : 0, p = live ? tid / H : 0;            // dh_prev role: hidden index kk, rows 40p .. 40p+39
   const float* whh = dir ? whh_r : whh_f;
   float* dg = (dir ? dg_r : dg_f) + (int64_t)b * Tt * G;
   int len = lens[b];
   if (len > Tt) len = (int)Tt;
-  // thread (k = j % H, p = j / H) holds W_hh[40p .. 40p+39][k] for the dh_prev = W_hh^T dgates product
-  const int k = j % H, p = j / H;
-  float wt[H];
-  float dw[H];
-  if (j < G) {
+  float wt[H], dw[H];
 #pragma unroll
-    for (int q = 0; q < H; ++q) { wt[q] = whh[(p * H + q) * H + k]; dw[q] = 0.f; }
-  }
-  for (int64_t i = (int64_t)len * G + j; i < Tt * G; i += 256) dg[i] = 0.f;
-  float dh_next = 0.f, dc_next = 0.f;  // carried by threads j < H
-  for (int s = len - 1; s >= 0; --s) {
-    const int t = dir ? len - 1 - s : s;             // step s of the forward recurrence touched frame t
-    const int tp = dir ? t + 1 : t - 1;              // frame of the previous step (s-1), if s > 0
+  for (int qq = 0; qq < H; ++qq) { wt[qq] = whh[(p * H + qq) * H + kk]; dw[qq] = 0.f; }
+  for (int64_t i = (int64_t)len * G + tid; i < Tt * G; i += kLstmThreads) dg[i] = 0.f;
+  if (tid < H) { s_part[0][tid] = 0.f; s_part[1][tid] = 0.f; s_part[2][tid] = 0.f; s_part[3][tid] = 0.f; }
+  // per-step operands, kPre steps ahead: every lane its own gate; lane q of a quad one of (c, c_prev, h_prev, d(out)) of unit u
+  auto fetch = [&](int s, float& ga, float& gb) {
+    const int t = dir ? len - 1 - s : s;
+    const int tp = dir ? t + 1 : t - 1;
     const float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
-    if (j < H) {
-      const float ig = sv[j], fg = sv[H + j], gg = sv[2 * H + j], og = sv[3 * H + j], c = sv[G + j];
-      float cprev = 0.f, hprev = 0.f;
-      if (s > 0) {
-        const float* sp = saved + (((int64_t)b * Tt + tp) * 2 + dir) * (G + 2 * H);
-        cprev = sp[G + j];
-        hprev = sp[G + H + j];
-      }
-      s_hprev[j] = hprev;
-      const float dh = Elem<T>::ld(dout + ((int64_t)b * Tt + t) * ldd + col0 + dir * H + j) + dh_next;
-      const float tc = tanhf(c);
-      const float d_o = dh * tc * og * (1.f - og);
-      const float dc = fmaf(dh * og, 1.f - tc * tc, dc_next);
-      s_dg[j] = dc * gg * ig * (1.f - ig);
-      s_dg[H + j] = dc * cprev * fg * (1.f - fg);
-      s_dg[2 * H + j] = dc * ig * (1.f - gg * gg);
-      s_dg[3 * H + j] = d_o;
-      dc_next = dc * fg;
-    }
-    __syncthreads();
-    if (j < G) {
-      const float mine = s_dg[j];
-      dg[(int64_t)t * G + j] = mine;
-      float acc = 0.f;
+    const float* sp = saved + (((int64_t)b * Tt + (s > 0 ? tp : t)) * 2 + dir) * (G + 2 * H);
+    ga = sv[j];
+    float v;
+    if (q == 0) v = sv[G + u];
+    else if (q == 1) v = sp[G + u];
+    else if (q == 2) v = sp[G + H + u];
+    else v = Elem<T>::ld(dout + ((int64_t)b * Tt + t) * ldd + col0 + dir * H + u);
+    gb = (s == 0 && (q == 1 || q == 2)) ? 0.f : v;       // no previous step: c_prev = h_prev = 0
+  };
+  float ra[kPre], rb_[kPre];
 #pragma unroll
-      for (int q4 = 0; q4 < H; q4 += 4) {
-        const float4 hv = *reinterpret_cast<const float4*>(s_hprev + q4);
-        dw[q4] = fmaf(mine, hv.x, dw[q4]); dw[q4 + 1] = fmaf(mine, hv.y, dw[q4 + 1]);
-        dw[q4 + 2] = fmaf(mine, hv.z, dw[q4 + 2]); dw[q4 + 3] = fmaf(mine, hv.w, dw[q4 + 3]);
-        const float4 gv = *reinterpret_cast<const float4*>(s_dg + p * H + q4);
-        acc = fmaf(wt[q4], gv.x, acc); acc = fmaf(wt[q4 + 1], gv.y, acc);
-        acc = fmaf(wt[q4 + 2], gv.z, acc); acc = fmaf(wt[q4 + 3], gv.w, acc);
-      }
-      s_part[p][k] = acc;
-    }
-    __syncthreads();
-    if (j < H) dh_next = (s_part[0][j] + s_part[1][j]) + (s_part[2][j] + s_part[3][j]);
+  for (int k = 0; k < kPre; ++k) {
+    ra[k] = 0.f; rb_[k] = 0.f;
+    if (len - 1 - k >= 0) fetch(len - 1 - k, ra[k], rb_[k]);
   }
-  if (j < G) {
-    float* o = pwhh + (((int64_t)b * 2 + dir) * G + j) * H;
+  float dc_next = 0.f;
+  __syncthreads();
+  for (int s0 = len - 1; s0 >= 0; s0 -= kPre) {
 #pragma unroll
-    for (int q = 0; q < H; ++q) o[q] = dw[q];
+    for (int k = 0; k < kPre; ++k) {
+      const int s = s0 - k;
+      if (s >= 0) {   // workgroup-uniform
+        const int t = dir ? len - 1 - s : s;
+        const float a = ra[k], x = rb_[k];
+        if (s - kPre >= 0) fetch(s - kPre, ra[k], rb_[k]);
+        const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
+        const float c = quad_bcast<0>(x), cprev = quad_bcast<1>(x), hprev = quad_bcast<2>(x), dy = quad_bcast<3>(x);
+        const float dh = dy + (s_part[0][u] + s_part[1][u]) + (s_part[2][u] + s_part[3][u]);    // + dh from step s+1
+        const float tc = tanh_fast(c);
+        const float d_o = dh * tc * og * (1.f - og);
+        const float dc = fmaf(dh * og, 1.f - tc * tc, dc_next);
+        float mine;
+        if (q == 0) mine = dc * gg * ig * (1.f - ig);
+        else if (q == 1) mine = dc * cprev * fg * (1.f - fg);
+        else if (q == 2) mine = dc * ig * (1.f - gg * gg);
+        else mine = d_o;
+        dc_next = dc * fg;
+        if (live) {                            // (s_part is rewritten only after the second barrier below: no hazard with the reads above)
+          s_dg[j] = mine;
+          dg[(int64_t)t * G + j] = mine;
+          if (q == 0) s_hprev[u] = hprev;
+        }
+        lds_barrier();
+        if (live) {
+          const float my = s_dg[tid];          // row tid of dW_hh
+          float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+          for (int q4 = 0; q4 < H; q4 += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(s_hprev + q4);
+            dw[q4] = fmaf(my, hv.x, dw[q4]); dw[q4 + 1] = fmaf(my, hv.y, dw[q4 + 1]);
+            dw[q4 + 2] = fmaf(my, hv.z, dw[q4 + 2]); dw[q4 + 3] = fmaf(my, hv.w, dw[q4 + 3]);
+            const float4 gv = *reinterpret_cast<const float4*>(s_dg + p * H + q4);
+            acc0 = fmaf(wt[q4], gv.x, acc0); acc1 = fmaf(wt[q4 + 1], gv.y, acc1);
+            acc0 = fmaf(wt[q4 + 2], gv.z, acc0); acc1 = fmaf(wt[q4 + 3], gv.w, acc1);
+          }
+          s_part[p][kk] = acc0 + acc1;
+        }
+        lds_barrier();
+      }
+    }
+  }
+  if (live) {
+    float* o = pwhh + (((int64_t)b * 2 + dir) * G + tid) * H;
+#pragma unroll
+    for (int qq = 0; qq < H; ++qq) o[qq] = dw[qq];
   }
 }
 
@@ -182,10 +224,10 @@ extern "C" int lasr_bilstm_fwd(const float* gx_f, const float* gx_r, const float
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && T_ > 0 && col0 >= 0 && ld_out >= col0 + 2 * H, "lasr_bilstm_fwd: shape");
   dim3 grid((unsigned)B, 2);
   if (dtype == LASR_F32)
-    hipLaunchKernelGGL(bilstm_fwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), gx_f, gx_r, whh_f, whh_r, bih_f, bhh_f, bih_r, bhh_r,
+    hipLaunchKernelGGL(bilstm_fwd_kernel<float>, grid, dim3(kLstmThreads), 0, as_stream(stream), gx_f, gx_r, whh_f, whh_r, bih_f, bhh_f, bih_r, bhh_r,
                        lens, T_, (float*)out, ld_out, col0, saved);
   else
-    hipLaunchKernelGGL(bilstm_fwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), gx_f, gx_r, whh_f, whh_r, bih_f, bhh_f, bih_r, bhh_r,
+    hipLaunchKernelGGL(bilstm_fwd_kernel<bf16_t>, grid, dim3(kLstmThreads), 0, as_stream(stream), gx_f, gx_r, whh_f, whh_r, bih_f, bhh_f, bih_r, bhh_r,
                        lens, T_, (bf16_t*)out, ld_out, col0, saved);
   LASR_LAUNCH_CHECK("bilstm_fwd_kernel");
   return 0;
@@ -204,10 +246,10 @@ extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int
   dim3 grid((unsigned)B, 2);
   hipStream_t st = as_stream(stream);
   if (dtype == LASR_F32)
-    hipLaunchKernelGGL(bilstm_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved,
+    hipLaunchKernelGGL(bilstm_bwd_kernel<float>, grid, dim3(kLstmThreads), 0, st, (const float*)dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved,
                        dg_f, dg_r, pwhh);
   else
-    hipLaunchKernelGGL(bilstm_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved,
+    hipLaunchKernelGGL(bilstm_bwd_kernel<bf16_t>, grid, dim3(kLstmThreads), 0, st, (const bf16_t*)dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved,
                        dg_f, dg_r, pwhh);
   LASR_LAUNCH_CHECK("bilstm_bwd_kernel");
   // pwhh is [B][2][G*H]: sum over b with a stride of 2*G*H -> view as B partials of 2*G*H columns, split at G*H

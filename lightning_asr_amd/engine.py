@@ -58,6 +58,7 @@ class NativeModel:
         self.grads = torch.zeros(self.n_param, dtype=torch.float32, device=self.device)
         self.buffers = torch.zeros(max(self.n_buffer, 1), dtype=torch.float32, device=self.device)
         self.counters: Dict[str, torch.Tensor] = OrderedDict()   # num_batches_tracked (host side, int64)
+        self._bump = 0          # training forwards replayed from a captured graph (num_batches_tracked is applied lazily)
         self._ws: Optional[torch.Tensor] = None
         self._ws_key: Optional[Tuple[int, int, int]] = None
         self._last_feats = None
@@ -86,11 +87,23 @@ class NativeModel:
 
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         sd = OrderedDict()
+        self._apply_bump()
         for t in self.tensors:
             sd[t.name] = self.counters[t.name].clone() if t.kind == 2 else self.view(t).detach().clone()
         return sd
 
+    def bump_counters(self, n: int = 1) -> None:
+        """n training forwards ran without passing through forward() / loss_backward() (graph replays)"""
+        self._bump += n
+
+    def _apply_bump(self) -> None:
+        if self._bump:
+            for k in self.counters:
+                self.counters[k] += self._bump
+            self._bump = 0
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        self._bump = 0
         names = {t.name for t in self.tensors}
         if strict:
             missing, extra = names - set(sd), set(sd) - names

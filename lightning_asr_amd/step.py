@@ -11,9 +11,10 @@ from typing import Optional
 
 import torch
 
+import ctypes as C
 import os
 
-from . import ops
+from . import _lib, ops
 from .comm import Communicator
 from .engine import NativeModel
 from .schedule import CosineAnnealingWarmupRestarts
@@ -52,6 +53,7 @@ class TrainStep:
         self.force_staged = bool(int(os.environ.get("LASR_FORCE_OVERLAP", "0"))) and \
             (self.comm is not None or torch.distributed.is_initialized())
         self._prefetched = None    # (key, feats, pct) of the batch announced by the previous step(prefetch_wave=...)
+        self._lr_state = None      # device image of the schedule (use_device_schedule)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP wrap-time broadcast of parameters and buffers from rank 0."""
@@ -81,9 +83,27 @@ class TrainStep:
         ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
                           self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         if self.schedule is not None:
-            self.lr = self.schedule.step()
-            self.lr_dev.fill_(self.lr)
+            self.lr = self.schedule.step()                 # host copy of the schedule: bookkeeping / logging / checkpoints
+            if self._lr_state is not None:                 # the rate the next step uses is computed on the device
+                _lib.call("lasr_lr_schedule_step", self._lr_state.data_ptr(), self.lr_dev.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+            else:
+                self.lr_dev.fill_(self.lr)
         self.global_step += 1
+
+    def use_device_schedule(self) -> None:
+        """Move the LR schedule's state onto the GPU (csrc/sched.hip): from now on every optimizer_step advances it with a
+        one-thread kernel instead of a host scalar + fill, so the whole step is capturable.  The host object keeps stepping
+        alongside (same values to f32 rounding) for logging and checkpoints."""
+        if self.schedule is None or self._lr_state is not None:
+            return
+        sc = self.schedule
+        nb = int(_lib.load().lasr_lr_schedule_state_bytes())
+        host = C.create_string_buffer(nb)
+        _lib.call("lasr_lr_schedule_init", host, nb, int(sc.first_cycle_steps), float(sc.cycle_mult), float(sc.base_max_lr),
+                  float(sc.min_lr), int(sc.warmup_steps), float(sc.gamma), int(sc.cycle), int(sc.step_in_cycle),
+                  int(sc.cur_cycle_steps), int(sc.last_epoch))
+        self._lr_state = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.model.device)
 
     def step_features(self, feats, pct, targets, tgt_lens, want_logp: bool = True):
         m = self.model
@@ -132,3 +152,93 @@ class TrainStep:
         out = self.step_features(feats, pct, targets, tgt_lens, want_logp=want_logp)
         self._prefetched = nxt
         return out
+
+
+class GraphedTrainStep:
+    """One static-shape training step captured into a hipGraph (torch.cuda.CUDAGraph over the stream the C ABI launches on) and
+    replayed: ~200 kernel launches per step become one graph launch, so the step no longer depends on how fast the host can
+    enqueue (measured on a box whose CPUs were shared with three other jobs: 2.9 ms/step host-bound against 2.35 ms of GPU work).
+
+    ``step(next_wave, targets, tgt_lens)``: like the prefetching ``TrainStep.step`` - the replay trains on the features the
+    PREVIOUS replay computed and computes the features of ``next_wave`` inside its CTC launch; ``targets`` belong to the batch
+    being trained on.  prefetch=False: features and training step of the same ``wave`` in one replay (ragged buckets).
+    Shapes are fixed at construction; one instance per (B, L, S)."""
+
+    def __init__(self, ts: TrainStep, B: int, L: int, S: int, ragged: bool = False, prefetch: bool = True, want_logp: bool = False):
+        self.ts, self.prefetch, self.want_logp = ts, prefetch, want_logp
+        dev = ts.model.device
+        self.wave = torch.zeros(B, L, dtype=torch.float32, device=dev)
+        self.lens = torch.full((B,), L, dtype=torch.int32, device=dev) if ragged else None
+        self.targets = torch.zeros(B, S, dtype=torch.int64, device=dev)
+        self.tgt_lens = torch.ones(B, dtype=torch.int32, device=dev)
+        self.graph = None
+        self.out = None
+        self.F_cur = self.pct_cur = None
+
+    def _body(self):
+        ts, m = self.ts, self.ts.model
+        if self.prefetch:
+            nf, npct = m.arm_prefetch(self.wave, self.lens)
+            out = ts.step_features(self.F_cur, self.pct_cur, self.targets, self.tgt_lens, want_logp=self.want_logp)
+            self.F_cur.copy_(nf)
+            self.pct_cur.copy_(npct)
+            return out
+        feats, pct = ts.features(self.wave, self.lens)
+        return ts.step_features(feats, pct, self.targets, self.tgt_lens, want_logp=self.want_logp)
+
+    def capture(self, first_wave: torch.Tensor, first_lens: Optional[torch.Tensor] = None, warmup: int = 2) -> None:
+        """first_wave: the batch the first replay trains on (prefetch mode: its features are computed eagerly here).
+        The eager warm-up passes and the capture pass leave the training state (parameters, BN buffers, optimiser moments,
+        schedule) exactly as it was: it is snapshotted before and restored after."""
+        ts, m = self.ts, self.ts.model
+        if ts.world > 1 and not int(os.environ.get("LASR_GRAPH_DP", "0")):
+            raise RuntimeError("graph capture of the data-parallel step (RCCL inside the graph) is opt-in: LASR_GRAPH_DP=1")
+        ts.use_device_schedule()
+        dev_state = [m.params, m.buffers, ts.exp_avg, ts.exp_avg_sq, ts.lr_dev] + ([ts._lr_state] if ts._lr_state is not None else [])
+        snap = [t.clone() for t in dev_state]
+        sched_sd = dict(ts.schedule.state_dict()) if ts.schedule is not None else None
+        gstep, bump = ts.global_step, m._bump
+        counters = {k: v.clone() for k, v in m.counters.items()}
+        self.wave.copy_(first_wave)                  # warm-up needs real audio (an all-zero wave has zero variance)
+        if self.lens is not None and first_lens is not None:
+            self.lens.copy_(first_lens)
+        if self.prefetch:
+            f, p_ = ts.features(first_wave, first_lens)
+            self.F_cur, self.pct_cur = f.clone(), p_.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=m.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):            # eager warm-up on a side stream (allocator / lazy-init settle before capture)
+            for _ in range(warmup):
+                self._body()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):       # records the launches; nothing executes
+            self.out = self._body()
+        for t, s_ in zip(dev_state, snap):
+            t.copy_(s_)
+        if self.prefetch:
+            self.F_cur.copy_(f)
+            self.pct_cur.copy_(p_)
+        if sched_sd is not None:
+            ts.schedule.load_state_dict(sched_sd)
+            ts.lr = ts.schedule.lr
+        ts.global_step, m._bump = gstep, bump
+        m.counters.update(counters)
+        torch.cuda.synchronize()
+
+    def step(self, wave: torch.Tensor, targets: torch.Tensor, tgt_lens: torch.Tensor, lens: Optional[torch.Tensor] = None):
+        """copies the inputs into the graph's static buffers and replays; returns the static (loss, nll, logp, argmax) tensors"""
+        self.wave.copy_(wave, non_blocking=True)
+        if self.lens is not None and lens is not None:
+            self.lens.copy_(lens, non_blocking=True)
+        self.targets.copy_(targets, non_blocking=True)
+        self.tgt_lens.copy_(tgt_lens, non_blocking=True)
+        self.graph.replay()
+        ts = self.ts
+        ts.model.bump_counters(1)
+        if ts.schedule is not None:
+            ts.lr = ts.schedule.step()
+        ts.global_step += 1
+        return self.out

@@ -178,3 +178,63 @@ def test_native_rccl_allreduce_orders_after_producer_stream(dev):
         comm.wait()
         assert float(buf.sum().item()) == float(k) * buf.numel()
     comm.close()
+
+
+def test_device_lr_schedule_matches_host(dev):
+    """lasr_lr_schedule_step (one-thread kernel, f64 state on the device) against the host class it mirrors
+    (scheduler/cosine_annearing_with_warmup.py:53-89) across warm-up, cosine decay and two restarts with cycle_mult / gamma."""
+    import ctypes as C
+    from lightning_asr_amd import _lib
+    from lightning_asr_amd.schedule import CosineAnnealingWarmupRestarts
+    sc = CosineAnnealingWarmupRestarts(None, first_cycle_steps=50, cycle_mult=2, max_lr=1e-2, min_lr=1e-4, warmup_steps=10, gamma=0.5)
+    nb = int(_lib.load().lasr_lr_schedule_state_bytes())
+    host = C.create_string_buffer(nb)
+    _lib.call("lasr_lr_schedule_init", host, nb, sc.first_cycle_steps, float(sc.cycle_mult), float(sc.base_max_lr), float(sc.min_lr),
+              sc.warmup_steps, float(sc.gamma), sc.cycle, sc.step_in_cycle, sc.cur_cycle_steps, sc.last_epoch)
+    state = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev)
+    lr = torch.zeros(1, dtype=torch.float32, device=dev)
+    got, exp = [], []
+    for _ in range(400):
+        _lib.call("lasr_lr_schedule_step", state.data_ptr(), lr.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        got.append(lr.clone())
+        exp.append(sc.step())
+    got = torch.cat(got).cpu().double()
+    exp = torch.tensor(exp, dtype=torch.float64)
+    assert ((got - exp).abs() / exp).max() < 2e-7          # f32 rounding of an f64 value
+    assert sc.cycle == 2                                   # the range covered two restarts
+
+
+@pytest.mark.parametrize("variant,prefetch", [("plain", True), ("plain", False), ("context_se", True)])
+def test_graphed_step_equals_eager(dev, variant, prefetch):
+    """GraphedTrainStep (the step captured into a hipGraph and replayed) against the eager TrainStep on the same batches:
+    same losses, bit-identical parameters; capture itself must leave the training state untouched."""
+    from lightning_asr_amd.engine import NativeModel
+    from lightning_asr_amd.schedule import CosineAnnealingWarmupRestarts
+    from lightning_asr_amd.step import GraphedTrainStep, TrainStep
+    batches = [tuple(t.to(dev) for t in _batch(0, s)) for s in range(4)]
+
+    def make():
+        m = NativeModel(variant, 28, mask=True, act="relu", dtype=torch.bfloat16, device=dev)
+        m.init_parameters(seed=9)
+        sc = CosineAnnealingWarmupRestarts(None, first_cycle_steps=1000, cycle_mult=2, max_lr=1e-2, min_lr=1e-4, warmup_steps=3, gamma=0.5)
+        return m, TrainStep(m, 1e-2, 1e-3, schedule=sc)
+    m0, ts0 = make()
+    l0 = []
+    for s, (w, tg, tl) in enumerate(batches):
+        nxt = batches[(s + 1) % 4][0] if prefetch else None
+        l0.append(float(ts0.step(w, tg, tl, prefetch_wave=nxt)[0].item()))
+    m1, ts1 = make()
+    p_before = m1.params.clone()
+    g = GraphedTrainStep(ts1, B, L, S, prefetch=prefetch, want_logp=True)
+    g.capture(batches[0][0])
+    assert torch.equal(m1.params, p_before) and ts1.global_step == 0 and ts1.schedule.last_epoch == 0
+    l1 = []
+    for s, (w, tg, tl) in enumerate(batches):
+        out = g.step(batches[(s + 1) % 4][0] if prefetch else w, tg, tl)
+        l1.append(float(out[0].item()))
+    torch.cuda.synchronize()
+    assert l0 == l1
+    assert torch.equal(m0.params, m1.params)
+    assert ts1.global_step == 4 and abs(ts1.lr - ts0.lr) < 1e-12
+    sd = m1.state_dict()
+    assert int(sd["encoder.first_cnn.bn.num_batches_tracked"]) == 4

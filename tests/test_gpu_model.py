@@ -64,8 +64,9 @@ def test_plain_loss_backward_matches_golden_f32(dev):
     o = R.OracleModel("plain", 28, mask=True, state=R.formula_state("plain", 28))
     st = R.NovogradState(len(o.parameters()))
     _, grads = R.train_step(o, st, x, tg, pct, tsz, 1e-2, 1e-3)
-    worst = max(rel_l2(m.view(t, m.grads), g) for t, g in zip(m.param_infos(), grads))
-    assert worst < 2e-3, worst
+    rels = {t.name: rel_l2(m.view(t, m.grads), g) for t, g in zip(m.param_infos(), grads)}
+    worst = max(rels.values())
+    assert worst < 2e-3, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
     # running statistics after one training forward
     for t in m.tensors:
         if t.kind == 1:

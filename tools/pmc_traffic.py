@@ -2,12 +2,16 @@
 dominant kernel class.  gfx950 corrections per MI355X_MICROARCH.md §HBM: counters are in KiB;
 FETCH_SIZE reads exactly half of a wide (16 B/lane) coalesced stream, so it is doubled; WRITE_SIZE is exact.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <out.json>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <kernel-substring> <out.json> [config]
+The output records the source hash of the kernels (bench.source_id): bench.py quotes it as roofline.traffic only on the same build.
 """
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(d, counter, sub):
@@ -23,7 +27,8 @@ def main():
     fd, wd, sub, out = sys.argv[1:5]
     fetch, nf = per_kernel(fd, "FETCH_SIZE", sub)
     write, nw = per_kernel(wd, "WRITE_SIZE", sub)
-    res = {"kernel": sub, "launches_fetch_pass": nf, "launches_write_pass": nw,
+    import bench
+    res = {"kernel": sub, "config": sys.argv[5] if len(sys.argv) > 5 else None, "source_id": bench.source_id(), "launches_fetch_pass": nf, "launches_write_pass": nw,
            "fetch_kib_raw_per_launch": fetch / max(nf, 1), "write_kib_per_launch": write / max(nw, 1),
            "hbm_bytes_per_launch": (2.0 * fetch / max(nf, 1) + write / max(nw, 1)) * 1024.0,
            "note": "FETCH_SIZE doubled (gfx950 wide-load correction), KiB -> bytes"}
