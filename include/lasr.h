@@ -188,6 +188,33 @@ typedef struct {
 int lasr_bn_finalize_partials(const lasr_bn_branch* branches, int n_branches, int64_t C, int64_t n_rows, float eps,
                               float momentum, void* stream);
 
+/* nn.Dropout(p) of SeprationConv / last_cnn2 (models/QuartNet.py:26,38,149) folded into the BN-apply kernels as a counter-based
+ * (Philox4x32-10) mask: forward and both backward passes regenerate it from (seed, *step, unit, element index); no mask tensor
+ * exists.  step: device scalar holding the index of the current training forward (lasr_mask_lengths_step bumps it as the first
+ * launch of a forward, so replayed graphs draw fresh masks); unit: distinct per layer.  A residual unit drops its MAIN branch
+ * before the add (the Dropout at the end of its SeprationConv), first_cnn / last_cnn2 drop after the activation.  Kept
+ * elements are scaled by 1/(1-p).  NULL descriptor or p = 0: off (the plain entry points).  lasr_dropout_mask writes the mask
+ * itself (1 = kept) for verification against a CPU reference.                                                           */
+typedef struct { const uint64_t* step; uint64_t seed; uint32_t unit; float p; } lasr_dropout;
+int lasr_mask_lengths_step(const float* pct, int64_t B, int64_t T, int32_t* lens, uint64_t* step_counter, void* stream);
+int lasr_dropout_mask(const lasr_dropout* dropout, int64_t n, uint8_t* keep, void* stream);
+int lasr_bn_act_fwd_drop(const void* y, const float* coef, const void* y2, const float* coef2, const float* se_scale, void* out,
+                         int dtype, int64_t B, int64_t T, int64_t C, int act, const lasr_dropout* dropout, void* stream);
+int lasr_bn_act_bwd_stats_drop(const void* dout, const void* y, const float* coef, const float* saved, const void* y2,
+                               const float* coef2, const float* saved2, const float* se_scale, const float* se_grad, float* sums,
+                               float* sums2, int dtype, int64_t B, int64_t T, int64_t C, int act, const lasr_dropout* dropout,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int lasr_se_bwd_drop(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
+                     const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
+                     int64_t C, int act, const lasr_dropout* dropout, float* seg, float* dW1, float* dW2, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const float* coef, const float* saved, const float* gamma,
+                               const void* y2, const float* coef2, const float* saved2, const float* gamma2,
+                               const float* se_scale, const float* se_grad, const float* sums, const float* sums2,
+                               const int32_t* row_lens, void* dy, void* dy2, float* dgamma, float* dbeta, float* dgamma2,
+                               float* dbeta2, int dtype, int64_t B, int64_t T, int64_t C, int act, const lasr_dropout* dropout,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* out = act( (y*coef_a + coef_b) * se_scale[b][c] + (y2*coef2_a + coef2_b) )
  * y2/coef2 (residual branch) and se_scale ([B][C] f32) may be NULL.
  * (BN-apply + SE scale + residual add + ReLU: models/QuartNet.py:35-37,74-77; ContextSE :55) */
@@ -357,6 +384,9 @@ int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* s
 /* Tensors in reference state_dict order.  kind: 0 = parameter (lives in the flat param buffer at
  * `offset` elements), 1 = f32 buffer (running_mean/var, flat buffer array), 2 = num_batches_tracked
  * (int64, kept by the host).  Returns the number of tensors; fills row i when i >= 0.            */
+/* nn.Dropout(p = drop_rate) of models/QuartNet.py:26,38,149 in every training forward / backward of this model (see
+ * lasr_dropout above): step_counter is a caller-owned device scalar (uint64, zero-initialised); p = 0 switches it off.   */
+int lasr_model_set_dropout(lasr_model_t* m, float p, uint64_t seed, uint64_t* step_counter);
 int64_t lasr_model_tensor_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap,
                                int64_t shape[4], int32_t* ndim, int32_t* kind, int64_t* offset);
 int64_t lasr_model_param_elems(const lasr_model_t* m);

@@ -15,6 +15,11 @@ VARIANT = {"plain": 0, "context": 1, "context_se": 2}
 _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
 
+class Dropout(C.Structure):
+    """lasr_dropout: device step counter, seed, unit index, p"""
+    _fields_ = [("step", C.c_void_p), ("seed", C.c_uint64), ("unit", C.c_uint32), ("p", C.c_float)]
+
+
 class ModelConfig(C.Structure):
     _fields_ = [("variant", C.c_int32), ("n_class", C.c_int32), ("in_c", C.c_int32),
                 ("mask", C.c_int32), ("act", C.c_int32), ("dtype", C.c_int32)]
@@ -98,6 +103,13 @@ SIGNATURES = {
     "lasr_model_unit_info": (_i32, [_p, _i64, C.c_char_p, _sz]),
     "lasr_model_loss_backward_partial": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _i64, _p]),
     "lasr_model_backward_continue": (_i32, [_p, _p, _p, _i64, _i64, _p, _p, _sz, _i64, _p]),
+    "lasr_mask_lengths_step": (_i32, [_p, _i64, _i64, _p, _p, _p]),
+    "lasr_dropout_mask": (_i32, [_p, _i64, _p, _p]),
+    "lasr_bn_act_fwd_drop": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _i64, _i64, _i32, _p, _p]),
+    "lasr_bn_act_bwd_stats_drop": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "lasr_bn_act_bwd_apply_drop": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "lasr_se_bwd_drop": (_i32, [_p] * 10 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "lasr_model_set_dropout": (_i32, [_p, _f32, C.c_uint64, _p]),
     "lasr_lr_schedule_state_bytes": (_sz, []),
     "lasr_lr_schedule_init": (_i32, [_p, _sz, _i64, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _i64, _i64, _i64, _i64]),
     "lasr_lr_schedule_step": (_i32, [_p, _p, _p]),

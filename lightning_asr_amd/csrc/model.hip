@@ -30,6 +30,10 @@ extern "C" size_t lasr_bilstm_bwd_workspace_bytes(int64_t B);
 extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f, const float* whh_r,
                                const int32_t* lens, int64_t B, int64_t T, const float* saved, float* dg_f, float* dg_r, float* dwhh_f,
                                float* dwhh_r, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
+                                const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
+                                int64_t C, int act, const lasr_dropout* dropout, float* seg, float* dW1, float* dW2, void* workspace,
+                                size_t workspace_bytes, void* stream);
 extern "C" int lasr_gemm_rowstat(const void* A, const void* B, const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                  float* row_stat, int32_t* row_arg, int* n_col_tiles, void* stream);
 extern "C" size_t lasr_gemm_rowstat_bytes(int64_t M, int64_t N);
@@ -102,6 +106,11 @@ struct lasr_model {
   LstmRef lstm;
   Plan plan;
   bool planned = false;
+  // nn.Dropout(p = drop_rate) of every SeprationConv and of last_cnn2 (models/QuartNet.py:26,38,149): counter-based masks
+  // regenerated in forward and backward (dropout.h); drop_step is a device scalar the first launch of a training forward bumps
+  float drop_p = 0.f;
+  uint64_t drop_seed = 0;
+  uint64_t* drop_step = nullptr;
   bool lean_active = false;   // the last loss ran the large-vocabulary head: d(logits) is the bf16 [N][ldc] tensor at o_d1, db is done
   int lean_tiles = 0;
   int bwd_cur = 0;       // ping-pong index of the gradient buffers between partial backward calls
@@ -320,6 +329,12 @@ extern "C" int lasr_model_create(const lasr_model_config* cfg, lasr_model_t** ou
 
 extern "C" void lasr_model_destroy(lasr_model_t* m) { delete m; }
 
+extern "C" int lasr_model_set_dropout(lasr_model_t* m, float p, uint64_t seed, uint64_t* step_counter) {
+  LASR_CHECK_ARG(m && p >= 0.f && p < 1.f && (p == 0.f || step_counter), "lasr_model_set_dropout: 0 <= p < 1 and a device step counter");
+  m->drop_p = p; m->drop_seed = seed; m->drop_step = p > 0.f ? step_counter : nullptr;
+  return 0;
+}
+
 extern "C" int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
                                        const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
                                        int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes) {
@@ -428,7 +443,8 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
   const int dt = m->cfg.dtype;
   const int64_t T = p.T, N = B * T;
   int32_t* lens = reinterpret_cast<int32_t*>(at(ws, p.o_lens));
-  LASR_TRY(lasr_mask_lengths(pct, B, T, lens, stream));
+  const bool dropping = training && m->drop_p > 0.f;
+  LASR_TRY(lasr_mask_lengths_step(pct, B, T, lens, dropping ? m->drop_step : nullptr, stream));   // (bumps the masks' step counter)
   if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
   void* scratch = at(ws, p.o_scratch);
   if (!training) {   // eval: BN coefficients of all layers from the running statistics, one launch
@@ -514,9 +530,10 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
       LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
                            atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), stream));
     }
-    LASR_TRY(lasr_bn_act_fwd(at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
-                             u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_se ? atf(ws, u.o_se_scale) : nullptr, at(ws, u.o_out), dt, B,
-                             T, u.co, u.act ? m->cfg.act : LASR_ACT_NONE, stream));
+    const lasr_dropout drop = {m->drop_step, m->drop_seed, (uint32_t)(&u - m->units.data()), dropping ? m->drop_p : 0.f};
+    LASR_TRY(lasr_bn_act_fwd_drop(at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
+                                  u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_se ? atf(ws, u.o_se_scale) : nullptr, at(ws, u.o_out), dt, B,
+                                  T, u.co, u.act ? m->cfg.act : LASR_ACT_NONE, dropping ? &drop : nullptr, stream));
     x = at(ws, u.o_out);
     Tx = T;
   }
@@ -606,23 +623,25 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     void* dy2 = u.has_res ? (defer_w ? at(ws, u.o_dy2) : at(ws, p.o_d2)) : nullptr;
     const float* se_scale = u.has_se ? atf(ws, u.o_se_scale) : nullptr;
     const float* se_grad = u.has_se ? atf(ws, u.o_se_grad) : nullptr;
+    const lasr_dropout drop = {m->drop_step, m->drop_seed, (uint32_t)ui, m->drop_p};   // the masks of this step's forward
+    const lasr_dropout* dq = m->drop_p > 0.f ? &drop : nullptr;
     if (u.has_se)
-      LASR_TRY(lasr_se_bwd(dout, at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
-                           u.has_res ? atf(ws, u.o_coef2) : nullptr, se_scale, atf(ws, u.o_se_hid), atf(ws, u.o_se_pool), params + u.w_se1,
-                           params + u.w_se2, dt, B, T, u.co, act, atf(ws, u.o_se_grad), grads + u.w_se1, grads + u.w_se2, scratch, sb,
-                           stream));
+      LASR_TRY(lasr_se_bwd_drop(dout, at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
+                                u.has_res ? atf(ws, u.o_coef2) : nullptr, se_scale, atf(ws, u.o_se_hid), atf(ws, u.o_se_pool), params + u.w_se1,
+                                params + u.w_se2, dt, B, T, u.co, act, dq, atf(ws, u.o_se_grad), grads + u.w_se1, grads + u.w_se2, scratch, sb,
+                                stream));
     // fused hand-over: pass 2 reduces pass 1's partial sums (LASR_NO_FUSE=1 keeps the separate reductions, for A/B runs)
     float* fsum = no_fuse() ? atf(ws, p.o_sums) : nullptr;
     float* fsum2 = no_fuse() ? atf(ws, p.o_sums2) : nullptr;
-    LASR_TRY(lasr_bn_act_bwd_stats(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), u.has_res ? at(ws, u.o_y2) : nullptr,
-                                   u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_res ? atf(ws, u.o_saved2) : nullptr, se_scale,
-                                   se_grad, fsum, fsum2, dt, B, T, u.co, act, scratch, sb, stream));
-    LASR_TRY(lasr_bn_act_bwd_apply(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma,
-                                   u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
-                                   u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, se_scale,
-                                   se_grad, fsum, fsum2, u.masked ? lens : nullptr, dy, dy2,
-                                   grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
-                                   u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, scratch, sb, stream));
+    LASR_TRY(lasr_bn_act_bwd_stats_drop(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), u.has_res ? at(ws, u.o_y2) : nullptr,
+                                        u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_res ? atf(ws, u.o_saved2) : nullptr, se_scale,
+                                        se_grad, fsum, fsum2, dt, B, T, u.co, act, dq, scratch, sb, stream));
+    LASR_TRY(lasr_bn_act_bwd_apply_drop(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma,
+                                        u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
+                                        u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, se_scale,
+                                        se_grad, fsum, fsum2, u.masked ? lens : nullptr, dy, dy2,
+                                        grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
+                                        u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, dq, scratch, sb, stream));
     // weight gradients of the main and residual 1x1: dW[co][ci] = dy^T gin, dWr = dy2^T x  (one split-K launch)
     const void* gin = u.has_dw ? at(ws, u.o_u) : x_in;
     {

@@ -3,6 +3,7 @@
 // Replaces models/QuartNet.py:33-37 (MaskCNN lengths, BatchNorm1d(eps=1e-3), ReLU) and :74-77
 // (residual add + ReLU), plus their autograd backward.  All statistics are f32.
 #include "common.h"
+#include "dropout.h"
 #include <algorithm>
 
 namespace lasr {
@@ -35,9 +36,11 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
   }
 }
 
-__global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, float Tf, int32_t* __restrict__ lens) {
+__global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, float Tf, int32_t* __restrict__ lens,
+                                    unsigned long long* __restrict__ step_counter) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < B) lens[i] = (int32_t)(Tf * pct[i]);  // f32 product, truncation toward zero (torch .int())
+  if (i == 0 && step_counter) *step_counter += 1ull;   // index of this training forward: the dropout masks' counter (dropout.h)
 }
 
 // ------------------------------------------------------------------ BN finalize --------------
@@ -239,13 +242,14 @@ __device__ __forceinline__ void ld_tab(const float* p, float (&o)[4]) { lds_vec8
 
 // out = act((a*y + b)*se + a2*y2 + b2);  s_tab = [a | b | a2 | b2][C].  Two items per thread in flight, no branch
 // around a load (HAS2 is a template parameter, the second item's index is clamped and only its store predicated).
-template <typename T, bool HAS2, bool SE>
+template <typename T, bool HAS2, bool SE, bool DROP>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                          const T* __restrict__ y2, const float* __restrict__ coef2,
                                                          const float* __restrict__ se, T* __restrict__ out,
-                                                         int rows, int Tt, int C, int act) {
+                                                         int rows, int Tt, int C, int act, DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) float s_tab[];
   constexpr int V = Vec<T>::kN;
+  const unsigned long long drop_step = DROP ? *drop.step : 0ull;
   for (int i = threadIdx.x * 4; i < 2 * C; i += 1024) {
     const int d = tab_pos<V>(i, C);
     *reinterpret_cast<float4*>(s_tab + d) = *reinterpret_cast<const float4*>(coef + i);
@@ -281,6 +285,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         o[j] = fmaf(v[j], a[j], b[j]);
         if (SE) o[j] *= sev[u][j];
       }
+      // nn.Dropout sits at the end of SeprationConv (models/QuartNet.py:38): on the main branch BEFORE the residual add of a
+      // block, AFTER the activation of first_cnn / last_cnn2
+      float dsc[V];
+      if (DROP) drop_scale<V>(drop, drop_step, off[u], dsc);
+      if (DROP && HAS2) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] *= dsc[j];
+      }
       if (HAS2) {
         Vec<T>::unpack(rw[u], w);
         tab_vec(s_tab + 2 * C, c, C, a); tab_vec(s_tab + 3 * C, c, C, b);
@@ -289,6 +301,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       }
 #pragma unroll
       for (int j = 0; j < V; ++j) o[j] = act_fwd(o[j], act);
+      if (DROP && !HAS2) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] *= dsc[j];
+      }
       if (it0 + 256 * u < n_items) Vec<T>::store(out + off[u], o);
     }
   }
@@ -299,15 +315,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 // no branch around a load; a thread's rows are taken two at a time with all six 16-byte loads issued before the
 // first is unpacked (four at a time, or the constants streamed from LDS, cost the second wave per SIMD:
 // measured 34 us against 11).  The kernel was a chain of eight exposed memory round trips per slab.
-template <typename T, bool HAS2, bool SE>
+template <typename T, bool HAS2, bool SE, bool DROP>
 __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                               const float* __restrict__ coef, const float* __restrict__ saved,
                                                               const T* __restrict__ y2, const float* __restrict__ coef2,
                                                               const float* __restrict__ saved2, const float* __restrict__ se,
                                                               const float* __restrict__ seg, float* __restrict__ partials,
-                                                              int rows, int Tt, int C, int act) {
+                                                              int rows, int Tt, int C, int act, DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [row_lanes][4][C]
   constexpr int V = Vec<T>::kN;
+  const unsigned long long drop_step = DROP ? *drop.step : 0ull;
   constexpr int RB = 2;                                           // rows in flight per thread
   const ColGeom g = col_geom<V>(C);
   const int r0 = blockIdx.x * kRowsPerBlock;
@@ -352,12 +369,16 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restric
           if (HAS2) Vec<T>::unpack(rr[i], rvi);
           const int r = rb + i * g.row_lanes;
           const float live = r < r1 ? 1.f : 0.f;                  // rows past the slab contribute nothing
+          float dsc[V];
+          if (DROP) drop_scale<V>(drop, drop_step, (uint32_t)min(r, rows - 1) * (uint32_t)C + (uint32_t)c, dsc);
 #pragma unroll
           for (int j = 0; j < V; ++j) {
             const float sej = SE ? sev[i][j] : 1.f;
-            const float z = fmaf(yvi[j], a1[j], b1[j]) * sej + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
-            const float d = dvi[j] * act_grad(z, act) * live;
-            const float d1 = fmaf(d, sej, (SE && seg) ? sgv[i][j] * live : 0.f);
+            const float zm = fmaf(yvi[j], a1[j], b1[j]) * sej * ((DROP && HAS2) ? dsc[j] : 1.f);
+            const float z = zm + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
+            const float d = dvi[j] * act_grad(z, act) * live * ((DROP && !HAS2) ? dsc[j] : 1.f);   // gradient at the pre-activation
+            const float dmn = (DROP && HAS2) ? d * dsc[j] : d;                                       // ... reaching the main branch
+            const float d1 = fmaf(dmn, sej, (SE && seg) ? sgv[i][j] * live : 0.f);
             acc[0][j] += d1;
             acc[1][j] = fmaf(d1, (yvi[j] - m1[j]) * q1[j], acc[1][j]);
             if (HAS2) {
@@ -451,14 +472,15 @@ __global__ __launch_bounds__(256) void bn_bwd_table_partials_kernel(const float*
 
 // pass 2b: dy = G1*d1 + B1*y + C1 (rows past the utterance length zeroed), dy2 = G2*d + B2*y2 + C2.
 // Two items per thread in flight, HAS2 a template parameter: no branch around a load.
-template <typename T, bool HAS2, bool SE>
+template <typename T, bool HAS2, bool SE, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const T* __restrict__ y2, const float* __restrict__ tab,
                                                            const float* __restrict__ se, const float* __restrict__ seg,
                                                            const int32_t* __restrict__ row_lens, T* __restrict__ dy,
-                                                           T* __restrict__ dy2, int rows, int Tt, int C, int act) {
+                                                           T* __restrict__ dy2, int rows, int Tt, int C, int act, DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) float s_tab[];  // [10][C]
   constexpr int V = Vec<T>::kN;
+  const unsigned long long drop_step = DROP ? *drop.step : 0ull;
   for (int i = threadIdx.x * 4; i < 10 * C; i += 1024) *reinterpret_cast<float4*>(s_tab + tab_pos<V>(i, C)) = *reinterpret_cast<const float4*>(tab + i);
   __syncthreads();
   const int cv = C / V;
@@ -499,6 +521,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       float z[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], a1[j], b1[j]) * (SE ? sev[u][j] : 1.f);
+      float dsc[V];
+      if (DROP) drop_scale<V>(drop, drop_step, off[u], dsc);
+      if (DROP && HAS2) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) z[j] *= dsc[j];
+      }
       if (HAS2) {
         tab_vec(s_tab + 5 * C, c, C, a1); tab_vec(s_tab + 6 * C, c, C, b1);
 #pragma unroll
@@ -506,11 +534,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       }
       float d[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
+      for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act) * ((DROP && !HAS2) ? dsc[j] : 1.f);
       tab_vec(s_tab + 2 * C, c, C, G); tab_vec(s_tab + 3 * C, c, C, Bc); tab_vec(s_tab + 4 * C, c, C, Cc);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const float d1 = fmaf(d[j], SE ? sev[u][j] : 1.f, (SE && seg) ? sgv[u][j] : 0.f);
+        const float d1 = fmaf((DROP && HAS2) ? d[j] * dsc[j] : d[j], SE ? sev[u][j] : 1.f, (SE && seg) ? sgv[u][j] : 0.f);
         o1[j] = masked ? 0.f : fmaf(G[j], d1, fmaf(Bc[j], yv[j], Cc[j]));
       }
       if (live) Vec<T>::store(dy + off[u], o1);
@@ -528,9 +556,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 using namespace lasr;
 
+extern "C" int lasr_bn_act_bwd_stats_drop(const void* dout, const void* y, const float* coef, const float* saved, const void* y2,
+                                          const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
+                                          float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
+                                          const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream);
+extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const float* coef, const float* saved,
+                                          const float* gamma, const void* y2, const float* coef2, const float* saved2,
+                                          const float* gamma2, const float* se_scale, const float* se_grad, const float* sums,
+                                          const float* sums2, const int32_t* row_lens, void* dy, void* dy2, float* dgamma,
+                                          float* dbeta, float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T_, int64_t C,
+                                          int act, const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream);
+
 #define DISPATCH_DTYPE(dtype, ...)                      \
   if ((dtype) == LASR_F32) { using T = float; __VA_ARGS__; } \
   else { using T = bf16_t; __VA_ARGS__; }
+
+// public descriptor -> kernel arguments (p = 0 or a null descriptor: dropout off)
+static DropArgs make_drop(const lasr_dropout* d) {
+  DropArgs a;
+  a.step = nullptr; a.seed = 0; a.unit = 0; a.thresh = 0; a.inv_keep = 1.f;
+  if (d && d->step && d->p > 0.f) {
+    a.step = reinterpret_cast<const unsigned long long*>(d->step);
+    a.seed = d->seed; a.unit = d->unit;
+    const float p = d->p < 0.999f ? d->p : 0.999f;
+    a.thresh = (uint32_t)(p * 65536.f + 0.5f);
+    a.inv_keep = 1.f / (1.f - (float)a.thresh / 65536.f);     // scale by the keep probability actually realised
+  }
+  return a;
+}
 
 extern "C" int lasr_bct_to_btc(const float* in, void* out, int dtype, int64_t B, int64_t C, int64_t T_, void* stream) {
   LASR_CHECK_ARG(in && out && (dtype == LASR_F32 || dtype == LASR_BF16), "lasr_bct_to_btc: bad argument");
@@ -549,10 +602,31 @@ extern "C" int lasr_btc_to_bct(const void* in, int dtype, float* out, int64_t B,
   return 0;
 }
 
-extern "C" int lasr_mask_lengths(const float* pct, int64_t B, int64_t T_, int32_t* lens, void* stream) {
+extern "C" int lasr_mask_lengths_step(const float* pct, int64_t B, int64_t T_, int32_t* lens, uint64_t* step_counter, void* stream) {
   LASR_CHECK_ARG(pct && lens && B > 0 && T_ > 0, "lasr_mask_lengths: bad argument");
-  hipLaunchKernelGGL(mask_lengths_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), pct, B, (float)T_, lens);
+  hipLaunchKernelGGL(mask_lengths_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), pct, B, (float)T_, lens,
+                     reinterpret_cast<unsigned long long*>(step_counter));
   LASR_LAUNCH_CHECK("mask_lengths_kernel");
+  return 0;
+}
+extern "C" int lasr_mask_lengths(const float* pct, int64_t B, int64_t T_, int32_t* lens, void* stream) {
+  return lasr_mask_lengths_step(pct, B, T_, lens, nullptr, stream);
+}
+
+// keep[e] = 1 / 0 for the first n elements of the mask a kernel draws for `dropout` at the CURRENT value of its step counter
+// (verification: the oracle applies the very same mask)
+namespace lasr {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(DropArgs d, int64_t n, uint8_t* __restrict__ keep) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v * 8 >= n) return;
+  const uint32_t m = d.step ? drop_keep8(d, *d.step, (uint32_t)v) : 0xffu;
+  for (int i = 0; i < 8 && v * 8 + i < n; ++i) keep[v * 8 + i] = (m >> i) & 1u;
+}
+}  // namespace lasr
+extern "C" int lasr_dropout_mask(const lasr_dropout* dropout, int64_t n, uint8_t* keep, void* stream) {
+  LASR_CHECK_ARG(dropout && keep && n > 0 && n < ((int64_t)1 << 34), "lasr_dropout_mask: bad argument");
+  hipLaunchKernelGGL(lasr::dropout_mask_kernel, dim3((unsigned)cdiv(cdiv(n, 8), 256)), dim3(256), 0, as_stream(stream), make_drop(dropout), n, keep);
+  LASR_LAUNCH_CHECK("dropout_mask_kernel");
   return 0;
 }
 
@@ -591,27 +665,42 @@ static int check_bn_shape(const char* who, int dtype, int64_t B, int64_t T_, int
   return 0;
 }
 
-extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2, const float* coef2, const float* se_scale,
-                               void* out, int dtype, int64_t B, int64_t T_, int64_t C, int act, void* stream) {
+extern "C" int lasr_bn_act_fwd_drop(const void* y, const float* coef, const void* y2, const float* coef2, const float* se_scale,
+                                    void* out, int dtype, int64_t B, int64_t T_, int64_t C, int act, const lasr_dropout* dropout,
+                                    void* stream) {
   LASR_CHECK_ARG(y && coef && out && (!y2 || coef2), "lasr_bn_act_fwd: null pointer");
   LASR_TRY(check_bn_shape("lasr_bn_act_fwd", dtype, B, T_, C));
+  const DropArgs da = make_drop(dropout);
   const int64_t rows = B * T_;
   const size_t shmem = (size_t)4 * C * sizeof(float);
   if (y2) {
-    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+    if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, true, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
                                              as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
-                                             (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, true, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
                                              as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
-                                             (int)T_, (int)C, act)); }
+                                             (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, false, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_act_fwd_kernel<T, true, false, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act, da); } }); }
   } else {
-    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+    if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, true, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
                                              as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
-                                             (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, true, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
                                              as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
-                                             (int)T_, (int)C, act)); }
+                                             (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, false, true>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_act_fwd_kernel<T, false, false, false>), dim3((unsigned)cdiv(rows, kFwdSlabRows)), dim3(256), shmem,
+                                             as_stream(stream), (const T*)y, coef, (const T*)y2, coef2, se_scale, (T*)out, (int)rows,
+                                             (int)T_, (int)C, act, da); } }); }
   }
   LASR_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
+}
+
+extern "C" int lasr_bn_act_fwd(const void* y, const float* coef, const void* y2, const float* coef2, const float* se_scale,
+                               void* out, int dtype, int64_t B, int64_t T_, int64_t C, int act, void* stream) {
+  return lasr_bn_act_fwd_drop(y, coef, y2, coef2, se_scale, out, dtype, B, T_, C, act, nullptr, stream);
 }
 
 extern "C" size_t lasr_bn_bwd_workspace_bytes(int64_t B, int64_t T_, int64_t C) {
@@ -623,6 +712,15 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
                                      const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
                                      float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return lasr_bn_act_bwd_stats_drop(dout, y, coef, saved, y2, coef2, saved2, se_scale, se_grad, sums, sums2, dtype, B, T_, C, act, nullptr,
+                                    workspace, workspace_bytes, stream);
+}
+
+extern "C" int lasr_bn_act_bwd_stats_drop(const void* dout, const void* y, const float* coef, const float* saved, const void* y2,
+                                          const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
+                                          float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
+                                          const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream) {
+  const DropArgs da = make_drop(dropout);
   LASR_CHECK_ARG(dout && y && coef && saved && workspace, "lasr_bn_act_bwd_stats: null pointer");
   LASR_CHECK_ARG(!y2 || (coef2 && saved2 && (sums2 || !sums)), "lasr_bn_act_bwd_stats: branch-2 pointers");
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_stats", dtype, B, T_, C));
@@ -636,17 +734,25 @@ extern "C" int lasr_bn_act_bwd_stats(const void* dout, const void* y, const floa
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_stats: C too large for LDS staging");
   float* partials = reinterpret_cast<float*>(workspace);
   if (y2) {
-    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+    if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act)); }
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); }
   } else {
-    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+    if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act)); }
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
+                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); }
   }
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
   if (!sums) return 0;   // partials stay in the workspace for lasr_bn_act_bwd_apply(sums = NULL)
@@ -661,6 +767,17 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
                                      const float* sums2, const int32_t* row_lens, void* dy, void* dy2, float* dgamma,
                                      float* dbeta, float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T_, int64_t C,
                                      int act, void* workspace, size_t workspace_bytes, void* stream) {
+  return lasr_bn_act_bwd_apply_drop(dout, y, coef, saved, gamma, y2, coef2, saved2, gamma2, se_scale, se_grad, sums, sums2, row_lens, dy, dy2,
+                                    dgamma, dbeta, dgamma2, dbeta2, dtype, B, T_, C, act, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const float* coef, const float* saved,
+                                          const float* gamma, const void* y2, const float* coef2, const float* saved2,
+                                          const float* gamma2, const float* se_scale, const float* se_grad, const float* sums,
+                                          const float* sums2, const int32_t* row_lens, void* dy, void* dy2, float* dgamma,
+                                          float* dbeta, float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T_, int64_t C,
+                                          int act, const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream) {
+  const DropArgs da = make_drop(dropout);
   LASR_CHECK_ARG(dout && y && coef && saved && gamma && dy && workspace, "lasr_bn_act_bwd_apply: null pointer");
   LASR_CHECK_ARG(!y2 || (coef2 && saved2 && gamma2 && (sums2 || !sums) && dy2), "lasr_bn_act_bwd_apply: branch-2 pointers");
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_apply", dtype, B, T_, C));
@@ -686,17 +803,25 @@ extern "C" int lasr_bn_act_bwd_apply(const void* dout, const void* y, const floa
   const size_t shmem = (size_t)10 * C * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_act_bwd_apply: C too large for the LDS coefficient table");
   if (y2) {
-    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+    if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
-                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
-                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); }
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, false, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, false, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } }); }
   } else {
-    if (se_scale) { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+    if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
-                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); } else { DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
-                                             (T*)dy2, (int)rows, (int)T_, (int)C, act)); }
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
+                                             (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } }); }
   }
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;

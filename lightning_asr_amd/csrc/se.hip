@@ -5,6 +5,7 @@
 // squeeze needs only per-(utterance, channel) sums of the pre-BN tensor: one extra read of y in
 // forward; the excite scale is folded into lasr_bn_act_fwd / lasr_bn_act_bwd_*.
 #include "common.h"
+#include "dropout.h"
 
 namespace lasr {
 
@@ -43,8 +44,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                             const float* __restrict__ coef, const T* __restrict__ y2,
                                                             const float* __restrict__ coef2, const float* __restrict__ se,
-                                                            int64_t Tt, int64_t C, int act, float* __restrict__ ds) {
+                                                            int64_t Tt, int64_t C, int act, float* __restrict__ ds, DropArgs drop) {
   __shared__ float s_red[16][65];
+  const bool dropping = drop.step != nullptr;            // workgroup-uniform
+  const unsigned long long drop_step = dropping ? *drop.step : 0ull;
   const int b = blockIdx.y;
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int64_t c = (int64_t)blockIdx.x * 64 + cl * 4;
@@ -62,14 +65,16 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
       Elem<T>::ld4(dout + base + t * C, dv);
       Elem<T>::ld4(y + base + t * C, yv);
       if (y2) Elem<T>::ld4(y2 + base + t * C, rv);
+      float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+      if (dropping) drop_scale<4>(drop, drop_step, (uint32_t)(base + t * C), dsc);   // same mask as bn_act_fwd (dropout.h)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float z1 = fmaf(yv[j], a1[j], b1[j]);
-        const float z = z1 * sc[j] + (y2 ? fmaf(rv[j], a2[j], b2[j]) : 0.f);
+        const float z = z1 * sc[j] * (y2 ? dsc[j] : 1.f) + (y2 ? fmaf(rv[j], a2[j], b2[j]) : 0.f);
         float g = 1.f;
         if (act == LASR_ACT_RELU) g = z > 0.f ? 1.f : 0.f;
         else if (act == LASR_ACT_SWISH) { const float s = 1.f / (1.f + __expf(-z)); g = s * (1.f + z * (1.f - s)); }
-        acc[j] = fmaf(dv[j] * g, z1, acc[j]);
+        acc[j] = fmaf(dv[j] * g * dsc[j], z1, acc[j]);       // d(out)/d(scale) = [act' . dropout scale] * BN output
       }
     }
   }
@@ -264,10 +269,31 @@ extern "C" size_t lasr_se_bwd_workspace_bytes(int64_t B, int64_t C) {
   return 2 * align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)B * (C / 8) * sizeof(float), 256);
 }
 
+extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
+                                const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T_,
+                                int64_t C, int act, const lasr_dropout* dropout, float* seg, float* dW1, float* dW2, void* workspace,
+                                size_t workspace_bytes, void* stream);
 extern "C" int lasr_se_bwd(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
                            const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T_,
                            int64_t C, int act, float* seg, float* dW1, float* dW2, void* workspace, size_t workspace_bytes,
                            void* stream) {
+  return lasr_se_bwd_drop(dout, y, coef, y2, coef2, scale, hidden, pooled, W1, W2, dtype, B, T_, C, act, nullptr, seg, dW1, dW2, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
+                                const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T_,
+                                int64_t C, int act, const lasr_dropout* dropout, float* seg, float* dW1, float* dW2, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  DropArgs da;
+  da.step = nullptr; da.seed = 0; da.unit = 0; da.thresh = 0; da.inv_keep = 1.f;
+  if (dropout && dropout->step && dropout->p > 0.f) {    // (same conversion as norm.hip's make_drop)
+    da.step = reinterpret_cast<const unsigned long long*>(dropout->step);
+    da.seed = dropout->seed; da.unit = dropout->unit;
+    const float p = dropout->p < 0.999f ? dropout->p : 0.999f;
+    da.thresh = (uint32_t)(p * 65536.f + 0.5f);
+    da.inv_keep = 1.f / (1.f - (float)da.thresh / 65536.f);
+  }
   LASR_CHECK_ARG(dout && y && coef && scale && hidden && pooled && W1 && W2 && seg && dW1 && dW2 && workspace, "lasr_se_bwd: null pointer");
   LASR_CHECK_ARG(!y2 || coef2, "lasr_se_bwd: residual coefficients");
   LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_se_bwd: bad dtype");
@@ -284,10 +310,10 @@ extern "C" int lasr_se_bwd(const void* dout, const void* y, const float* coef, c
   hipStream_t st = as_stream(stream);
   if (dtype == LASR_F32)
     hipLaunchKernelGGL(se_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)y, coef, (const float*)y2,
-                       coef2, scale, T_, C, act, ds);
+                       coef2, scale, T_, C, act, ds, da);
   else
     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, coef,
-                       (const bf16_t*)y2, coef2, scale, T_, C, act, ds);
+                       (const bf16_t*)y2, coef2, scale, T_, C, act, ds, da);
   LASR_LAUNCH_CHECK("se_bwd_reduce_kernel");
   hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + 5 * H) * sizeof(float), st, ds, scale, hidden, W1, W2,
                      (int)C, H, 1.0f / (float)T_, seg, d2, dh);

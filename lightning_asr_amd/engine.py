@@ -92,6 +92,23 @@ class NativeModel:
             sd[t.name] = self.counters[t.name].clone() if t.kind == 2 else self.view(t).detach().clone()
         return sd
 
+    def set_dropout(self, p: float, seed: int = 0) -> None:
+        """nn.Dropout(p) of every SeprationConv and of last_cnn2 (models/QuartNet.py:26,38,149) in training forwards: a
+        counter-based mask regenerated in forward and backward (csrc/dropout.h).  p = 0 switches it off."""
+        if not 0.0 <= p < 1.0:
+            raise ValueError("dropout probability has to be in [0, 1), got %r" % (p,))
+        if not hasattr(self, "drop_step"):
+            self.drop_step = torch.zeros(1, dtype=torch.int64, device=self.device)     # index of the current training forward
+        self.drop_p, self.drop_seed = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
+        call("lasr_model_set_dropout", self._h, float(p), self.drop_seed, _p(self.drop_step))
+
+    def dropout_mask(self, unit: int, n_elems: int) -> torch.Tensor:
+        """keep-mask (uint8, 1 = kept) unit `unit` drew in the LAST training forward, for verification against a CPU reference"""
+        d = _lib.Dropout(self.drop_step.data_ptr(), self.drop_seed, unit, self.drop_p)
+        out = torch.empty(n_elems, dtype=torch.uint8, device=self.device)
+        call("lasr_dropout_mask", C.byref(d), n_elems, _p(out), _stream())
+        return out
+
     def bump_counters(self, n: int = 1) -> None:
         """n training forwards ran without passing through forward() / loss_backward() (graph replays)"""
         self._bump += n

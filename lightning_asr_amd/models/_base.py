@@ -42,11 +42,11 @@ class MyModel2Base(nn.Module):
     def __init__(self, labels: Sequence[str], drop_rate: float = 0.0, mask: bool = False, in_c: int = 64,
                  act: str = "relu", dtype=torch.float32, device="cuda", seed: Optional[int] = None):
         super().__init__()
-        if drop_rate:
-            raise NotImplementedError("drop_rate != 0 is not implemented in the HIP plan (conf/conf.yaml uses 0.)")
         self.labels = labels
         self.native = NativeModel(self.variant, len(labels) + 1, mask=bool(mask), act=act, dtype=dtype, in_c=in_c, device=device)
         self.native.init_parameters(int(torch.initial_seed() & 0x7fffffff) if seed is None else seed)
+        if drop_rate:   # nn.Dropout(p=drop_rate) in every SeprationConv and in last_cnn2 (models/QuartNet.py:26,38,149)
+            self.native.set_dropout(float(drop_rate), int(torch.initial_seed()) if seed is None else seed)
         self.last_argmax = None
         self._plist: List[nn.Parameter] = []
         self._counters = {}

@@ -112,6 +112,7 @@ class Bf16OracleModel(R.OracleModel):
                  state: Optional[Dict[str, torch.Tensor]] = None, in_c: int = 64, dtype=torch.float64, emulate: bool = True):
         super().__init__(variant, n_class, mask, act, state, in_c)
         self.dtype, self.emulate = dtype, emulate
+        self.drop = None              # (keep mask (B, C, T) of the unit being run, 1/(1-p)): the GPU's own mask (run_unit)
         self.lean_head = False        # large-vocabulary head of csrc/ctc_lean.hip: the logits themselves are a bf16 tensor
         self.forced_mask: Optional[torch.Tensor] = None      # consumed by the next activation (run_unit)
         for k, v in self.state.items():
@@ -136,6 +137,13 @@ class Bf16OracleModel(R.OracleModel):
             m, self.forced_mask = self.forced_mask, None
             return _ActForcedMask.apply(z, m)
         return R.activation(z, self.act)
+
+    def _dropout(self, z):
+        """nn.Dropout at the end of SeprationConv / last_cnn2 (models/QuartNet.py:38,149) with a GIVEN mask"""
+        if self.drop is None:
+            return z
+        keep, inv = self.drop
+        return z * (keep.to(z.dtype) * inv)
 
     def st(self, x):
         return _Store.apply(x) if self.emulate else x
@@ -165,8 +173,8 @@ class Bf16OracleModel(R.OracleModel):
             g = torch.sigmoid(F.linear(F.relu(F.linear(pooled, s[prefix + ".se.fc.0.weight"])), s[prefix + ".se.fc.2.weight"]))
             z = z * g.unsqueeze(2)
         if not last:
-            z = self.st(self._act(z))
-        return z
+            return self.st(self._dropout(self._act(z)))
+        return self._dropout(z)          # residual units: the main branch is dropped BEFORE the add (it ends the SeprationConv)
 
     def _block(self, x, lens, name: str, k: int) -> torch.Tensor:
         p = "encoder." + name
@@ -181,7 +189,7 @@ class Bf16OracleModel(R.OracleModel):
         y = self.st(F.conv1d(x, self.sh(self.state["encoder.last_cnn2.0.weight"])))
         if self.keep_taps:
             self.taps["encoder.last_cnn2.y"] = y
-        return self.st(self._act(self._bn(y, "encoder.last_cnn2.1")))
+        return self.st(self._dropout(self._act(self._bn(y, "encoder.last_cnn2.1"))))
 
     def _lstm_dir(self, x_btc: torch.Tensor, sfx: str, valid: torch.Tensor) -> torch.Tensor:
         """one direction of the BiLSTM (models/QuartNetContext.py:186-199) -> (B, H, T).  The gate pre-activations' input
@@ -283,12 +291,13 @@ def _unit_params(model: R.OracleModel, prefixes) -> Dict[str, torch.Tensor]:
 
 
 def run_unit(model: Bf16OracleModel, unit: str, x_in: torch.Tensor, lens: torch.Tensor, dout: Optional[torch.Tensor],
-             act_mask: Optional[torch.Tensor] = None):
+             act_mask: Optional[torch.Tensor] = None, drop=None):
     """One unit of the plan from ITS OWN stored input: forward (training-mode BN) and, if ``dout`` is given, backward.
     act_mask: the GPU's `out > 0` (ReLU derivative; see _ActForcedMask).
     Returns {"u","y","y2","out","dx", "grads": {key: tensor}} (absent entries omitted)."""
     model.training, model.keep_taps, model.taps = True, True, {}
     model.forced_mask = act_mask
+    model.drop = drop                 # (keep mask (B, C, T), 1/(1-p)) or None
     params = _unit_params(model, _prefixes(model.variant, unit))
     for p in params.values():
         p.requires_grad_(True)
@@ -316,7 +325,7 @@ def run_unit(model: Bf16OracleModel, unit: str, x_in: torch.Tensor, lens: torch.
     for p in params.values():
         p.requires_grad_(False)
         p.grad = None
-    model.keep_taps, model.taps = False, {}
+    model.keep_taps, model.taps, model.drop = False, {}, None
     return res
 
 

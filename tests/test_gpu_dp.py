@@ -201,7 +201,7 @@ def test_device_lr_schedule_matches_host(dev):
     got = torch.cat(got).cpu().double()
     exp = torch.tensor(exp, dtype=torch.float64)
     assert ((got - exp).abs() / exp).max() < 2e-7          # f32 rounding of an f64 value
-    assert sc.cycle == 2                                   # the range covered two restarts
+    assert sc.cycle >= 2                                   # the range covered at least two restarts
 
 
 @pytest.mark.parametrize("variant,prefetch", [("plain", True), ("plain", False), ("context_se", True)])

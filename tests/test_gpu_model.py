@@ -188,3 +188,37 @@ def test_staged_backward_equals_single_call(dev, n_buckets):
     assert all(a[0] == b[1] for a, b in zip(seen[:-1], seen[1:]))  # contiguous, reverse layer order
     assert torch.equal(m1.grads, m2.grads)
     assert m2.unit_names()[0] == "first_cnn" and m2.unit_names()[-1] == "last_cnn2"
+
+
+def test_dropout_kwarg_trains_and_is_off_in_eval(dev):
+    """MyModel2(drop_rate=0.2) (models/QuartNet.py:265): training forwards differ from step to step and from the p = 0 model,
+    the same seed reproduces the same trajectory, eval mode ignores dropout."""
+    from lightning_asr_amd import ops
+    from lightning_asr_amd.models.QuartNet import MyModel2
+    labels = [c.strip() for c in open("data/labels.txt").readlines()]
+    x, tg, pct, tsz = golden_inputs()
+
+    def make(p):
+        torch.manual_seed(3)
+        mm = MyModel2(labels, drop_rate=p, mask=True, device=str(dev))
+        mm.load_state_dict(R.formula_state("plain", 28))
+        return mm
+    m0, m1, m2 = make(0.0), make(0.2), make(0.2)
+    m0.train(); m1.train(); m2.train()
+    a0 = m0(x.to(dev), pct.to(dev))
+    a1 = m1(x.to(dev), pct.to(dev))
+    a1.sum().backward()                          # backward through the masked plan runs (same masks: tests/test_gpu_units.py)
+    assert torch.isfinite(m1.native.grads).all() and m1.native.grads.abs().max() > 0
+    a1 = a1.detach()
+    a1b = m1(x.to(dev), pct.to(dev)).detach()
+    a2 = m2(x.to(dev), pct.to(dev))
+    assert torch.isfinite(a1).all()
+    assert (a1 - a0).abs().max() > 1e-3          # dropout changes the forward
+    assert (a1 - a1b).abs().max() > 1e-3         # a fresh mask per training forward (the device step counter moved)
+    assert torch.equal(a1, a2)                   # same seed, same step index: same masks
+    m0.eval(); m1.eval()
+    # (running statistics differ after the training forwards above: compare eval outputs of two p = 0.2 models instead)
+    m2.eval()
+    m1.load_state_dict(m2.state_dict())
+    e1, e2 = m1(x.to(dev), pct.to(dev)), m2(x.to(dev), pct.to(dev))
+    assert torch.equal(e1, e2)

@@ -63,7 +63,7 @@ def _ragged_batch(B, L_max, L_min, V, seed, chars_per_s=2.8):
 
 
 def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag, oracle_dtype=torch.float32, weights="random",
-                    lean=False):
+                    lean=False, drop_p=0.0):
     from lightning_asr_amd import ops
     from lightning_asr_amd.engine import NativeModel
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -72,6 +72,8 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     state = R.random_state(variant, n_class, 0) if weights == "random" else R.formula_state(variant, n_class)
     m = NativeModel(variant, n_class, mask=True, act="relu", dtype=dtype, device=dev)
     m.load_state_dict(state)
+    if drop_p:
+        m.set_dropout(drop_p, seed=12345)
     B = wave.shape[0]
     _, feats, frames, pct = ops.mel(wave.to(dev), None if sample_lens is None else sample_lens.to(dev), None, None, True, dtype,
                                     want_bft=False, want_btf=True)
@@ -128,7 +130,16 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         else:
             dout = grad_of(names[i + 1], co)
         out_gpu = _bct(m.tap(name))
-        r = E.run_unit(o, name, x_in, lens, dout, act_mask=out_gpu > 0)
+        drop = None
+        if drop_p:      # the mask this unit drew in the forward above, read back from the same counter-based generator
+            keep = m.dropout_mask(i, N * co).view(B, T, co).transpose(1, 2).cpu()
+            thresh = int(drop_p * 65536 + 0.5)
+            drop = (keep, 1.0 / (1.0 - thresh / 65536.0))
+            report.setdefault("drop_kept_frac", {})[name] = keep.float().mean().item()
+            assert abs(keep.float().mean().item() - (1 - drop_p)) < 5e-3, (name, keep.float().mean().item())
+        # ReLU mask from the GPU's output.  With dropout it is still right where it matters: a residual unit drops before the add
+        # (out > 0 <=> z > 0), first_cnn / last_cnn2 drop after the activation and a dropped element's gradient is zero anyway
+        r = E.run_unit(o, name, x_in, lens, dout, act_mask=out_gpu > 0, drop=drop)
         note(name, "act", "out", rel_l2(out_gpu, r["out"]))
         note(name, "act", "y", rel_l2(_bct(m.tap(name + ".y")), r["y"]))
         if "u" in r:
@@ -171,6 +182,11 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     # end to end: the emulated oracle's own whole forward from the same features (loss only: see the module docstring)
     o2 = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
                            emulate=(mode == "bf16"))
+    if drop_p:
+        report["worst"] = worst
+        with open("gpurun_out/unit_parity_%s.json" % tag, "w") as f:
+            json.dump(report, f, indent=1)
+        return report
     o2.training = True
     o2.lean_head = lean
     with torch.no_grad():
@@ -191,6 +207,18 @@ def test_units_f32_small_validates_harness(dev):
     lens = torch.tensor([32000, 32000, 28000, 16000], dtype=torch.int32)
     rep = run_units_check(dev, "context_se", 28, torch.float32, wave, lens, tg, tl, "f32_small_context_se", torch.float64, "formula")
     assert rep["worst"]["act"] < 2e-5
+
+
+@pytest.mark.parametrize("variant,dtype", [("context_se", torch.float32), ("plain", torch.bfloat16)])
+def test_units_with_dropout(dev, variant, dtype):
+    """drop_rate = 0.1 (models/QuartNet.py:26,38,149): every unit's forward and backward with the counter-based masks, against the
+    oracle applying the SAME masks (read back through lasr_dropout_mask); kept fraction ~ 1 - p in every layer."""
+    wave, tg, tl = R.synth_batch(6, 48000, 30, 27, seed=21)
+    lens = torch.tensor([48000, 48000, 40000, 30000, 48000, 20000], dtype=torch.int32)
+    f32 = dtype == torch.float32
+    rep = run_units_check(dev, variant, 28, dtype, wave, lens, tg, tl, "dropout_%s_%s" % (variant, "f32" if f32 else "bf16"),
+                          torch.float64 if f32 else torch.float32, "formula" if f32 else "random", drop_p=0.1)
+    assert len(rep["drop_kept_frac"]) == len(rep["units"]) - 1 - (1 if variant != "plain" else 0)     # every unit but the head (and the LSTM)
 
 
 def test_units_cfg2_plain_bf16_bs32_10s(dev):
