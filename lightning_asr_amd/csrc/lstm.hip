@@ -23,7 +23,8 @@ static constexpr int H = 40, G = 4 * H;  // hidden size, gate rows
 //   * the per-step global operands (gx; the saved gates, cell states and d(out) in backward) come through a register ring
 //     fetched kPre steps ahead: s_waitcnt vmcnt counts loads AND the step's stores in issue order, so a one-step prefetch
 //     made every step wait for the previous step's stores to retire (forward 352 us, backward 525 us for T' = 501).
-static constexpr int kLstmThreads = 192;   // 160 gate rows + 32 lanes that only keep the barriers company
+static constexpr int kLstmThreads = G;     // one thread per gate row (2.5 waves: the hardware masks the missing lanes, no `tid < G` branches -
+                                           // a divergent branch around the step's loads made the compiler drain vmcnt at its join)
 static constexpr int kPre = 8;
 
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -45,8 +46,7 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* _
                                                                   int64_t ldo, int64_t col0, float* __restrict__ saved) {
   __shared__ __attribute__((aligned(16))) float s_h[2][H];
   const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-  const bool live = tid < G;
-  const int u = live ? tid >> 2 : 0, q = tid & 3, j = q * H + u;
+  const int u = tid >> 2, q = tid & 3, j = q * H + u;
   const float* gx = (dir ? gx_r : gx_f) + (int64_t)b * Tt * G;
   const float* whh = dir ? whh_r : whh_f;
   int len = lens[b];
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* _
       if (s < len) {   // workgroup-uniform
         const int t = dir ? len - 1 - s : s;
         float a0 = ring[k] + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (s + kPre < len) ring[k] = gx[(int64_t)(dir ? len - 1 - (s + kPre) : s + kPre) * G + j];
+        {   // unconditional (clamped) refill: a load inside a branch is followed by s_waitcnt vmcnt(0) at the join - the whole
+            // HBM round trip on the step's critical path (0.65 us per step measured), which is what the ring is there to hide
+          const int sn = min(s + kPre, len - 1);
+          ring[k] = gx[(int64_t)(dir ? len - 1 - sn : sn) * G + j];
+        }
         const float* hp = s_h[s & 1];
 #pragma unroll
         for (int k4 = 0; k4 < H; k4 += 4) {
@@ -82,13 +86,15 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* _
           a0 = fmaf(w[k4], hv.x, a0); a1 = fmaf(w[k4 + 1], hv.y, a1); a2 = fmaf(w[k4 + 2], hv.z, a2); a3 = fmaf(w[k4 + 3], hv.w, a3);
         }
         const float pre = (a0 + a1) + (a2 + a3);
-        const float a = q == 2 ? tanh_fast(pre) : sigmoid_fast(pre);
+        // one exp + one rcp for either non-linearity, no divergent branch: tanh(x) = 2 sigmoid(2x) - 1
+        const float sg = sigmoid_fast(q == 2 ? 2.f * pre : pre);
+        const float a = q == 2 ? fmaf(2.f, sg, -1.f) : sg;
         float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
-        if (live) sv[j] = a;
+        sv[j] = a;
         const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
         c = fmaf(fg, c, ig * gg);
         const float h = og * tanh_fast(c);
-        if (live && q == 0) {
+        if (q == 0) {
           s_h[(s + 1) & 1][u] = h;
           sv[G + u] = c;
           sv[G + H + u] = h;
@@ -112,9 +118,8 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __res
   __shared__ __attribute__((aligned(16))) float s_hprev[H];
   __shared__ float s_part[4][H];
   const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-  const bool live = tid < G;
-  const int u = live ? tid >> 2 : 0, q = tid & 3, j = q * H + u;        // gate-gradient role
-  const int kk = live ? tid % H : 0, p = live ? tid / H : 0;            // dh_prev role: hidden index kk, rows 40p .. 40p+39
+  const int u = tid >> 2, q = tid & 3, j = q * H + u;                    // gate-gradient role
+  const int kk = tid % H, p = tid / H;                                  // dh_prev role: hidden index kk, rows 40p .. 40p+39
   const float* whh = dir ? whh_r : whh_f;
   float* dg = (dir ? dg_r : dg_f) + (int64_t)b * Tt * G;
   int len = lens[b];
@@ -131,11 +136,12 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __res
     const float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
     const float* sp = saved + (((int64_t)b * Tt + (s > 0 ? tp : t)) * 2 + dir) * (G + 2 * H);
     ga = sv[j];
-    float v;
-    if (q == 0) v = sv[G + u];
-    else if (q == 1) v = sp[G + u];
-    else if (q == 2) v = sp[G + H + u];
-    else v = Elem<T>::ld(dout + ((int64_t)b * Tt + t) * ldd + col0 + dir * H + u);
+    // lane q of the quad: c, c_prev, h_prev (one f32 load from a selected address) or d(out) (a T load): both issued by every
+    // lane, the right one selected - no divergent branch around a load
+    const float* src = q == 0 ? sv + G + u : (q == 1 ? sp + G + u : sp + G + H + u);
+    const float vs = *src;
+    const float vd = Elem<T>::ld(dout + ((int64_t)b * Tt + t) * ldd + col0 + dir * H + u);
+    const float v = q == 3 ? vd : vs;
     gb = (s == 0 && (q == 1 || q == 2)) ? 0.f : v;       // no previous step: c_prev = h_prev = 0
   };
   float ra[kPre], rb_[kPre];
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __res
       if (s >= 0) {   // workgroup-uniform
         const int t = dir ? len - 1 - s : s;
         const float a = ra[k], x = rb_[k];
-        if (s - kPre >= 0) fetch(s - kPre, ra[k], rb_[k]);
+        fetch(max(s - kPre, 0), ra[k], rb_[k]);          // unconditional (clamped): see the forward kernel
         const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
         const float c = quad_bcast<0>(x), cprev = quad_bcast<1>(x), hprev = quad_bcast<2>(x), dy = quad_bcast<3>(x);
         const float dh = dy + (s_part[0][u] + s_part[1][u]) + (s_part[2][u] + s_part[3][u]);    // + dh from step s+1
@@ -166,13 +172,11 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __res
         else if (q == 2) mine = dc * ig * (1.f - gg * gg);
         else mine = d_o;
         dc_next = dc * fg;
-        if (live) {                            // (s_part is rewritten only after the second barrier below: no hazard with the reads above)
-          s_dg[j] = mine;
-          dg[(int64_t)t * G + j] = mine;
-          if (q == 0) s_hprev[u] = hprev;
-        }
+        s_dg[j] = mine;                        // (s_part is rewritten only after the second barrier below: no hazard with the reads above)
+        dg[(int64_t)t * G + j] = mine;
+        if (q == 0) s_hprev[u] = hprev;
         lds_barrier();
-        if (live) {
+        {
           const float my = s_dg[tid];          // row tid of dW_hh
           float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __res
       }
     }
   }
-  if (live) {
+  {
     float* o = pwhh + (((int64_t)b * 2 + dir) * G + tid) * H;
 #pragma unroll
     for (int qq = 0; qq < H; ++qq) o[qq] = dw[qq];

@@ -179,11 +179,15 @@ class Trainer:
         import torch.distributed as dist
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            # nccl = RCCL, one GPU per rank.  LASR_DIST_BACKEND=gloo: rehearsal with several ranks sharing one GPU (RCCL refuses
+            # two ranks on a device) - the tests' world_size-2 fit
+            backend = os.environ.get("LASR_DIST_BACKEND", "nccl" if self.device.type == "cuda" else "gloo")
             if self.device.type == "cuda":
                 torch.cuda.set_device(self.device)
+            if backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.device)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group(backend)
         return dist
 
     def _batch(self, batch, dm, idx=0):
