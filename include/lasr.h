@@ -208,6 +208,17 @@ int lasr_se_bwd_drop(const void* dout, const void* y, const float* coef, const v
                      const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
                      int64_t C, int act, const lasr_dropout* dropout, float* seg, float* dW1, float* dW2, void* workspace,
                      size_t workspace_bytes, void* stream);
+/* Backward of a ContextSE unit's  out = act(BN(y) * se + BN_res(y2))  (models/QuartNetContextSE.py:19-23,54-57) in TWO passes over
+ * (dout, y, y2): per-utterance raw sums -> SE-scale gradient by algebra (gamma*sum(d*xhat) + beta*sum(d)) -> excite-MLP backward
+ * (seg_out [B][C], dW1, dW2) -> BN-backward constants -> dy, dy2, dgamma, dbeta.  ysum [B][C] = sum_t y from lasr_seqsum.
+ * Replaces lasr_se_bwd + lasr_bn_act_bwd_stats + lasr_bn_act_bwd_apply (three passes) for the SE units.                      */
+size_t lasr_bn_se_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
+int lasr_bn_se_bwd(const void* dout, const void* y, const float* coef, const float* saved, const float* gamma, const float* beta,
+                   const void* y2, const float* coef2, const float* saved2, const float* gamma2, const float* se_scale,
+                   const float* se_hidden, const float* se_pooled, const float* ysum, const float* W1, const float* W2,
+                   const int32_t* row_lens, void* dy, void* dy2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
+                   float* dW1, float* dW2, float* seg_out, int dtype, int64_t B, int64_t T, int64_t C, int act,
+                   const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream);
 int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const float* coef, const float* saved, const float* gamma,
                                const void* y2, const float* coef2, const float* saved2, const float* gamma2,
                                const float* se_scale, const float* se_grad, const float* sums, const float* sums2,

@@ -109,6 +109,8 @@ SIGNATURES = {
     "lasr_bn_act_bwd_stats_drop": (_i32, [_p] * 11 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "lasr_bn_act_bwd_apply_drop": (_i32, [_p] * 20 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "lasr_se_bwd_drop": (_i32, [_p] * 10 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _sz, _p]),
+    "lasr_bn_se_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lasr_bn_se_bwd": (_i32, [_p] * 26 + [_i32, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "lasr_model_set_dropout": (_i32, [_p, _f32, C.c_uint64, _p]),
     "lasr_lr_schedule_state_bytes": (_sz, []),
     "lasr_lr_schedule_init": (_i32, [_p, _sz, _i64, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _i64, _i64, _i64, _i64]),

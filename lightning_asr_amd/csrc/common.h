@@ -135,6 +135,10 @@ int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, flo
 // time (measured: 0.65 us per LSTM step with it).  Use only where the waves exchange data through LDS alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// se.hip: back through the excite MLP from ds = d(loss)/d(scale) (used by lasr_se_bwd and by norm.hip's fused SE + BN backward)
+int launch_se_mlp_bwd(const float* ds, const float* scale, const float* hidden, const float* pooled, const float* W1, const float* W2,
+                      int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, float* d2, float* dh, hipStream_t st);
+
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

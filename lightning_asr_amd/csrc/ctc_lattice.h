@@ -176,9 +176,11 @@ __device__ __forceinline__ void ctc_lattice(const float* __restrict__ lp, const 
           const int t = t_first + dt * step;
 #pragma unroll
           for (int i = 0; i < NS; ++i) em[i] = ring[u][i];
-          if (step + kPre < Tb) {
+          {   // unconditional refill from a clamped row: a load inside a branch is drained (s_waitcnt vmcnt(0)) at the branch's
+              // join, which put the memory round trip back on every step's critical path
+            const int tq = BETA ? max(t - kPre, 0) : min(t + kPre, Tb - 1);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) ring[u][i] = lp[(int64_t)(t + dt * kPre) * C + (cls4[i] >> 2)];
+            for (int i = 0; i < NS; ++i) ring[u][i] = lp[(int64_t)tq * C + (cls4[i] >> 2)];
           }
           advance();
         }

@@ -34,6 +34,13 @@ extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* co
                                 const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
                                 int64_t C, int act, const lasr_dropout* dropout, float* seg, float* dW1, float* dW2, void* workspace,
                                 size_t workspace_bytes, void* stream);
+extern "C" size_t lasr_bn_se_bwd_workspace_bytes(int64_t B, int64_t T, int64_t C);
+extern "C" int lasr_bn_se_bwd(const void* dout, const void* y, const float* coef, const float* saved, const float* gamma, const float* beta,
+                              const void* y2, const float* coef2, const float* saved2, const float* gamma2, const float* se_scale,
+                              const float* se_hidden, const float* se_pooled, const float* ysum, const float* W1, const float* W2,
+                              const int32_t* row_lens, void* dy, void* dy2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
+                              float* dW1, float* dW2, float* seg_out, int dtype, int64_t B, int64_t T, int64_t C, int act,
+                              const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int lasr_gemm_rowstat(const void* A, const void* B, const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                  float* row_stat, int32_t* row_arg, int* n_col_tiles, void* stream);
 extern "C" size_t lasr_gemm_rowstat_bytes(int64_t M, int64_t N);
@@ -250,6 +257,7 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
       u.o_se_scale = take(cur, (size_t)B * u.co * sizeof(float));
       u.o_se_grad = take(cur, (size_t)B * u.co * sizeof(float));
       scratch = std::max(scratch, lasr_se_bwd_workspace_bytes(B, u.co));
+      scratch = std::max(scratch, lasr_bn_se_bwd_workspace_bytes(B, p.T, u.co));
     }
     cmax = std::max<int64_t>(cmax, std::max(u.ci, u.co));
     scratch = std::max(scratch, 2 * lasr_gemm_workspace_bytes(N, u.co, 1, 1));
@@ -625,6 +633,18 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     const float* se_grad = u.has_se ? atf(ws, u.o_se_grad) : nullptr;
     const lasr_dropout drop = {m->drop_step, m->drop_seed, (uint32_t)ui, m->drop_p};   // the masks of this step's forward
     const lasr_dropout* dq = m->drop_p > 0.f ? &drop : nullptr;
+    static const bool se_unfused = getenv("LASR_SE_UNFUSED_BWD") != nullptr;    // A/B switch: the three-pass form
+    const bool se_fused = u.has_se && !se_unfused && !no_fuse();
+    if (se_fused) {
+      // SE units: statistics, SE-scale gradient, excite-MLP backward and BN apply in two passes over (dout, y, y2)
+      LASR_TRY(lasr_bn_se_bwd(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma, params + u.bn.beta,
+                              u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
+                              u.has_res ? atf(ws, u.o_saved2) : nullptr, u.has_res ? params + u.bn_res.gamma : nullptr, se_scale,
+                              atf(ws, u.o_se_hid), atf(ws, u.o_se_pool), atf(ws, u.o_se_sum), params + u.w_se1, params + u.w_se2,
+                              u.masked ? lens : nullptr, dy, dy2, grads + u.bn.gamma, grads + u.bn.beta,
+                              u.has_res ? grads + u.bn_res.gamma : nullptr, u.has_res ? grads + u.bn_res.beta : nullptr, grads + u.w_se1,
+                              grads + u.w_se2, atf(ws, u.o_se_grad), dt, B, T, u.co, act, dq, scratch, sb, stream));
+    } else {
     if (u.has_se)
       LASR_TRY(lasr_se_bwd_drop(dout, at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
                                 u.has_res ? atf(ws, u.o_coef2) : nullptr, se_scale, atf(ws, u.o_se_hid), atf(ws, u.o_se_pool), params + u.w_se1,
@@ -642,6 +662,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                                         se_grad, fsum, fsum2, u.masked ? lens : nullptr, dy, dy2,
                                         grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
                                         u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, dq, scratch, sb, stream));
+    }
     // weight gradients of the main and residual 1x1: dW[co][ci] = dy^T gin, dWr = dy2^T x  (one split-K launch)
     const void* gin = u.has_dw ? at(ws, u.o_u) : x_in;
     {

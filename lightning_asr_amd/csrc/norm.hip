@@ -321,14 +321,22 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restric
                                                               const T* __restrict__ y2, const float* __restrict__ coef2,
                                                               const float* __restrict__ saved2, const float* __restrict__ se,
                                                               const float* __restrict__ seg, float* __restrict__ partials,
-                                                              int rows, int Tt, int C, int act, DropArgs drop) {
+                                                              int rows, int Tt, int C, int act, DropArgs drop, int per_utt) {
   extern __shared__ __attribute__((aligned(16))) float s_part[];  // [row_lanes][4][C]
   constexpr int V = Vec<T>::kN;
   const unsigned long long drop_step = DROP ? *drop.step : 0ull;
   constexpr int RB = 2;                                           // rows in flight per thread
   const ColGeom g = col_geom<V>(C);
-  const int r0 = blockIdx.x * kRowsPerBlock;
-  const int r1 = min(r0 + kRowsPerBlock, rows);
+  // per_utt (fused SE + BN backward): slabs do not cross utterances - workgroup (b, slab) - and the sums are those of the gradient
+  // at the BN output WITHOUT the SE scale / pooled-path term (per-utterance factors, applied when the slabs are folded)
+  int r0 = blockIdx.x * kRowsPerBlock;
+  int r1 = min(r0 + kRowsPerBlock, rows);
+  if (per_utt) {
+    const int nslab = (Tt + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int ub = blockIdx.x / nslab, sl = blockIdx.x - ub * nslab;
+    r0 = ub * Tt + sl * kRowsPerBlock;
+    r1 = min(r0 + kRowsPerBlock, (ub + 1) * Tt);
+  }
   if (g.rl < g.row_lanes) {
     for (int cvi = g.cl; cvi < g.cv; cvi += g.col_threads) {
       const int c = cvi * V;
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restric
             const float z = zm + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
             const float d = dvi[j] * act_grad(z, act) * live * ((DROP && !HAS2) ? dsc[j] : 1.f);   // gradient at the pre-activation
             const float dmn = (DROP && HAS2) ? d * dsc[j] : d;                                       // ... reaching the main branch
-            const float d1 = fmaf(dmn, sej, (SE && seg) ? sgv[i][j] * live : 0.f);
+            const float d1 = per_utt ? dmn : fmaf(dmn, sej, (SE && seg) ? sgv[i][j] * live : 0.f);
             acc[0][j] += d1;
             acc[1][j] = fmaf(d1, (yvi[j] - m1[j]) * q1[j], acc[1][j]);
             if (HAS2) {
@@ -552,6 +560,55 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+
+// ---- fused SE + BN backward (ContextSE units): the per-(utterance, slab) raw sums of bn_bwd_stats(per_utt) ----------------
+// P[b][k][c], k = 0..3: sum_t dm, sum_t dm*xhat1 (main branch, dm = gradient reaching the BN output without SE factors),
+// sum_t d, sum_t d*xhat2 (residual branch).  The SE scale's gradient needs no pass of its own:
+//   ds[b][c] = sum_t dm * z1 = gamma_c * P1 + beta_c * P0      (z1 = BN output = gamma*xhat1 + beta)
+// (was se_bwd_reduce_kernel: a third read of dout, y, y2 - 29 us per unit at cfg4).   grid (ceil(C/256), B)
+__global__ __launch_bounds__(256) void se_stats_fold_kernel(const float* __restrict__ partials, int nslab, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ P, float* __restrict__ ds) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int sl = 0; sl < nslab; ++sl) {
+    const float* p = partials + ((size_t)(b * nslab + sl) * 4) * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += (double)p[(size_t)k * C];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) P[((size_t)b * 4 + k) * C + c] = (float)a[k];
+  ds[(size_t)b * C + c] = (float)((double)gamma[c] * a[1] + (double)beta[c] * a[0]);
+}
+
+// the BN-backward constants of the unit from the per-utterance sums, the SE scale and the pooled-path gradient seg:
+//   d1 = dm*se + seg  =>  s1 = sum_b (se*P0 + T*seg),  s2 = sum_b (se*P1 + seg*X1),  X1[b][c] = sum_t xhat1 = (sum_t y - T*mean)*rstd
+// grid ceil(C/64), block 64: one thread per channel, the batch walked with 8 loads in flight
+__global__ __launch_bounds__(64) void bn_bwd_table_se_kernel(const float* __restrict__ P, const float* __restrict__ se,
+                                                             const float* __restrict__ seg, const float* __restrict__ ysum, int B, int Tt,
+                                                             const float* __restrict__ coef, const float* __restrict__ saved,
+                                                             const float* __restrict__ gamma, const float* __restrict__ coef2,
+                                                             const float* __restrict__ saved2, const float* __restrict__ gamma2, float inv_n,
+                                                             int C, float* __restrict__ tab, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const float mean = saved[c], rstd = saved[C + c];
+  double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float p0 = P[((size_t)b * 4 + 0) * C + c], p1 = P[((size_t)b * 4 + 1) * C + c];
+    const float sc = se[(size_t)b * C + c], sg = seg[(size_t)b * C + c];
+    const float x1 = (ysum[(size_t)b * C + c] - (float)Tt * mean) * rstd;
+    s1 += (double)sc * p0 + (double)Tt * sg;
+    s2 += (double)sc * p1 + (double)sg * x1;
+    q1 += (double)P[((size_t)b * 4 + 2) * C + c];
+    q2 += (double)P[((size_t)b * 4 + 3) * C + c];
+  }
+  bn_bwd_table_channel(c, C, (float)s1, (float)s2, (float)q1, (float)q2, coef2 != nullptr, coef, saved, gamma, coef2, saved2, gamma2, inv_n, tab,
+                       dgamma, dbeta, dgamma2, dbeta2);
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -566,6 +623,11 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
                                           const float* sums2, const int32_t* row_lens, void* dy, void* dy2, float* dgamma,
                                           float* dbeta, float* dgamma2, float* dbeta2, int dtype, int64_t B, int64_t T_, int64_t C,
                                           int act, const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream);
+
+static int bn_bwd_stats_impl(const void* dout, const void* y, const float* coef, const float* saved, const void* y2,
+                             const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
+                             float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
+                             const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream, int per_utt);
 
 #define DISPATCH_DTYPE(dtype, ...)                      \
   if ((dtype) == LASR_F32) { using T = float; __VA_ARGS__; } \
@@ -720,13 +782,22 @@ extern "C" int lasr_bn_act_bwd_stats_drop(const void* dout, const void* y, const
                                           const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
                                           float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
                                           const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream) {
+  return bn_bwd_stats_impl(dout, y, coef, saved, y2, coef2, saved2, se_scale, se_grad, sums, sums2, dtype, B, T_, C, act, dropout, workspace,
+                           workspace_bytes, stream, 0);
+}
+
+// per_utt = 1: partials [B * ceil(T/32)][4][C] of the raw sums, one workgroup per (utterance, 32-frame slab) (see the kernel)
+static int bn_bwd_stats_impl(const void* dout, const void* y, const float* coef, const float* saved, const void* y2,
+                             const float* coef2, const float* saved2, const float* se_scale, const float* se_grad,
+                             float* sums, float* sums2, int dtype, int64_t B, int64_t T_, int64_t C, int act,
+                             const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream, int per_utt) {
   const DropArgs da = make_drop(dropout);
   LASR_CHECK_ARG(dout && y && coef && saved && workspace, "lasr_bn_act_bwd_stats: null pointer");
   LASR_CHECK_ARG(!y2 || (coef2 && saved2 && (sums2 || !sums)), "lasr_bn_act_bwd_stats: branch-2 pointers");
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_stats", dtype, B, T_, C));
   const int64_t rows = B * T_;
-  const int nblk = (int)cdiv(rows, kRowsPerBlock);
-  if (workspace_bytes < lasr_bn_bwd_workspace_bytes(B, T_, C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_stats: workspace");
+  const int nblk = per_utt ? (int)(B * cdiv(T_, kRowsPerBlock)) : (int)cdiv(rows, kRowsPerBlock);
+  if (workspace_bytes < (size_t)nblk * 4 * C * sizeof(float)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_stats: workspace");
   const int cv = (int)(C / (dtype == LASR_F32 ? 4 : 8));
   const int col_threads = cv < 256 ? cv : 256;
   const int row_lanes = 256 / col_threads;
@@ -736,23 +807,23 @@ extern "C" int lasr_bn_act_bwd_stats_drop(const void* dout, const void* y, const
   if (y2) {
     if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, true, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); }
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } }); }
   } else {
     if (se_scale) { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, true, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } }); } else { DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false, true>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } else { hipLaunchKernelGGL((bn_bwd_stats_kernel<T, false, false, false>), dim3(nblk), dim3(256), shmem, as_stream(stream),
                                              (const T*)dout, (const T*)y, coef, saved, (const T*)y2, coef2, saved2, se_scale, se_grad,
-                                             partials, (int)rows, (int)T_, (int)C, act, da); } }); }
+                                             partials, (int)rows, (int)T_, (int)C, act, da, per_utt); } }); }
   }
   LASR_LAUNCH_CHECK("bn_bwd_stats_kernel");
   if (!sums) return 0;   // partials stay in the workspace for lasr_bn_act_bwd_apply(sums = NULL)
@@ -822,6 +893,70 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
                                              (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, false, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
                                              (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, se_grad, row_lens, (T*)dy,
                                              (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } }); }
+  }
+  LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  return 0;
+}
+
+extern "C" size_t lasr_bn_se_bwd_workspace_bytes(int64_t B, int64_t T_, int64_t C) {
+  // raw partials [B*ceil(T/32)][4][C] | folded table [10][C] | P [B][4][C] | ds, d2 [B][C] | dh [B][C/8]
+  return align_up((size_t)B * cdiv(T_, kRowsPerBlock) * 4 * C * sizeof(float), 256) + align_up((size_t)10 * C * sizeof(float), 256) +
+         align_up((size_t)B * 4 * C * sizeof(float), 256) + 2 * align_up((size_t)B * C * sizeof(float), 256) +
+         align_up((size_t)B * (C / 8) * sizeof(float), 256);
+}
+
+// Backward of a ContextSE unit's  out = act(BN(y) * se + BN_res(y2))  (models/QuartNetContextSE.py:19-23,54-57) in TWO passes over
+// (dout, y, y2) instead of three: per-utterance raw sums -> ds (SE scale gradient) by algebra -> excite-MLP backward (seg, dW1,
+// dW2) -> BN-backward constants -> apply.  ysum [B][C] = sum_t y of the forward (lasr_seqsum).  seg_out [B][C] is also returned.
+extern "C" int lasr_bn_se_bwd(const void* dout, const void* y, const float* coef, const float* saved, const float* gamma, const float* beta,
+                              const void* y2, const float* coef2, const float* saved2, const float* gamma2, const float* se_scale,
+                              const float* se_hidden, const float* se_pooled, const float* ysum, const float* W1, const float* W2,
+                              const int32_t* row_lens, void* dy, void* dy2, float* dgamma, float* dbeta, float* dgamma2, float* dbeta2,
+                              float* dW1, float* dW2, float* seg_out, int dtype, int64_t B, int64_t T_, int64_t C, int act,
+                              const lasr_dropout* dropout, void* workspace, size_t workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(dout && y && coef && saved && gamma && beta && se_scale && se_hidden && se_pooled && ysum && W1 && W2 && dy && dgamma &&
+                     dbeta && dW1 && dW2 && seg_out && workspace, "lasr_bn_se_bwd: null pointer");
+  LASR_CHECK_ARG(!y2 || (coef2 && saved2 && gamma2 && dy2 && dgamma2 && dbeta2), "lasr_bn_se_bwd: branch-2 pointers");
+  LASR_TRY(check_bn_shape("lasr_bn_se_bwd", dtype, B, T_, C));
+  if (workspace_bytes < lasr_bn_se_bwd_workspace_bytes(B, T_, C)) return fail(LASR_E_WORKSPACE, "lasr_bn_se_bwd: workspace");
+  hipStream_t st = as_stream(stream);
+  const int nslab = (int)cdiv(T_, kRowsPerBlock);
+  char* w = reinterpret_cast<char*>(workspace);
+  float* partials = reinterpret_cast<float*>(w);
+  w += align_up((size_t)B * nslab * 4 * C * sizeof(float), 256);
+  float* tab = reinterpret_cast<float*>(w);
+  w += align_up((size_t)10 * C * sizeof(float), 256);
+  float* P = reinterpret_cast<float*>(w);
+  w += align_up((size_t)B * 4 * C * sizeof(float), 256);
+  float* ds = reinterpret_cast<float*>(w);
+  w += align_up((size_t)B * C * sizeof(float), 256);
+  float* d2 = reinterpret_cast<float*>(w);
+  w += align_up((size_t)B * C * sizeof(float), 256);
+  float* dh = reinterpret_cast<float*>(w);
+  // pass 1: raw per-(utterance, slab) sums (the SE scale enters the pre-activation z only)
+  LASR_TRY(bn_bwd_stats_impl(dout, y, coef, saved, y2, coef2, saved2, se_scale, nullptr, nullptr, nullptr, dtype, B, T_, C, act, dropout,
+                             partials, (size_t)B * nslab * 4 * C * sizeof(float), stream, 1));
+  hipLaunchKernelGGL(se_stats_fold_kernel, dim3((unsigned)cdiv(C, 256), (unsigned)B), dim3(256), 0, st, partials, nslab, (int)C, gamma, beta, P, ds);
+  LASR_LAUNCH_CHECK("se_stats_fold_kernel");
+  LASR_TRY(launch_se_mlp_bwd(ds, se_scale, se_hidden, se_pooled, W1, W2, B, T_, C, seg_out, dW1, dW2, d2, dh, st));
+  hipLaunchKernelGGL(bn_bwd_table_se_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, P, se_scale, seg_out, ysum, (int)B, (int)T_, coef,
+                     saved, gamma, y2 ? coef2 : nullptr, saved2, gamma2, 1.0f / (float)(B * T_), (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
+  LASR_LAUNCH_CHECK("bn_bwd_table_se_kernel");
+  // pass 2: dy = G*(d*se + seg) + Bc*y + Cc, dy2 = G2*d + ...
+  const DropArgs da = make_drop(dropout);
+  const int64_t rows = B * T_;
+  const size_t shmem = (size_t)10 * C * sizeof(float);
+  LASR_CHECK_SHAPE(shmem <= 64 * 1024, "lasr_bn_se_bwd: C too large for the LDS coefficient table");
+  if (y2) {
+    DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, seg_out, row_lens, (T*)dy, (T*)dy2, (int)rows, (int)T_, (int)C, act, da); }
+                            else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, seg_out, row_lens, (T*)dy, (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } });
+  } else {
+    DISPATCH_DTYPE(dtype, { if (da.step) { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true, true>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, seg_out, row_lens, (T*)dy, (T*)dy2, (int)rows, (int)T_, (int)C, act, da); }
+                            else { hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true, false>), dim3((unsigned)cdiv(rows, kSlabRows)), dim3(256), shmem, st,
+                                             (const T*)dout, (const T*)y, (const T*)y2, tab, se_scale, seg_out, row_lens, (T*)dy, (T*)dy2, (int)rows, (int)T_, (int)C, act, da); } });
   }
   LASR_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;

@@ -241,6 +241,23 @@ __global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__
 
 }  // namespace lasr
 
+namespace lasr {
+// back through the excite MLP from ds [B][C] = d(loss)/d(scale): seg [B][C], dW1, dW2; d2 [B][C] and dh [B][C/8] are scratch
+int launch_se_mlp_bwd(const float* ds, const float* scale, const float* hidden, const float* pooled, const float* W1, const float* W2,
+                      int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, float* d2, float* dh, hipStream_t st) {
+  const int H = (int)(C / 8);
+  if (C % 32 != 0 || H > 64 || (size_t)B * (64 + H) * sizeof(float) > 64 * 1024)
+    return fail(LASR_E_SHAPE, "lasr_se_bwd: C=%lld B=%lld (the kernels are built for C <= 512 in multiples of 32)", (long long)C, (long long)B);
+  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + 5 * H) * sizeof(float), st, ds, scale, hidden, W1, W2,
+                     (int)C, H, 1.0f / (float)T_, seg, d2, dh);
+  LASR_LAUNCH_CHECK("se_mlp_bwd_kernel");
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((unsigned)cdiv(C, 64), 2), dim3(256), (size_t)B * (64 + H) * sizeof(float), st, d2, hidden, dh,
+                     pooled, (int)B, (int)C, H, dW1, dW2);
+  LASR_LAUNCH_CHECK("se_wgrad_kernel");
+  return 0;
+}
+}  // namespace lasr
+
 using namespace lasr;
 
 extern "C" int lasr_seqsum(const void* x, int dtype, int64_t B, int64_t T_, int64_t C, float* sums, void* stream) {
@@ -299,9 +316,6 @@ extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* co
   LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_se_bwd: bad dtype");
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && T_ > 0 && C >= 8 && C % 8 == 0 && C <= 8192, "lasr_se_bwd: C=%lld", (long long)C);
   if (workspace_bytes < lasr_se_bwd_workspace_bytes(B, C)) return fail(LASR_E_WORKSPACE, "lasr_se_bwd: workspace");
-  const int H = (int)(C / 8);
-  LASR_CHECK_SHAPE(C % 32 == 0 && H <= 64 && (size_t)B * (64 + H) * sizeof(float) <= 64 * 1024,
-                   "lasr_se_bwd: C=%lld B=%lld (the kernels are built for C <= 512 in multiples of 32)", (long long)C, (long long)B);
   char* w = reinterpret_cast<char*>(workspace);
   float* ds = reinterpret_cast<float*>(w);
   float* d2 = reinterpret_cast<float*>(w + align_up((size_t)B * C * sizeof(float), 256));
@@ -315,11 +329,5 @@ extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* co
     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, coef,
                        (const bf16_t*)y2, coef2, scale, T_, C, act, ds, da);
   LASR_LAUNCH_CHECK("se_bwd_reduce_kernel");
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + 5 * H) * sizeof(float), st, ds, scale, hidden, W1, W2,
-                     (int)C, H, 1.0f / (float)T_, seg, d2, dh);
-  LASR_LAUNCH_CHECK("se_mlp_bwd_kernel");
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((unsigned)cdiv(C, 64), 2), dim3(256), (size_t)B * (64 + H) * sizeof(float), st, d2, hidden, dh,
-                     pooled, (int)B, (int)C, H, dW1, dW2);
-  LASR_LAUNCH_CHECK("se_wgrad_kernel");
-  return 0;
+  return launch_se_mlp_bwd(ds, scale, hidden, pooled, W1, W2, B, T_, C, seg, dW1, dW2, d2, dh, st);
 }

@@ -9,7 +9,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $root/gpurun_out/pmc_${cfg}_$c
-  LASR_BENCH_GRAPH=0 rocprofv3 --pmc $c -d $root/gpurun_out/pmc_${cfg}_$c -o pmc -- python3 $root/bench.py --config $cfg --dtype $dtype --no-cpu-baseline --steps 6 --warmup 3 \
+  LASR_BENCH_GRAPH=0 rocprofv3 --pmc $c --output-format csv -d $root/gpurun_out/pmc_${cfg}_$c -o pmc -- python3 $root/bench.py --config $cfg --dtype $dtype --no-cpu-baseline --steps 6 --warmup 3 \
       > $root/gpurun_out/pmc_${cfg}_$c.log 2>&1 || { tail -5 $root/gpurun_out/pmc_${cfg}_$c.log; exit 1; }
 done
 mkdir -p $root/profiles
