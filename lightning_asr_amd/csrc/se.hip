@@ -112,15 +112,16 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int h0 = wid * 4; h0 < H; h0 += 16) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int h0 = wid * 8; h0 < H; h0 += 32) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int c = lane; c < C; c += 64) {
       const float pv = s_p[c];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = fmaf(W1[(int64_t)min(h0 + u, H - 1) * C + c], pv, acc[u]);
+      for (int u = 0; u < 8; ++u) acc[u] = fmaf(W1[(int64_t)min(h0 + u, H - 1) * C + c], pv, acc[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const float v = fmaxf(wave_sum(acc[u]), 0.f);
       if (lane == 0 && h0 + u < H) {
         s_h[h0 + u] = v;
@@ -132,12 +133,12 @@ __global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict
   for (int c = threadIdx.x; c < C; c += 256) {
     const float4* w = reinterpret_cast<const float4*>(W2 + (int64_t)c * H);   // H % 4 == 0 (H = C/8, C % 32 == 0 checked on the host)
     float acc = 0.f;
-    for (int h4 = 0; h4 < H / 4; h4 += 8) {
-      float4 wv[8];
+    for (int h4 = 0; h4 < H / 4; h4 += 16) {
+      float4 wv[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = w[min(h4 + u, H / 4 - 1)];
+      for (int u = 0; u < 16; ++u) wv[u] = w[min(h4 + u, H / 4 - 1)];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         if (h4 + u < H / 4) {
           const float4 hv = *reinterpret_cast<const float4*>(s_h + 4 * (h4 + u));
           acc = fmaf(wv[u].x, hv.x, acc); acc = fmaf(wv[u].y, hv.y, acc); acc = fmaf(wv[u].z, hv.z, acc); acc = fmaf(wv[u].w, hv.w, acc);
@@ -175,12 +176,12 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     const int rows = C / 4, c0 = wid * rows;       // this wave's rows of W2
     float acc = 0.f;
     const int hl = min(lane, H - 1);
-    for (int r = 0; r < rows; r += 8) {
-      float wv[8];
+    for (int r = 0; r < rows; r += 32) {
+      float wv[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = W2[(int64_t)(c0 + min(r + u, rows - 1)) * H + hl];
+      for (int u = 0; u < 32; ++u) wv[u] = W2[(int64_t)(c0 + min(r + u, rows - 1)) * H + hl];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 32; ++u)
         if (r + u < rows) acc = fmaf(wv[u], s_d2[c0 + r + u], acc);
     }
     if (lane < H) s_part[wid * H + lane] = acc;
@@ -196,12 +197,12 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     float acc = 0.f;
-    for (int h = 0; h < H; h += 8) {
-      float wv[8];
+    for (int h = 0; h < H; h += 32) {
+      float wv[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) wv[u] = W1[(int64_t)min(h + u, H - 1) * C + c];
+      for (int u = 0; u < 32; ++u) wv[u] = W1[(int64_t)min(h + u, H - 1) * C + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 32; ++u)
         if (h + u < H) acc = fmaf(wv[u], s_dh[h + u], acc);
     }
     seg[(int64_t)b * C + c] = acc * inv_T;
