@@ -254,17 +254,33 @@ def main():
     use_graph = args.graph and world == 1           # (RCCL inside a captured graph is opt-in: LASR_GRAPH_DP=1)
     graphs = {}
     if use_graph:
-        # hipGraph replay: the ~200 launches of a step become one graph launch (host-enqueue time no longer bounds the step)
-        if cfg["ragged"]:                            # one graph per bucket shape, features + step of the same batch
-            for bk in batches:
-                key = (bk[0].shape[1], bk[2].shape[1])
-                if key not in graphs:
-                    graphs[key] = GraphedTrainStep(ts, B, key[0], key[1], ragged=True, prefetch=False)
-                    graphs[key].capture(bk[0], bk[1])
-        else:
-            g0 = GraphedTrainStep(ts, B, batches[0][0].shape[1], batches[0][2].shape[1], ragged=False, prefetch=args.prefetch)
-            g0.capture(batches[0][0])
-            graphs[None] = g0
+        # hipGraph replay: the ~200 launches of a step become one graph launch (host-enqueue time no longer bounds the step).  The
+        # graphs read the resident synthetic batches IN PLACE: nothing is copied per step.
+        try:
+            if cfg["ragged"]:                            # one graph per bucket, features + step of the same batch
+                for i, bk in enumerate(batches):
+                    graphs[i] = GraphedTrainStep(ts, B, bk[0].shape[1], bk[2].shape[1], ragged=True, prefetch=False,
+                                                 inputs=(bk[0], bk[1], bk[2], bk[3]))
+                    graphs[i].capture()
+            elif args.prefetch:                          # two graphs ping-pong the feature buffers: A trains on F0 and writes F1, B the reverse
+                F0, p0 = ts.features(batches[0][0])
+                F0, p0 = F0.clone(), p0.clone()
+                F1, p1 = torch.empty_like(F0), torch.empty_like(p0)
+                for i in range(2):
+                    cur, nxt = batches[i], batches[1 - i]
+                    graphs[i] = GraphedTrainStep(ts, B, cur[0].shape[1], cur[2].shape[1], prefetch=True, inputs=(nxt[0], None, cur[2], cur[3]),
+                                                 feats_in=(F0, p0) if i == 0 else (F1, p1), feats_out=(F1, p1) if i == 0 else (F0, p0))
+                    graphs[i].capture()
+                f, p_ = ts.features(batches[0][0])       # (the captures' warm-up passes ran through the buffers: re-prime step 0's features)
+                F0.copy_(f); p0.copy_(p_)
+            else:
+                for i, bk in enumerate(batches):
+                    graphs[i] = GraphedTrainStep(ts, B, bk[0].shape[1], bk[2].shape[1], prefetch=False, inputs=(bk[0], None, bk[2], bk[3]))
+                    graphs[i].capture()
+        except Exception as e:                           # a box whose runtime refuses the capture: eager launches, said in the JSON
+            sys.stderr.write("graph capture failed (%s): falling back to eager launches\n" % (e,))
+            use_graph, graphs = False, {}
+            torch.cuda.synchronize()
 
     def one_step(eager=False):
         i = step_no[0]
@@ -275,9 +291,7 @@ def main():
         if eager or not use_graph:
             return ts.step(w, t_, l_, sample_lens=sl, prefetch_wave=None if nxt is None else nxt[0],
                            prefetch_lens=None if nxt is None else nxt[1], want_logp=False)   # the training step reads loss + argmax only
-        if cfg["ragged"]:
-            return graphs[(w.shape[1], t_.shape[1])].step(w, t_, l_, lens=sl)
-        return graphs[None].step(nxt[0] if nxt is not None else w, t_, l_)
+        return graphs[i % len(batches)].replay()
 
     for _ in range(args.warmup):
         loss, *_ = one_step()

@@ -162,15 +162,20 @@ class NativeModel:
                     bound = 1.0 / (fan_in ** 0.5)
                     self.view(t).copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * bound).to(self.device))
 
-    def arm_prefetch(self, wave, sample_lens=None, dither=None, aug=None, normalize: bool = True):
+    def arm_prefetch(self, wave, sample_lens=None, dither=None, aug=None, normalize: bool = True, out=None):
         """The next loss_backward / loss_backward_staged call also computes the log-mel features of `wave` (B, L) - the NEXT
         step's batch - in the grid of its CTC lattice kernel (lasr_ctc_loss_mel).  Returns (feats (B, T, 64), pct (B)), valid
         once that call has been enqueued."""
         B, L = wave.shape
         T = int(self._lib.lasr_mel_num_frames(L))
-        feats = torch.empty(B, T, 64, dtype=self.act_dtype, device=self.device)
+        if out is not None:                       # caller-owned (feats (B, T, 64), pct (B)): e.g. the ping-pong pair of two captured graphs
+            feats, pct = out
+            if tuple(feats.shape) != (B, T, 64) or feats.dtype != self.act_dtype or not feats.is_contiguous():
+                raise ValueError("arm_prefetch(out=): feats must be a contiguous (%d, %d, 64) %s tensor" % (B, T, self.act_dtype))
+        else:
+            feats = torch.empty(B, T, 64, dtype=self.act_dtype, device=self.device)
+            pct = torch.empty(B, dtype=torch.float32, device=self.device)
         frames = torch.empty(B, dtype=torch.int32, device=self.device)
-        pct = torch.empty(B, dtype=torch.float32, device=self.device)
         nb = int(self._lib.lasr_mel_workspace_bytes(B, T))
         ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.device)
         call("lasr_model_set_prefetch", self._h, _p(wave), _p(sample_lens), _p(dither), _p(aug), B, L, int(normalize), _p(feats),

@@ -164,30 +164,42 @@ class GraphedTrainStep:
     being trained on.  prefetch=False: features and training step of the same ``wave`` in one replay (ragged buckets).
     Shapes are fixed at construction; one instance per (B, L, S)."""
 
-    def __init__(self, ts: TrainStep, B: int, L: int, S: int, ragged: bool = False, prefetch: bool = True, want_logp: bool = False):
+    def __init__(self, ts: TrainStep, B: int, L: int, S: int, ragged: bool = False, prefetch: bool = True, want_logp: bool = False,
+                 inputs=None, feats_in=None, feats_out=None):
+        """inputs = (wave, sample_lens | None, targets, tgt_lens): tensors already resident in HBM that the graph reads IN PLACE
+        (``replay()`` then takes no data and nothing is copied); otherwise static buffers are allocated and ``step()`` copies
+        into them.  feats_in / feats_out = (feats, pct) pairs: the features this graph trains on and where it writes the
+        prefetched ones - two graphs with the pairs swapped ping-pong without the end-of-step copy."""
         self.ts, self.prefetch, self.want_logp = ts, prefetch, want_logp
         dev = ts.model.device
-        self.wave = torch.zeros(B, L, dtype=torch.float32, device=dev)
-        self.lens = torch.full((B,), L, dtype=torch.int32, device=dev) if ragged else None
-        self.targets = torch.zeros(B, S, dtype=torch.int64, device=dev)
-        self.tgt_lens = torch.ones(B, dtype=torch.int32, device=dev)
+        self.bound = inputs is not None
+        if self.bound:
+            self.wave, self.lens, self.targets, self.tgt_lens = inputs
+        else:
+            self.wave = torch.zeros(B, L, dtype=torch.float32, device=dev)
+            self.lens = torch.full((B,), L, dtype=torch.int32, device=dev) if ragged else None
+            self.targets = torch.zeros(B, S, dtype=torch.int64, device=dev)
+            self.tgt_lens = torch.ones(B, dtype=torch.int32, device=dev)
         self.graph = None
         self.out = None
-        self.F_cur = self.pct_cur = None
+        self.F_cur, self.pct_cur = feats_in if feats_in is not None else (None, None)
+        self.feats_out = feats_out
 
     def _body(self):
         ts, m = self.ts, self.ts.model
         if self.prefetch:
-            nf, npct = m.arm_prefetch(self.wave, self.lens)
+            nf, npct = m.arm_prefetch(self.wave, self.lens, out=self.feats_out)
             out = ts.step_features(self.F_cur, self.pct_cur, self.targets, self.tgt_lens, want_logp=self.want_logp)
-            self.F_cur.copy_(nf)
-            self.pct_cur.copy_(npct)
+            if self.feats_out is None:
+                self.F_cur.copy_(nf)
+                self.pct_cur.copy_(npct)
             return out
         feats, pct = ts.features(self.wave, self.lens)
         return ts.step_features(feats, pct, self.targets, self.tgt_lens, want_logp=self.want_logp)
 
-    def capture(self, first_wave: torch.Tensor, first_lens: Optional[torch.Tensor] = None, warmup: int = 2) -> None:
-        """first_wave: the batch the first replay trains on (prefetch mode: its features are computed eagerly here).
+    def capture(self, first_wave: Optional[torch.Tensor] = None, first_lens: Optional[torch.Tensor] = None, warmup: int = 2) -> None:
+        """first_wave: the batch the first replay trains on (prefetch mode: its features are computed eagerly here; not needed
+        with bound inputs + feats_in, whose features the caller provides).
         The eager warm-up passes and the capture pass leave the training state (parameters, BN buffers, optimiser moments,
         schedule) exactly as it was: it is snapshotted before and restored after."""
         ts, m = self.ts, self.ts.model
@@ -199,10 +211,12 @@ class GraphedTrainStep:
         sched_sd = dict(ts.schedule.state_dict()) if ts.schedule is not None else None
         gstep, bump = ts.global_step, m._bump
         counters = {k: v.clone() for k, v in m.counters.items()}
-        self.wave.copy_(first_wave)                  # warm-up needs real audio (an all-zero wave has zero variance)
-        if self.lens is not None and first_lens is not None:
-            self.lens.copy_(first_lens)
-        if self.prefetch:
+        if not self.bound:
+            self.wave.copy_(first_wave)              # warm-up needs real audio (an all-zero wave has zero variance)
+            if self.lens is not None and first_lens is not None:
+                self.lens.copy_(first_lens)
+        f = p_ = None
+        if self.prefetch and self.F_cur is None:
             f, p_ = ts.features(first_wave, first_lens)
             self.F_cur, self.pct_cur = f.clone(), p_.clone()
         cur = torch.cuda.current_stream()
@@ -218,7 +232,7 @@ class GraphedTrainStep:
             self.out = self._body()
         for t, s_ in zip(dev_state, snap):
             t.copy_(s_)
-        if self.prefetch:
+        if f is not None:
             self.F_cur.copy_(f)
             self.pct_cur.copy_(p_)
         if sched_sd is not None:
@@ -230,11 +244,17 @@ class GraphedTrainStep:
 
     def step(self, wave: torch.Tensor, targets: torch.Tensor, tgt_lens: torch.Tensor, lens: Optional[torch.Tensor] = None):
         """copies the inputs into the graph's static buffers and replays; returns the static (loss, nll, logp, argmax) tensors"""
+        if self.bound:
+            raise RuntimeError("this graph reads its inputs in place (inputs=...): use replay()")
         self.wave.copy_(wave, non_blocking=True)
         if self.lens is not None and lens is not None:
             self.lens.copy_(lens, non_blocking=True)
         self.targets.copy_(targets, non_blocking=True)
         self.tgt_lens.copy_(tgt_lens, non_blocking=True)
+        return self.replay()
+
+    def replay(self):
+        """one training step from the captured graph (inputs as they are in the bound / static buffers right now)"""
         self.graph.replay()
         ts = self.ts
         ts.model.bump_counters(1)
