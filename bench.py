@@ -127,6 +127,14 @@ def cpu_baseline(cfg_name: str, V: int):
     else:
         B, warm, steps = 32, 3, 5
         wave, tg, tl = R.synth_batch(B, int(cfg["clip_s"] * SR), 100, V, 1234)
+        # the CPU front-end beside it: the oracle's torch.stft restatement per clip, one thread (a DataLoader worker of
+        # the reference, data_module.py:150-174) - not part of `value`, whose features are precomputed like the GPU's prefetch
+        torch.set_num_threads(1)
+        R.parse_wave(wave[0:1])
+        t0 = time.perf_counter()
+        for i in range(4):
+            R.parse_wave(wave[i:i + 1])
+        mel_s = (time.perf_counter() - t0) / 4
         feats = torch.stack([R.parse_wave(wave[i:i + 1])[0] for i in range(B)]).unsqueeze(1)
         pct = torch.ones(B)
         real_s = B * cfg["clip_s"]
@@ -167,7 +175,8 @@ def cpu_baseline(cfg_name: str, V: int):
     parts = [step() for _ in range(steps)]
     dt = sum(sum(p) for p in parts) / steps
     names = ("fwd", "ctc_fwd", "bwd", "novograd")
-    return {"value": real_s / dt, "unit": "audio-seconds/sec", "cores": best, "kind": "port",
+    out_extra = {"mel_s_per_clip_1thread": mel_s} if not cfg["ragged"] else {}
+    return {**out_extra, "value": real_s / dt, "unit": "audio-seconds/sec", "cores": best, "kind": "port",
             "sample": "%s, %d warm-up + %d timed steps of fwd+CTC+bwd+NovoGrad, f32, features precomputed" % (sample, warm, steps),
             "cpu_model": cpu_model(), "cores_available": avail, "s_per_step": dt,
             "split_s": {k: sum(p[i] for p in parts) / steps for i, k in enumerate(names)},

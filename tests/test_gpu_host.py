@@ -165,3 +165,23 @@ def test_asr_translator_on_reference_style_checkpoint(dev, tmp_path):
         f.write(json.dumps({"audio_filepath": str(wp), "duration": 2.0, "text": "a b"}) + "\n")
     outs = tr.evalute_manifest(str(man), batch_size=1)
     assert len(outs) == 1
+
+
+def test_cfg1_plumbing_4x10s_one_step(dev, tmp_path):
+    """BASELINE config 1 ("asr13x1, 4 x 10 s synthetic 16 kHz clips, labels.txt vocab, train.py 1 step"): the reference runs it on
+    the CPU; this build has no CPU path by contract, so the same plumbing - manifest -> wav decode -> on-device features ->
+    LightingModule.training_step -> NovoGrad -> checkpoint - runs its one step on the GPU."""
+    data = tmp_path / "cfg1"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_data.py"), "--out", str(data), "--n-train", "4",
+                    "--n-dev", "4", "--seconds", "10.0"], check=True)
+    from lightning_asr_amd.train import main
+    out = tmp_path / "run_cfg1"
+    tr = main(["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
+               "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % os.path.join(ROOT, "data", "labels.txt"),
+               "train.train_batch_size=4", "train.dev_batch_size=4", "train.total_epoch=1", "train.max_steps=1",
+               "output_dir=%s" % out])
+    assert tr.global_step == 1
+    rec = tr.history[-1]
+    assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0
+    ckpt = torch.load(out / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
+    assert ckpt["global_step"] == 1 and len(ckpt["state_dict"]) == 184
