@@ -66,7 +66,9 @@ def test_training_step_matches_oracle_f32(dev):
         assert p.grad is not None and p.grad.shape == g.shape
     worst = max(((p.grad.cpu().double() - g.double()).norm() / (g.double().norm() + 1e-30)).item()
                 for p, g in zip(m.parameters(), grads_ref))
-    assert worst < 3e-3, worst
+    # end-to-end f32 bound = the f32 oracle's own spread across thread counts on one host (6.8e-3, see
+    # tests/test_gpu_model.py::test_plain_loss_backward_matches_golden_f32); the tight bound is per unit (test_gpu_units.py)
+    assert worst < 1e-2, worst
     opt.step()
     worst = max(((p.detach().cpu().double() - q.detach().double()).norm() / (q.detach().double().norm() + 1e-30)).item()
                 for p, q in zip(m.parameters(), om.parameters()))
@@ -179,7 +181,9 @@ def test_cfg1_plumbing_4x10s_one_step(dev, tmp_path):
     tr = main(["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
                "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % os.path.join(ROOT, "data", "labels.txt"),
                "train.train_batch_size=4", "train.dev_batch_size=4", "train.total_epoch=1", "train.max_steps=1",
-               "output_dir=%s" % out])
+               # the reference hard-codes warmup_steps=1000 (train.py:55) and its scheduler asserts warmup < epochs * batches,
+               # so a one-batch run needs the warmup override this build's config adds
+               "train.warmup_steps=0", "output_dir=%s" % out])
     assert tr.global_step == 1
     rec = tr.history[-1]
     assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0

@@ -60,13 +60,18 @@ def test_plain_loss_backward_matches_golden_f32(dev):
     assert abs(loss.item() - gold["losses"][0]) / gold["losses"][0] < 1e-4
     norms = np.array([m.view(t, m.grads).norm().item() for t in m.param_infos()])
     assert np.abs(norms / gold["grad_norms"] - 1).max() < 5e-3
-    # full gradients against the oracle (bit-identical to the reference for this variant)
-    o = R.OracleModel("plain", 28, mask=True, state=R.formula_state("plain", 28))
-    st = R.NovogradState(len(o.parameters()))
-    _, grads = R.train_step(o, st, x, tg, pct, tsz, 1e-2, 1e-3)
+    # full gradients against the oracle run in f64.  The f32 oracle is NOT a stable yardstick for this check: through the
+    # 24-block BN stack one activation landing on the other side of zero moves every upstream gradient by a few 1e-3, and
+    # the CPU's own f32 result does that as a function of torch's thread count (profiles/r02_golden_f32_threads.txt:
+    # same host, 128 vs <=32 threads, 6.8e-3 apart; f32 vs f64 oracle in the dev container 3.2e-3).  So the end-to-end
+    # bound is that noise level; the tight f32 bound (2e-5 per unit, teacher-forced) is tests/test_gpu_units.py.
+    from oracle import ref_bf16 as E
+    o = E.Bf16OracleModel("plain", 28, mask=True, state=R.formula_state("plain", 28), dtype=torch.float64, emulate=False)
+    _, _, _, grads = E.loss_and_grads(o, x, tg, pct, tsz)
     rels = {t.name: rel_l2(m.view(t, m.grads), g) for t, g in zip(m.param_infos(), grads)}
     worst = max(rels.values())
-    assert worst < 2e-3, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    print("worst grad rel-L2 vs f64 oracle %.3e" % worst)
+    assert worst < 1e-2, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
     # running statistics after one training forward
     for t in m.tensors:
         if t.kind == 1:
