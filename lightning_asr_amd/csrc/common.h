@@ -135,9 +135,47 @@ int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, flo
 // time (measured: 0.65 us per LSTM step with it).  Use only where the waves exchange data through LDS alone.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// se.hip: back through the excite MLP from ds = d(loss)/d(scale) (used by lasr_se_bwd and by norm.hip's fused SE + BN backward)
-int launch_se_mlp_bwd(const float* ds, const float* scale, const float* hidden, const float* pooled, const float* W1, const float* W2,
-                      int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, float* d2, float* dh, hipStream_t st);
+// se.hip: back through the excite MLP of a ContextSE unit, for the whole batch, in two launches (se_bwd_hidden_kernel,
+// se_bwd_pool_kernel).  Either from ds = d(loss)/d(scale) [B][C] (lasr_se_bwd), or - norm.hip's fused SE + BN backward - from the
+// per-(utterance, slab) raw sums of bn_bwd_stats(per_utt), in which case the second launch also folds the BN-backward constants
+// `tab` and the BN parameter gradients.  work: se_bwd_work_bytes(B, C).
+struct SeBwdBn {            // the BN side of the fused form (partials == nullptr: not used)
+  const float* partials; int nslab;                      // [B * nslab][4][C] raw sums
+  const float* gamma; const float* beta; const float* ysum;
+  const float* coef; const float* saved; const float* coef2; const float* saved2; const float* gamma2;
+  float inv_n; float* tab; float* dgamma; float* dbeta; float* dgamma2; float* dbeta2;
+};
+size_t se_bwd_work_bytes(int64_t B, int64_t C);
+int launch_se_bwd(const float* ds, const SeBwdBn* bn, const float* scale, const float* hidden, const float* pooled, const float* W1,
+                  const float* W2, int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, void* work, hipStream_t st);
+
+// pass 2a: per-channel constants of the backward apply, folded once by C threads:
+//   dy = G*d1 + Bc*y + Cc   with G = gamma*rstd, Bc = -G*rstd*s2/n, Cc = G*(mean*rstd*s2/n - s1/n)
+// tab = [a1 | b1 | G1 | B1 | C1 | a2 | b2 | G2 | B2 | C2][C]; also emits dgamma = s2, dbeta = s1.
+__device__ __forceinline__ void bn_bwd_table_channel(int c, int C, float s1, float s2, float s1b, float s2b, bool has2,
+                                                     const float* __restrict__ coef, const float* __restrict__ saved,
+                                                     const float* __restrict__ gamma, const float* __restrict__ coef2,
+                                                     const float* __restrict__ saved2, const float* __restrict__ gamma2, float inv_n,
+                                                     float* __restrict__ tab, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
+  {
+    const float q = saved[C + c], w = s2 * inv_n, G = gamma[c] * q;
+    tab[c] = coef[c]; tab[C + c] = coef[C + c]; tab[2 * C + c] = G; tab[3 * C + c] = -G * q * w;
+    tab[4 * C + c] = G * (saved[c] * q * w - s1 * inv_n);
+    if (dbeta) dbeta[c] = s1;
+    if (dgamma) dgamma[c] = s2;
+  }
+  if (has2) {
+    const float q = saved2[C + c], w = s2b * inv_n, G = gamma2[c] * q;
+    tab[5 * C + c] = coef2[c]; tab[6 * C + c] = coef2[C + c]; tab[7 * C + c] = G; tab[8 * C + c] = -G * q * w;
+    tab[9 * C + c] = G * (saved2[c] * q * w - s1b * inv_n);
+    if (dbeta2) dbeta2[c] = s1b;
+    if (dgamma2) dgamma2[c] = s2b;
+  } else {
+    for (int k = 5; k < 10; ++k) tab[k * C + c] = 0.f;
+  }
+}
+
 
 // ---- wave / block reductions (wave = 64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

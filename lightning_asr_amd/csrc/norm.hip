@@ -410,33 +410,7 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_stats_kernel(const T* __restric
   }
 }
 
-// pass 2a: per-channel constants of the backward apply, folded once by C threads:
-//   dy = G*d1 + Bc*y + Cc   with G = gamma*rstd, Bc = -G*rstd*s2/n, Cc = G*(mean*rstd*s2/n - s1/n)
-// tab = [a1 | b1 | G1 | B1 | C1 | a2 | b2 | G2 | B2 | C2][C]; also emits dgamma = s2, dbeta = s1.
-__device__ __forceinline__ void bn_bwd_table_channel(int c, int C, float s1, float s2, float s1b, float s2b, bool has2,
-                                                     const float* __restrict__ coef, const float* __restrict__ saved,
-                                                     const float* __restrict__ gamma, const float* __restrict__ coef2,
-                                                     const float* __restrict__ saved2, const float* __restrict__ gamma2, float inv_n,
-                                                     float* __restrict__ tab, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
-  {
-    const float q = saved[C + c], w = s2 * inv_n, G = gamma[c] * q;
-    tab[c] = coef[c]; tab[C + c] = coef[C + c]; tab[2 * C + c] = G; tab[3 * C + c] = -G * q * w;
-    tab[4 * C + c] = G * (saved[c] * q * w - s1 * inv_n);
-    if (dbeta) dbeta[c] = s1;
-    if (dgamma) dgamma[c] = s2;
-  }
-  if (has2) {
-    const float q = saved2[C + c], w = s2b * inv_n, G = gamma2[c] * q;
-    tab[5 * C + c] = coef2[c]; tab[6 * C + c] = coef2[C + c]; tab[7 * C + c] = G; tab[8 * C + c] = -G * q * w;
-    tab[9 * C + c] = G * (saved2[c] * q * w - s1b * inv_n);
-    if (dbeta2) dbeta2[c] = s1b;
-    if (dgamma2) dgamma2[c] = s2b;
-  } else {
-    for (int k = 5; k < 10; ++k) tab[k * C + c] = 0.f;
-  }
-}
-
+// (pass 2a's per-channel fold, bn_bwd_table_channel, lives in common.h: se.hip's excite-backward kernel ends in it too)
 __global__ __launch_bounds__(256) void bn_bwd_table_kernel(const float* __restrict__ coef, const float* __restrict__ saved,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            const float* __restrict__ coef2, const float* __restrict__ saved2,
@@ -560,54 +534,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-
-// ---- fused SE + BN backward (ContextSE units): the per-(utterance, slab) raw sums of bn_bwd_stats(per_utt) ----------------
-// P[b][k][c], k = 0..3: sum_t dm, sum_t dm*xhat1 (main branch, dm = gradient reaching the BN output without SE factors),
-// sum_t d, sum_t d*xhat2 (residual branch).  The SE scale's gradient needs no pass of its own:
-//   ds[b][c] = sum_t dm * z1 = gamma_c * P1 + beta_c * P0      (z1 = BN output = gamma*xhat1 + beta)
-// (was se_bwd_reduce_kernel: a third read of dout, y, y2 - 29 us per unit at cfg4).   grid (ceil(C/256), B)
-__global__ __launch_bounds__(256) void se_stats_fold_kernel(const float* __restrict__ partials, int nslab, int C,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ P, float* __restrict__ ds) {
-  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (c >= C) return;
-  double a[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int sl = 0; sl < nslab; ++sl) {
-    const float* p = partials + ((size_t)(b * nslab + sl) * 4) * C + c;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) a[k] += (double)p[(size_t)k * C];
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) P[((size_t)b * 4 + k) * C + c] = (float)a[k];
-  ds[(size_t)b * C + c] = (float)((double)gamma[c] * a[1] + (double)beta[c] * a[0]);
-}
-
-// the BN-backward constants of the unit from the per-utterance sums, the SE scale and the pooled-path gradient seg:
-//   d1 = dm*se + seg  =>  s1 = sum_b (se*P0 + T*seg),  s2 = sum_b (se*P1 + seg*X1),  X1[b][c] = sum_t xhat1 = (sum_t y - T*mean)*rstd
-// grid ceil(C/64), block 64: one thread per channel, the batch walked with 8 loads in flight
-__global__ __launch_bounds__(64) void bn_bwd_table_se_kernel(const float* __restrict__ P, const float* __restrict__ se,
-                                                             const float* __restrict__ seg, const float* __restrict__ ysum, int B, int Tt,
-                                                             const float* __restrict__ coef, const float* __restrict__ saved,
-                                                             const float* __restrict__ gamma, const float* __restrict__ coef2,
-                                                             const float* __restrict__ saved2, const float* __restrict__ gamma2, float inv_n,
-                                                             int C, float* __restrict__ tab, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  const float mean = saved[c], rstd = saved[C + c];
-  double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float p0 = P[((size_t)b * 4 + 0) * C + c], p1 = P[((size_t)b * 4 + 1) * C + c];
-    const float sc = se[(size_t)b * C + c], sg = seg[(size_t)b * C + c];
-    const float x1 = (ysum[(size_t)b * C + c] - (float)Tt * mean) * rstd;
-    s1 += (double)sc * p0 + (double)Tt * sg;
-    s2 += (double)sc * p1 + (double)sg * x1;
-    q1 += (double)P[((size_t)b * 4 + 2) * C + c];
-    q2 += (double)P[((size_t)b * 4 + 3) * C + c];
-  }
-  bn_bwd_table_channel(c, C, (float)s1, (float)s2, (float)q1, (float)q2, coef2 != nullptr, coef, saved, gamma, coef2, saved2, gamma2, inv_n, tab,
-                       dgamma, dbeta, dgamma2, dbeta2);
-}
 
 }  // namespace lasr
 
@@ -899,10 +825,9 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
 }
 
 extern "C" size_t lasr_bn_se_bwd_workspace_bytes(int64_t B, int64_t T_, int64_t C) {
-  // raw partials [B*ceil(T/32)][4][C] | folded table [10][C] | P [B][4][C] | ds, d2 [B][C] | dh [B][C/8]
+  // raw partials [B*ceil(T/32)][4][C] | folded table [10][C] | the excite backward's hand-over (se_bwd_work_bytes)
   return align_up((size_t)B * cdiv(T_, kRowsPerBlock) * 4 * C * sizeof(float), 256) + align_up((size_t)10 * C * sizeof(float), 256) +
-         align_up((size_t)B * 4 * C * sizeof(float), 256) + 2 * align_up((size_t)B * C * sizeof(float), 256) +
-         align_up((size_t)B * (C / 8) * sizeof(float), 256);
+         se_bwd_work_bytes(B, C);
 }
 
 // Backward of a ContextSE unit's  out = act(BN(y) * se + BN_res(y2))  (models/QuartNetContextSE.py:19-23,54-57) in TWO passes over
@@ -926,22 +851,16 @@ extern "C" int lasr_bn_se_bwd(const void* dout, const void* y, const float* coef
   w += align_up((size_t)B * nslab * 4 * C * sizeof(float), 256);
   float* tab = reinterpret_cast<float*>(w);
   w += align_up((size_t)10 * C * sizeof(float), 256);
-  float* P = reinterpret_cast<float*>(w);
-  w += align_up((size_t)B * 4 * C * sizeof(float), 256);
-  float* ds = reinterpret_cast<float*>(w);
-  w += align_up((size_t)B * C * sizeof(float), 256);
-  float* d2 = reinterpret_cast<float*>(w);
-  w += align_up((size_t)B * C * sizeof(float), 256);
-  float* dh = reinterpret_cast<float*>(w);
+  void* se_work = w;
   // pass 1: raw per-(utterance, slab) sums (the SE scale enters the pre-activation z only)
   LASR_TRY(bn_bwd_stats_impl(dout, y, coef, saved, y2, coef2, saved2, se_scale, nullptr, nullptr, nullptr, dtype, B, T_, C, act, dropout,
                              partials, (size_t)B * nslab * 4 * C * sizeof(float), stream, 1));
-  hipLaunchKernelGGL(se_stats_fold_kernel, dim3((unsigned)cdiv(C, 256), (unsigned)B), dim3(256), 0, st, partials, nslab, (int)C, gamma, beta, P, ds);
-  LASR_LAUNCH_CHECK("se_stats_fold_kernel");
-  LASR_TRY(launch_se_mlp_bwd(ds, se_scale, se_hidden, se_pooled, W1, W2, B, T_, C, seg_out, dW1, dW2, d2, dh, st));
-  hipLaunchKernelGGL(bn_bwd_table_se_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, P, se_scale, seg_out, ysum, (int)B, (int)T_, coef,
-                     saved, gamma, y2 ? coef2 : nullptr, saved2, gamma2, 1.0f / (float)(B * T_), (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
-  LASR_LAUNCH_CHECK("bn_bwd_table_se_kernel");
+  // fold -> ds -> excite-MLP backward (seg, dW1, dW2) -> BN-backward constants: two launches (se.hip)
+  SeBwdBn bn;
+  bn.partials = partials; bn.nslab = nslab; bn.gamma = gamma; bn.beta = beta; bn.ysum = ysum;
+  bn.coef = coef; bn.saved = saved; bn.coef2 = y2 ? coef2 : nullptr; bn.saved2 = saved2; bn.gamma2 = gamma2;
+  bn.inv_n = 1.0f / (float)(B * T_); bn.tab = tab; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.dgamma2 = dgamma2; bn.dbeta2 = dbeta2;
+  LASR_TRY(launch_se_bwd(nullptr, &bn, se_scale, se_hidden, se_pooled, W1, W2, B, T_, C, seg_out, dW1, dW2, se_work, st));
   // pass 2: dy = G*(d*se + seg) + Bc*y + Cc, dy2 = G2*d + ...
   const DropArgs da = make_drop(dropout);
   const int64_t rows = B * T_;

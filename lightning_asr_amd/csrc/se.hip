@@ -39,6 +39,46 @@ __global__ __launch_bounds__(256) void seqsum_kernel(const T* __restrict__ x, in
   }
 }
 
+// The same sums with 16-byte loads (C a multiple of the vector width, 16-byte rows): block 256 = 64/V column threads x row lanes,
+// eight row loads in flight per thread, clamped rows (no branch around a load).  The first form above issues one 8-byte load per
+// thread and trip: 11.5 us for the 16 MB of a 512-channel unit at cfg4.
+template <typename T>
+__global__ __launch_bounds__(256) void seqsum_vec_kernel(const T* __restrict__ x, int Tt, int C, float* __restrict__ sums) {
+  constexpr int V = Vec<T>::kN, CT = 64 / V, RL = 256 / CT, RB = 8;
+  __shared__ float s_red[RL][65];
+  const int b = blockIdx.y, cl = threadIdx.x % CT, rl = threadIdx.x / CT;
+  const int c = blockIdx.x * 64 + cl * V;
+  const T* xb = x + (size_t)b * Tt * C + min(c, C - V);
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  for (int t0 = rl; t0 < Tt; t0 += RB * RL) {
+    uint4 r[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) r[i] = Vec<T>::raw(xb + (size_t)min(t0 + i * RL, Tt - 1) * C);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      float v[V];
+      Vec<T>::unpack(r[i], v);
+      const bool live = t0 + i * RL < Tt;
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += live ? v[j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) s_red[rl][cl * V + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < RL; ++r) s += s_red[r][threadIdx.x];
+      sums[(size_t)b * C + cc] = s;
+    }
+  }
+}
+
 // ds[b][c] = sum_t dout * act'(z) * (a1*y + b1),  z = (a1*y+b1)*se + (a2*y2+b2): gradient w.r.t. the scale
 template <typename T>
 __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y,
@@ -92,169 +132,244 @@ __global__ __launch_bounds__(256) void se_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// One workgroup per utterance.  pooled = a*sums/T + b ; hidden = relu(W1 pooled) ; scale = sigmoid(W2 hidden).
-// The two mat-vecs are latency-, not bandwidth-work (256 KB of weights per utterance out of L2): what matters is how many
-// loads are in flight.  W1 [H][C]: one wave per group of 4 hidden units, lanes along C (coalesced), the 4 x C/64 loads of a
-// group issued before the first reduction (one unit at a time = 16 dependent trips per wave: 36 us per launch);
-// W2 [C][H]: one thread per output channel reads its own row as H/4 16-byte loads, all in flight.
-__global__ __launch_bounds__(256) void se_mlp_fwd_kernel(const float* __restrict__ sums, const float* __restrict__ coef,
-                                                         const float* __restrict__ W1, const float* __restrict__ W2, int C, int H,
-                                                         float inv_T, float* __restrict__ pooled, float* __restrict__ hidden,
-                                                         float* __restrict__ scale) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C] | hidden[H]
-  float* s_p = sm;
-  float* s_h = sm + C;
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float p = fmaf(coef[c], sums[(int64_t)b * C + c] * inv_T, coef[C + c]);
-    s_p[c] = p;
-    pooled[(int64_t)b * C + c] = p;
-  }
-  __syncthreads();
+// ---- excite MLP, forward, for the whole batch ------------------------------------------------------------------------------
+// pooled = a*sums/T + b ; hidden = relu(W1 pooled) ; scale = sigmoid(W2 hidden).  The two mat-vecs are latency-, not
+// bandwidth-work; one workgroup per utterance (the first form) made every workgroup stream both weight matrices - 256 KB out of
+// L2 through one CU, 14.8 us per unit at cfg4.  Here each launch is dealt over (outputs x utterances), a workgroup reads only the
+// weight rows of its outputs, and every wave has all of its loads in flight at once: two launches of one memory round trip each.
+static constexpr int kSeHid = 4;      // hidden units per workgroup (se_hidden_kernel)
+static constexpr int kSeUtt = 8;      // utterances per workgroup (both forward kernels)
+static constexpr int kSeCh = 32;      // output channels per workgroup (se_scale_kernel)
+
+// grid (ceil(H / 4), ceil(B / 8)), block 256: wave w takes utterances 8*by + w and + 4, lanes along c (coalesced rows of W1
+// and of the sums); the 4 hidden units of the workgroup share every pooled value.  Workgroups of column 0 also store `pooled`.
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ sums, const float* __restrict__ coef,
+                                                        const float* __restrict__ W1, int B, int C, int H, float inv_T,
+                                                        float* __restrict__ pooled, float* __restrict__ hidden) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int h0 = wid * 8; h0 < H; h0 += 32) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int h0 = blockIdx.x * kSeHid;
+  const int b0 = blockIdx.y * kSeUtt + wid, b1 = b0 + 4;
+  const int bb0 = min(b0, B - 1), bb1 = min(b1, B - 1);          // clamped: no branch around the loads
+  float acc0[kSeHid], acc1[kSeHid];
+#pragma unroll
+  for (int u = 0; u < kSeHid; ++u) { acc0[u] = 0.f; acc1[u] = 0.f; }
 #pragma unroll 8
-    for (int c = lane; c < C; c += 64) {
-      const float pv = s_p[c];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] = fmaf(W1[(int64_t)min(h0 + u, H - 1) * C + c], pv, acc[u]);
+  for (int c = lane; c < C; c += 64) {
+    const float a = coef[c], bc = coef[C + c];
+    const float p0 = fmaf(a, sums[(size_t)bb0 * C + c] * inv_T, bc);
+    const float p1 = fmaf(a, sums[(size_t)bb1 * C + c] * inv_T, bc);
+    if (blockIdx.x == 0) {
+      if (b0 < B) pooled[(size_t)b0 * C + c] = p0;
+      if (b1 < B) pooled[(size_t)b1 * C + c] = p1;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float v = fmaxf(wave_sum(acc[u]), 0.f);
-      if (lane == 0 && h0 + u < H) {
-        s_h[h0 + u] = v;
-        hidden[(int64_t)b * H + h0 + u] = v;
-      }
+    for (int u = 0; u < kSeHid; ++u) {
+      const float w = W1[(size_t)min(h0 + u, H - 1) * C + c];
+      acc0[u] = fmaf(w, p0, acc0[u]);
+      acc1[u] = fmaf(w, p1, acc1[u]);
     }
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float4* w = reinterpret_cast<const float4*>(W2 + (int64_t)c * H);   // H % 4 == 0 (H = C/8, C % 32 == 0 checked on the host)
-    float acc = 0.f;
-    for (int h4 = 0; h4 < H / 4; h4 += 16) {
-      float4 wv[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) wv[u] = w[min(h4 + u, H / 4 - 1)];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        if (h4 + u < H / 4) {
-          const float4 hv = *reinterpret_cast<const float4*>(s_h + 4 * (h4 + u));
-          acc = fmaf(wv[u].x, hv.x, acc); acc = fmaf(wv[u].y, hv.y, acc); acc = fmaf(wv[u].z, hv.z, acc); acc = fmaf(wv[u].w, hv.w, acc);
-        }
-      }
+  for (int u = 0; u < kSeHid; ++u) {
+    const float v0 = fmaxf(wave_sum(acc0[u]), 0.f), v1 = fmaxf(wave_sum(acc1[u]), 0.f);
+    if (lane == 0 && h0 + u < H) {
+      if (b0 < B) hidden[(size_t)b0 * H + h0 + u] = v0;
+      if (b1 < B) hidden[(size_t)b1 * H + h0 + u] = v1;
     }
-    scale[(int64_t)b * C + c] = 1.f / (1.f + expf(-acc));
   }
 }
 
-// One workgroup per utterance: back through sigmoid, W2, relu, W1, the mean over T.
-// Writes seg[b][c] = d(loss)/d(BN output z1[b,t,c]) through the pooled path (same for every t) and the two small per-utterance
-// vectors the batched weight-gradient kernel below needs: d2[b][c] = d(pre-sigmoid), dh[b][h] = d(pre-relu).
-//   dh[h] = relu'(.) sum_c W2[c][h] d2[c]: lanes along h (a row of W2 is one coalesced 4*H-byte read), each wave walks C/4 rows
-//   with 8 row loads in flight, the four waves' partial vectors meet in LDS;
-//   seg[c] = sum_h W1[h][c] dh[h] / T: one thread per c, rows of W1 read coalesced across c, 8 in flight.
-__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ scale,
-                                                         const float* __restrict__ hidden, const float* __restrict__ W1,
-                                                         const float* __restrict__ W2, int C, int H, float inv_T,
-                                                         float* __restrict__ seg, float* __restrict__ d2_out, float* __restrict__ dh_out) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // d2[C] | part[4][H] | dh[H]
+// grid (ceil(C / 32), ceil(B / 8)), block 256 = 32 channels x 8 utterances; the workgroup's rows of W2 ([32][H], contiguous) and
+// its utterances' hidden vectors sit in LDS (W2 rows at pitch H + 1: the 32 channel lanes hit 32 banks).
+__global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__ hidden, const float* __restrict__ W2, int B, int C, int H,
+                                                       float* __restrict__ scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // w2[32][H + 1] | hid[8][H]
+  float* s_w2 = sm;
+  float* s_hid = sm + kSeCh * (H + 1);
+  const int c0 = blockIdx.x * kSeCh, b0 = blockIdx.y * kSeUtt;
+  for (int i = threadIdx.x; i < kSeCh * H; i += 256) {
+    const int cl = i / H, h = i - cl * H;
+    s_w2[cl * (H + 1) + h] = c0 + cl < C ? W2[(size_t)c0 * H + i] : 0.f;
+  }
+  for (int i = threadIdx.x; i < kSeUtt * H; i += 256) {
+    const int bl = i / H;
+    s_hid[i] = b0 + bl < B ? hidden[(size_t)b0 * H + i] : 0.f;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  float acc = 0.f;
+  for (int h = 0; h < H; ++h) acc = fmaf(s_w2[cl * (H + 1) + h], s_hid[bl * H + h], acc);
+  if (c0 + cl < C && b0 + bl < B) scale[(size_t)(b0 + bl) * C + c0 + cl] = 1.f / (1.f + expf(-acc));
+}
+
+// ---- excite MLP, backward, for the whole batch -----------------------------------------------------------------------------
+// Was four dependent launches per unit (fold of the raw sums, one-workgroup-per-utterance MLP backward, batched weight gradients,
+// BN-backward constants: 6.8 + 15.3 + 12.2 + 16.7 us at cfg4).  Two launches, each dealt over channel chunks with the whole
+// batch inside a workgroup, so the batch sums (weight gradients, BN constants) close inside the workgroup that owns the channels:
+//   se_bwd_hidden_kernel (chunk of 32 channels): ds -> d2 = ds*s*(1-s) ; dW2[c][:] = sum_b d2[b][c] hidden[b][:] ;
+//                                                 dh_part[chunk][b][h] = sum_{c in chunk} W2[c][h] d2[b][c]
+//   se_bwd_pool_kernel   (chunk of 16 channels): dh = relu'(hidden) * sum_chunks dh_part ; seg[b][c] = sum_h W1[h][c] dh[b][h] / T ;
+//                                                 dW1[:][c] = sum_b dh[b][:] pooled[b][c] ; [BN constants of the chunk's channels]
+static constexpr int kSeC1 = 32, kSeC2 = 16;
+
+// Fused form (bn.partials != nullptr): ds comes from the per-(utterance, slab) raw sums P[b][k][c], k = 0..3: sum_t dm,
+// sum_t dm*xhat1 (main branch, dm = gradient reaching the BN output without SE factors), sum_t d, sum_t d*xhat2 (residual branch):
+//   ds[b][c] = sum_t dm * z1 = gamma_c * P1 + beta_c * P0      (z1 = BN output = gamma*xhat1 + beta)
+// - no pass of its own over (dout, y, y2).  The folded sums P [B][4][C] are kept for the second launch.
+__global__ __launch_bounds__(512) void se_bwd_hidden_kernel(const float* __restrict__ ds, const float* __restrict__ partials, int nslab,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ scale, const float* __restrict__ hidden,
+                                                            const float* __restrict__ W2, int B, int C, int H, float* __restrict__ P,
+                                                            float* __restrict__ dW2, float* __restrict__ dh_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // d2[B][32] | hid[B][H] | w2[32][H]
   float* s_d2 = sm;
-  float* s_part = sm + C;
-  float* s_dh = s_part + 4 * H;
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float s = scale[(int64_t)b * C + c];
-    const float v = ds[(int64_t)b * C + c] * s * (1.f - s);
-    s_d2[c] = v;
-    d2_out[(int64_t)b * C + c] = v;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  {
-    const int rows = C / 4, c0 = wid * rows;       // this wave's rows of W2
-    float acc = 0.f;
-    const int hl = min(lane, H - 1);
-    for (int r = 0; r < rows; r += 32) {
-      float wv[32];
+  float* s_hid = s_d2 + (size_t)B * kSeC1;
+  float* s_w2 = s_hid + (size_t)B * H;
+  const int c0 = blockIdx.x * kSeC1;
+  for (int i = threadIdx.x; i < B * H; i += 512) s_hid[i] = hidden[i];
+  for (int i = threadIdx.x; i < kSeC1 * H; i += 512) s_w2[i] = W2[(size_t)c0 * H + i];      // C % 32 == 0: whole chunks only
+  for (int i = threadIdx.x; i < B * kSeC1; i += 512) {
+    const int b = i >> 5, c = c0 + (i & 31);
+    float dsv;
+    if (partials) {
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
+      const float* p = partials + (size_t)b * nslab * 4 * C + c;
+#pragma unroll 4
+      for (int sl = 0; sl < nslab; ++sl) {
 #pragma unroll
-      for (int u = 0; u < 32; ++u) wv[u] = W2[(int64_t)(c0 + min(r + u, rows - 1)) * H + hl];
+        for (int k = 0; k < 4; ++k) a[k] += (double)p[((size_t)sl * 4 + k) * C];
+      }
 #pragma unroll
-      for (int u = 0; u < 32; ++u)
-        if (r + u < rows) acc = fmaf(wv[u], s_d2[c0 + r + u], acc);
+      for (int k = 0; k < 4; ++k) P[((size_t)b * 4 + k) * C + c] = (float)a[k];
+      dsv = (float)((double)gamma[c] * a[1] + (double)beta[c] * a[0]);
+    } else {
+      dsv = ds[(size_t)b * C + c];
     }
-    if (lane < H) s_part[wid * H + lane] = acc;
+    const float s = scale[(size_t)b * C + c];
+    s_d2[i] = dsv * s * (1.f - s);
   }
   __syncthreads();
-  if (threadIdx.x < H) {
-    const int h = threadIdx.x;
-    const float a = (s_part[h] + s_part[H + h]) + (s_part[2 * H + h] + s_part[3 * H + h]);
-    const float v = hidden[(int64_t)b * H + h] > 0.f ? a : 0.f;
-    s_dh[h] = v;
-    dh_out[(int64_t)b * H + h] = v;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  // dW2 rows of the chunk: [32][H], consecutive threads along h
+  for (int i = threadIdx.x; i < kSeC1 * H; i += 512) {
+    const int cl = i / H, h = i - cl * H;
     float acc = 0.f;
-    for (int h = 0; h < H; h += 32) {
-      float wv[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) wv[u] = W1[(int64_t)min(h + u, H - 1) * C + c];
-#pragma unroll
-      for (int u = 0; u < 32; ++u)
-        if (h + u < H) acc = fmaf(wv[u], s_dh[h + u], acc);
-    }
-    seg[(int64_t)b * C + c] = acc * inv_T;
+    for (int b = 0; b < B; ++b) acc = fmaf(s_d2[b * kSeC1 + cl], s_hid[b * H + h], acc);
+    dW2[(size_t)c0 * H + i] = acc;
+  }
+  // this chunk's share of d(hidden pre-activation), before relu'
+  float* out = dh_part + (size_t)blockIdx.x * B * H;
+  for (int i = threadIdx.x; i < B * H; i += 512) {
+    const int b = i / H, h = i - b * H;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int cl = 0; cl < kSeC1; ++cl) acc = fmaf(s_w2[cl * H + h], s_d2[b * kSeC1 + cl], acc);
+    out[i] = acc;
   }
 }
 
-// dW2[c][h] = sum_b d2[b][c] * hidden[b][h],  dW1[h][c] = sum_b dh[b][h] * pooled[b][c]: two 32-term outer-product sums per
-// weight, for all utterances in ONE launch (was: per-utterance [C][H] slabs, 2 x 4 MB written and re-read by two reductions).
-// grid (ceil(C/64), 2): blockIdx.y = 0 -> dW2 tile [64 c][H], 1 -> dW1 tile [H][64 c].  The batch's four small matrices sit in LDS.
-__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ d2, const float* __restrict__ hidden,
-                                                       const float* __restrict__ dh, const float* __restrict__ pooled, int B, int C, int H,
-                                                       float* __restrict__ dW1, float* __restrict__ dW2) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // a[B][64] | v[B][H]
-  float* s_a = sm;
-  float* s_v = sm + (size_t)B * 64;
-  const int c0 = blockIdx.x * 64;
-  const bool w2 = blockIdx.y == 0;
-  const float* A = w2 ? d2 : pooled;      // [B][C], the 64-channel slice
-  const float* V = w2 ? hidden : dh;      // [B][H]
-  for (int i = threadIdx.x; i < B * 64; i += 256) {
-    const int bb = i >> 6, cc = i & 63;
-    s_a[i] = c0 + cc < C ? A[(int64_t)bb * C + c0 + cc] : 0.f;
-  }
-  for (int i = threadIdx.x; i < B * H; i += 256) s_v[i] = V[i];
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * H; i += 256) {
-    // dW2 is [C][H]: consecutive threads along h;  dW1 is [H][C]: consecutive threads along c  (coalesced stores either way)
-    const int cc = w2 ? i / H : i & 63;
-    const int h = w2 ? i - cc * H : i >> 6;
-    if (c0 + cc >= C) continue;
+// Fused form (bn.tab != nullptr): the BN-backward constants of the chunk's channels from the per-utterance sums, the SE scale and
+// the pooled-path gradient seg:
+//   d1 = dm*se + seg  =>  s1 = sum_b (se*P0 + T*seg),  s2 = sum_b (se*P1 + seg*X1),  X1[b][c] = sum_t xhat1 = (sum_t y - T*mean)*rstd
+__global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restrict__ dh_part, int nchunk, const float* __restrict__ hidden,
+                                                          const float* __restrict__ pooled, const float* __restrict__ W1,
+                                                          const float* __restrict__ scale, const float* __restrict__ P, int B, int Tt,
+                                                          int C, int H, float* __restrict__ seg, float* __restrict__ dW1, SeBwdBn bn) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dh[B][H] | w1[H][16] | pool[B][16] | seg[B][16] | red[4][32][16] f64
+  float* s_dh = sm;
+  float* s_w1 = s_dh + (size_t)B * H;
+  float* s_pool = s_w1 + (size_t)H * kSeC2;
+  float* s_seg = s_pool + (size_t)B * kSeC2;
+  const int c0 = blockIdx.x * kSeC2;
+  const float inv_T = 1.f / (float)Tt;
+  for (int i = threadIdx.x; i < B * H; i += 512) {
     float acc = 0.f;
-    for (int bb = 0; bb < B; ++bb) acc = fmaf(s_a[bb * 64 + cc], s_v[bb * H + h], acc);
-    if (w2) dW2[(int64_t)(c0 + cc) * H + h] = acc;
-    else dW1[(int64_t)h * C + c0 + cc] = acc;
+#pragma unroll 8
+    for (int k = 0; k < nchunk; ++k) acc += dh_part[(size_t)k * B * H + i];
+    s_dh[i] = hidden[i] > 0.f ? acc : 0.f;
+  }
+  for (int i = threadIdx.x; i < H * kSeC2; i += 512) s_w1[i] = W1[(size_t)(i >> 4) * C + c0 + (i & 15)];
+  for (int i = threadIdx.x; i < B * kSeC2; i += 512) s_pool[i] = pooled[(size_t)(i >> 4) * C + c0 + (i & 15)];
+  __syncthreads();
+  for (int i = threadIdx.x; i < B * kSeC2; i += 512) {
+    const int b = i >> 4, cl = i & 15;
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc = fmaf(s_w1[h * kSeC2 + cl], s_dh[b * H + h], acc);
+    acc *= inv_T;
+    s_seg[i] = acc;
+    seg[(size_t)b * C + c0 + cl] = acc;
+  }
+  for (int i = threadIdx.x; i < H * kSeC2; i += 512) {
+    const int h = i >> 4, cl = i & 15;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc = fmaf(s_dh[b * H + h], s_pool[b * kSeC2 + cl], acc);
+    dW1[(size_t)h * C + c0 + cl] = acc;
+  }
+  if (!bn.tab) return;                                          // workgroup-uniform
+  __syncthreads();
+  // 32 utterance lanes x 16 channels, f64 sums, fixed-order fold
+  size_t red_off = (size_t)(B * H + H * kSeC2 + 2 * B * kSeC2) * sizeof(float);
+  red_off = (red_off + 7) & ~(size_t)7;
+  double* s_red = reinterpret_cast<double*>(reinterpret_cast<char*>(sm) + red_off);   // [4][32][16]
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, c = c0 + cl;
+  const float mean = bn.saved[c], rstd = bn.saved[C + c];
+  double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
+  for (int b = bl; b < B; b += 32) {
+    const float p0 = P[((size_t)b * 4 + 0) * C + c], p1 = P[((size_t)b * 4 + 1) * C + c];
+    const float sc = scale[(size_t)b * C + c], sg = s_seg[b * kSeC2 + cl];
+    const float x1 = (bn.ysum[(size_t)b * C + c] - (float)Tt * mean) * rstd;
+    s1 += (double)sc * p0 + (double)Tt * sg;
+    s2 += (double)sc * p1 + (double)sg * x1;
+    q1 += (double)P[((size_t)b * 4 + 2) * C + c];
+    q2 += (double)P[((size_t)b * 4 + 3) * C + c];
+  }
+  s_red[(0 * 32 + bl) * kSeC2 + cl] = s1; s_red[(1 * 32 + bl) * kSeC2 + cl] = s2;
+  s_red[(2 * 32 + bl) * kSeC2 + cl] = q1; s_red[(3 * 32 + bl) * kSeC2 + cl] = q2;
+  __syncthreads();
+  if (threadIdx.x < kSeC2) {
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      for (int l = 0; l < 32; ++l) t[q] += s_red[(q * 32 + l) * kSeC2 + cl];
+    bn_bwd_table_channel(c, C, (float)t[0], (float)t[1], (float)t[2], (float)t[3], bn.coef2 != nullptr, bn.coef, bn.saved, bn.gamma, bn.coef2,
+                         bn.saved2, bn.gamma2, bn.inv_n, bn.tab, bn.dgamma, bn.dbeta, bn.dgamma2, bn.dbeta2);
   }
 }
 
 }  // namespace lasr
 
 namespace lasr {
-// back through the excite MLP from ds [B][C] = d(loss)/d(scale): seg [B][C], dW1, dW2; d2 [B][C] and dh [B][C/8] are scratch
-int launch_se_mlp_bwd(const float* ds, const float* scale, const float* hidden, const float* pooled, const float* W1, const float* W2,
-                      int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, float* d2, float* dh, hipStream_t st) {
+static size_t se_pool_smem(int64_t B, int64_t H) {
+  size_t n = (size_t)(B * H + H * kSeC2 + 2 * B * kSeC2) * sizeof(float);
+  n = (n + 7) & ~(size_t)7;
+  return n + (size_t)4 * 32 * kSeC2 * sizeof(double);
+}
+static size_t se_hidden_smem(int64_t B, int64_t H) { return (size_t)(B * kSeC1 + B * H + kSeC1 * H) * sizeof(float); }
+
+// work = P [B][4][C] | dh_part [C/32][B][C/8]
+size_t se_bwd_work_bytes(int64_t B, int64_t C) {
+  return align_up((size_t)B * 4 * C * sizeof(float), 256) + align_up((size_t)(C / kSeC1) * B * (C / 8) * sizeof(float), 256);
+}
+
+int launch_se_bwd(const float* ds, const SeBwdBn* bn, const float* scale, const float* hidden, const float* pooled, const float* W1,
+                  const float* W2, int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, void* work, hipStream_t st) {
   const int H = (int)(C / 8);
-  if (C % 32 != 0 || H > 64 || (size_t)B * (64 + H) * sizeof(float) > 64 * 1024)
-    return fail(LASR_E_SHAPE, "lasr_se_bwd: C=%lld B=%lld (the kernels are built for C <= 512 in multiples of 32)", (long long)C, (long long)B);
-  hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + 5 * H) * sizeof(float), st, ds, scale, hidden, W1, W2,
-                     (int)C, H, 1.0f / (float)T_, seg, d2, dh);
-  LASR_LAUNCH_CHECK("se_mlp_bwd_kernel");
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((unsigned)cdiv(C, 64), 2), dim3(256), (size_t)B * (64 + H) * sizeof(float), st, d2, hidden, dh,
-                     pooled, (int)B, (int)C, H, dW1, dW2);
-  LASR_LAUNCH_CHECK("se_wgrad_kernel");
+  if (C % 32 != 0 || se_pool_smem(B, H) > 64 * 1024 || se_hidden_smem(B, H) > 64 * 1024)
+    return fail(LASR_E_SHAPE, "lasr_se_bwd: C=%lld B=%lld (C a multiple of 32; the batch's excite vectors must fit 64 KB of LDS)",
+                (long long)C, (long long)B);
+  float* P = reinterpret_cast<float*>(work);
+  float* dh_part = reinterpret_cast<float*>(reinterpret_cast<char*>(work) + align_up((size_t)B * 4 * C * sizeof(float), 256));
+  const int nchunk = (int)(C / kSeC1);
+  const bool fused = bn && bn->partials;
+  hipLaunchKernelGGL(se_bwd_hidden_kernel, dim3((unsigned)nchunk), dim3(512), se_hidden_smem(B, H), st, ds, fused ? bn->partials : nullptr,
+                     fused ? bn->nslab : 0, fused ? bn->gamma : nullptr, fused ? bn->beta : nullptr, scale, hidden, W2, (int)B, (int)C, H, P, dW2,
+                     dh_part);
+  LASR_LAUNCH_CHECK("se_bwd_hidden_kernel");
+  SeBwdBn b2;
+  if (fused) b2 = *bn;
+  else { memset(&b2, 0, sizeof(b2)); }
+  hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((unsigned)(C / kSeC2)), dim3(512), se_pool_smem(B, H), st, dh_part, nchunk, hidden, pooled, W1,
+                     scale, P, (int)B, (int)T_, (int)C, H, seg, dW1, b2);
+  LASR_LAUNCH_CHECK("se_bwd_pool_kernel");
   return 0;
 }
 }  // namespace lasr
@@ -265,7 +380,11 @@ extern "C" int lasr_seqsum(const void* x, int dtype, int64_t B, int64_t T_, int6
   LASR_CHECK_ARG(x && sums && (dtype == LASR_F32 || dtype == LASR_BF16), "lasr_seqsum: bad argument");
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && T_ > 0 && C > 0 && C % 4 == 0, "lasr_seqsum: shape");
   dim3 grid((unsigned)cdiv(C, 64), (unsigned)B);
-  if (dtype == LASR_F32) hipLaunchKernelGGL(seqsum_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, T_, C, sums);
+  const int v = dtype == LASR_F32 ? 4 : 8;
+  const bool vec = C % v == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && T_ < ((int64_t)1 << 30) && C < ((int64_t)1 << 30);
+  if (vec && dtype == LASR_F32) hipLaunchKernelGGL(seqsum_vec_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (int)T_, (int)C, sums);
+  else if (vec) hipLaunchKernelGGL(seqsum_vec_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (int)T_, (int)C, sums);
+  else if (dtype == LASR_F32) hipLaunchKernelGGL(seqsum_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, T_, C, sums);
   else hipLaunchKernelGGL(seqsum_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, T_, C, sums);
   LASR_LAUNCH_CHECK("seqsum_kernel");
   return 0;
@@ -276,15 +395,20 @@ extern "C" int lasr_se_fwd(const float* sums, const float* coef, const float* W1
   LASR_CHECK_ARG(sums && coef && W1 && W2 && pooled && hidden && scale, "lasr_se_fwd: null pointer");
   LASR_CHECK_SHAPE(B > 0 && T_ > 0 && C >= 32 && C % 32 == 0 && C <= 8192, "lasr_se_fwd: C=%lld", (long long)C);
   const int H = (int)(C / 8);
-  hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3((unsigned)B), dim3(256), (size_t)(C + H) * sizeof(float), as_stream(stream), sums, coef, W1,
-                     W2, (int)C, H, 1.0f / (float)T_, pooled, hidden, scale);
-  LASR_LAUNCH_CHECK("se_mlp_fwd_kernel");
+  LASR_CHECK_SHAPE(B < 65536 * kSeUtt, "lasr_se_fwd: B=%lld", (long long)B);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)cdiv(H, kSeHid), (unsigned)cdiv(B, kSeUtt)), dim3(256), 0, st, sums, coef, W1, (int)B,
+                     (int)C, H, 1.0f / (float)T_, pooled, hidden);
+  LASR_LAUNCH_CHECK("se_hidden_kernel");
+  hipLaunchKernelGGL(se_scale_kernel, dim3((unsigned)cdiv(C, kSeCh), (unsigned)cdiv(B, kSeUtt)), dim3(256),
+                     (size_t)(kSeCh * (H + 1) + kSeUtt * H) * sizeof(float), st, hidden, W2, (int)B, (int)C, H, scale);
+  LASR_LAUNCH_CHECK("se_scale_kernel");
   return 0;
 }
 
 extern "C" size_t lasr_se_bwd_workspace_bytes(int64_t B, int64_t C) {
-  // ds [B][C] | d2 [B][C] | dh [B][C/8]
-  return 2 * align_up((size_t)B * C * sizeof(float), 256) + align_up((size_t)B * (C / 8) * sizeof(float), 256);
+  // ds [B][C] | the two launches' hand-over (se_bwd_work_bytes)
+  return align_up((size_t)B * C * sizeof(float), 256) + se_bwd_work_bytes(B, C);
 }
 
 extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
@@ -319,8 +443,7 @@ extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* co
   if (workspace_bytes < lasr_se_bwd_workspace_bytes(B, C)) return fail(LASR_E_WORKSPACE, "lasr_se_bwd: workspace");
   char* w = reinterpret_cast<char*>(workspace);
   float* ds = reinterpret_cast<float*>(w);
-  float* d2 = reinterpret_cast<float*>(w + align_up((size_t)B * C * sizeof(float), 256));
-  float* dh = reinterpret_cast<float*>(w + 2 * align_up((size_t)B * C * sizeof(float), 256));
+  void* work = w + align_up((size_t)B * C * sizeof(float), 256);
   dim3 grid((unsigned)cdiv(C, 64), (unsigned)B);
   hipStream_t st = as_stream(stream);
   if (dtype == LASR_F32)
@@ -330,5 +453,5 @@ extern "C" int lasr_se_bwd_drop(const void* dout, const void* y, const float* co
     hipLaunchKernelGGL(se_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, coef,
                        (const bf16_t*)y2, coef2, scale, T_, C, act, ds, da);
   LASR_LAUNCH_CHECK("se_bwd_reduce_kernel");
-  return launch_se_mlp_bwd(ds, scale, hidden, pooled, W1, W2, B, T_, C, seg, dW1, dW2, d2, dh, st);
+  return launch_se_bwd(ds, nullptr, scale, hidden, pooled, W1, W2, B, T_, C, seg, dW1, dW2, work, st);
 }

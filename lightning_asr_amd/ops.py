@@ -279,6 +279,35 @@ def bn_act(y, coef, y2=None, coef2=None, se_scale=None, act: str = "relu") -> to
     return out
 
 
+def se_fwd(y, coef, W1, W2):
+    """SELayer forward on the pre-BN tensor y (B,T,C) (models/QuartNetContextSE.py:8-23): the squeeze is taken through the BN
+    coefficients coef [2][C] (mean_T(BN(y)) = a * mean_T(y) + b).  -> (ysum (B,C), pooled (B,C), hidden (B,C/8), scale (B,C)), f32."""
+    B, T, Cc = y.shape
+    dev = y.device
+    ysum = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+    pooled = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+    hidden = torch.empty(B, Cc // 8, dtype=torch.float32, device=dev)
+    scale = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+    call("lasr_seqsum", _p(y), _dt(y), B, T, Cc, _p(ysum), _stream())
+    call("lasr_se_fwd", _p(ysum), _p(coef), _p(W1), _p(W2), B, T, Cc, _p(pooled), _p(hidden), _p(scale), _stream())
+    return ysum, pooled, hidden, scale
+
+
+def se_bwd(dout, y, coef, scale, hidden, pooled, W1, W2, y2=None, coef2=None, act: str = "relu"):
+    """Backward of the SE branch of out = act(BN(y) * scale + BN2(y2)): -> (seg (B,C) = d(loss)/d(BN output) through the pooled
+    mean, dW1 (C/8,C), dW2 (C,C/8))."""
+    B, T, Cc = y.shape
+    dev = y.device
+    seg = torch.empty(B, Cc, dtype=torch.float32, device=dev)
+    dW1 = torch.empty(Cc // 8, Cc, dtype=torch.float32, device=dev)
+    dW2 = torch.empty(Cc, Cc // 8, dtype=torch.float32, device=dev)
+    nb = int(_lib.load().lasr_se_bwd_workspace_bytes(B, Cc))
+    ws = _ws(nb, dev)
+    call("lasr_se_bwd", _p(dout), _p(y), _p(coef), _p(y2), _p(coef2), _p(scale), _p(hidden), _p(pooled), _p(W1), _p(W2), _dt(y), B, T, Cc,
+         ACT[act], _p(seg), _p(dW1), _p(dW2), _p(ws), nb, _stream())
+    return seg, dW1, dW2
+
+
 def bn_act_bwd(dout, y, coef, saved, gamma, y2=None, coef2=None, saved2=None, gamma2=None, se_scale=None, se_grad=None,
                row_lens=None, act: str = "relu", fused: bool = False):
     """Returns (dy, dy2, dgamma, dbeta, dgamma2, dbeta2).  fused: pass 2 reduces pass 1's partial sums itself."""
