@@ -279,8 +279,10 @@ static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dt
   g.bias = bias; g.addend = addend; g.row_lens = row_lens; g.rows_per_seq = rows_per_seq;
   g.stat_partials = nullptr; g.split_ws = nullptr;
   const size_t esz = dtype_size(dtype_ab);
-  // bf16 operands without an addend take the bf16-MFMA kernel (gemm_bf16.hip); everything else the f32-MFMA one
-  const bool use_bf16 = dtype_ab == LASR_BF16 && addend == nullptr && !getenv("LASR_FORCE_F32_MFMA");
+  // bf16 operands take the bf16-MFMA kernel (gemm_bf16.hip) - with an addend only in the form its epilogue reads (bf16 C,
+  // 4-element groups aligned); everything else the f32-MFMA one
+  const bool addend_ok = addend == nullptr || (dtype_c == LASR_BF16 && N % 4 == 0 && g.ldc % 4 == 0 && reinterpret_cast<uintptr_t>(addend) % 8 == 0);
+  const bool use_bf16 = dtype_ab == LASR_BF16 && addend_ok && !getenv("LASR_FORCE_F32_MFMA");
   // vector loads (4 elements, or 8 for the bf16 kernel) need the row pitch and base to keep every group aligned
   const int vw = use_bf16 ? 8 : 4;
   g.vecA = (g.lda % vw == 0) && (reinterpret_cast<uintptr_t>(A) % (vw * esz) == 0);

@@ -33,6 +33,7 @@ union Frag { uint4 u; s16x8 s; bf16x8 b; };
 struct Bf16Args {
   const bf16_t* A; const bf16_t* B; void* C;
   const float* bias; const int32_t* row_lens; float* stat_partials; float* split_ws;
+  const bf16_t* addend;   // 128x128 tile, bf16 C only: C = round(A B^T + bias + addend), addend [M][ldc] (N, ldc multiples of 4)
   int M, N, K, lda, ldb, ldc, rows_per_seq, k_per_split;
   int gm, gn, gz;      // tile grid
   int vecA, vecB, vecC;
@@ -322,6 +323,21 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
   } else {
     // ---- bf16 destination: bias, row mask, round; per-wave 64 x 64 LDS image; read back as 16-byte vectors for the
     //      column sums (statistics of the values as stored) and the stores (8 rows x 128 B per instruction)
+    // addend (the accumulating data-gradient GEMMs of the context branch): 4 consecutive bf16 per register quad, all 16 loads
+    // of the lane issued before the barrier
+    uint2 adv[2][2][4];
+    const bool has_add = g.addend != nullptr;                 // workgroup-uniform
+    if (has_add) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const uint32_t mrow = (uint32_t)min(m0 + wm * 64 + mi * 32 + l31, g.M - 1) * (uint32_t)g.ldc;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            adv[mi][ni][j] = *reinterpret_cast<const uint2*>(g.addend + mrow + (uint32_t)min(n0 + wn * 64 + ni * 32 + 8 * j + 4 * half, g.N - 4));
+      }
+    }
     __syncthreads();  // every wave is done reading the operand images
     char* epi = smem + wid * (64 * EPI_LD);
     const bool has_bias = g.bias != nullptr;
@@ -335,6 +351,11 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
+          if (has_add) {
+            const uint2 a = adv[mi][ni][j];
+            v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
+            v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
+          }
           if (has_bias) {
             const int n = n0 + wn * 64 + ni * 32 + 8 * j + 4 * half;
 #pragma unroll
@@ -837,6 +858,7 @@ static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
   a.vecC = (g.ldc % 8 == 0) && (reinterpret_cast<uintptr_t>(g.C) % 16 == 0);
   a.A2 = nullptr; a.lda2 = 0; a.K1 = 0; a.act = 0;
   a.row_stat = nullptr; a.row_arg = nullptr;
+  a.addend = reinterpret_cast<const bf16_t*>(g.addend);
   return 0;
 }
 
@@ -855,7 +877,9 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
   for (int i = 0; i < n; ++i) big_tiles += cdiv(g[i].M, big::BTM) * cdiv(g[i].N, btn) * gz[i];
   bool vec = true;   // every operand aligned for 16-byte chunks (pitch % 8, base % 16): true for all model tensors
   for (int i = 0; i < n; ++i) vec = vec && g[i].vecA && g[i].vecB;
-  const bool use_big = !f32_out && vec && big_tiles >= big_min;
+  bool has_add = false;
+  for (int i = 0; i < n; ++i) has_add = has_add || g[i].addend != nullptr;   // (epilogue of the 128x128 tile only)
+  const bool use_big = !f32_out && vec && big_tiles >= big_min && !has_add;
   const int tm = use_big ? big::BTM : TM, tn = use_big ? btn : TN;
   Bf16Batch b;
   LASR_TRY(fill_args(b.p[0], g[0], tm, tn, gz[0]));

@@ -733,7 +733,8 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
           dg_ab = at(ws, p.o_d1);
         }
         LASR_TRY(lasr_colsum_f32(atf(ws, p.o_dg[d]), grads + m->lstm.b_ih[d], N, 160, scratch, sb, stream));
-        LASR_TRY(lasr_colsum_f32(atf(ws, p.o_dg[d]), grads + m->lstm.b_hh[d], N, 160, scratch, sb, stream));
+        // both biases enter the gates as b_ih + b_hh: one gradient, stored twice
+        LASR_TRY(lasr_copy_cols(grads + m->lstm.b_ih[d], LASR_F32, 160, 0, grads + m->lstm.b_hh[d], LASR_F32, 160, 0, 1, 160, 0, stream));
         LASR_TRY(lasr_gemm(dg_ab, x23, grads + m->lstm.w_ih[d], dt, LASR_F32, 160, 256, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16,
                            scratch, sb, stream));
         LASR_TRY(lasr_gemm(dg_ab, wptr(m, params, ws, m->lstm.w_ih[d]), at(ws, p.o_g[cur ^ 1]), dt, dt, N, 256, 160, 0, 1, nullptr,

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__
 // batch inside a workgroup, so the batch sums (weight gradients, BN constants) close inside the workgroup that owns the channels:
 //   se_bwd_hidden_kernel (chunk of 32 channels): ds -> d2 = ds*s*(1-s) ; dW2[c][:] = sum_b d2[b][c] hidden[b][:] ;
 //                                                 dh_part[chunk][b][h] = sum_{c in chunk} W2[c][h] d2[b][c]
-//   se_bwd_pool_kernel   (chunk of 16 channels): dh = relu'(hidden) * sum_chunks dh_part ; seg[b][c] = sum_h W1[h][c] dh[b][h] / T ;
+//   se_bwd_pool_kernel   (chunk of 16 channels): dW2 = sum_groups dW2_part ; dh = relu'(hidden) * sum_chunks dh_part ; seg[b][c] = sum_h W1[h][c] dh[b][h] / T ;
 //                                                 dW1[:][c] = sum_b dh[b][:] pooled[b][c] ; [BN constants of the chunk's channels]
 static constexpr int kSeC1 = 32, kSeC2 = 16;
 
@@ -216,20 +216,23 @@ static constexpr int kSeC1 = 32, kSeC2 = 16;
 // sum_t dm*xhat1 (main branch, dm = gradient reaching the BN output without SE factors), sum_t d, sum_t d*xhat2 (residual branch):
 //   ds[b][c] = sum_t dm * z1 = gamma_c * P1 + beta_c * P0      (z1 = BN output = gamma*xhat1 + beta)
 // - no pass of its own over (dout, y, y2).  The folded sums P [B][4][C] are kept for the second launch.
-__global__ __launch_bounds__(512) void se_bwd_hidden_kernel(const float* __restrict__ ds, const float* __restrict__ partials, int nslab,
+// grid (C / 32, ceil(B / 8)), block 256 = 8 utterances x 32 channels (the fold of the raw sums is the bulk of the bytes - 4 MB per
+// unit at cfg4 - so it is dealt over utterance groups as well: with the whole batch in one workgroup per chunk it took 12 us).
+// dW2 therefore leaves as one partial per utterance group, dW2_part[group][C][H], summed by the second launch.
+__global__ __launch_bounds__(256) void se_bwd_hidden_kernel(const float* __restrict__ ds, const float* __restrict__ partials, int nslab,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ scale, const float* __restrict__ hidden,
                                                             const float* __restrict__ W2, int B, int C, int H, float* __restrict__ P,
-                                                            float* __restrict__ dW2, float* __restrict__ dh_part) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // d2[B][32] | hid[B][H] | w2[32][H]
+                                                            float* __restrict__ dW2_part, float* __restrict__ dh_part) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // d2[8][32] | hid[8][H] | w2[32][H]
   float* s_d2 = sm;
-  float* s_hid = s_d2 + (size_t)B * kSeC1;
-  float* s_w2 = s_hid + (size_t)B * H;
-  const int c0 = blockIdx.x * kSeC1;
-  for (int i = threadIdx.x; i < B * H; i += 512) s_hid[i] = hidden[i];
-  for (int i = threadIdx.x; i < kSeC1 * H; i += 512) s_w2[i] = W2[(size_t)c0 * H + i];      // C % 32 == 0: whole chunks only
-  for (int i = threadIdx.x; i < B * kSeC1; i += 512) {
-    const int b = i >> 5, c = c0 + (i & 31);
+  float* s_hid = s_d2 + kSeUtt * kSeC1;
+  float* s_w2 = s_hid + kSeUtt * H;
+  const int c0 = blockIdx.x * kSeC1, b0 = blockIdx.y * kSeUtt;
+  for (int i = threadIdx.x; i < kSeUtt * H; i += 256) s_hid[i] = b0 + i / H < B ? hidden[(size_t)b0 * H + i] : 0.f;
+  for (int i = threadIdx.x; i < kSeC1 * H; i += 256) s_w2[i] = W2[(size_t)c0 * H + i];      // C % 32 == 0: whole chunks only
+  {
+    const int bl = threadIdx.x >> 5, b = min(b0 + bl, B - 1), c = c0 + (threadIdx.x & 31);
     float dsv;
     if (partials) {
       double a[4] = {0.0, 0.0, 0.0, 0.0};
@@ -239,31 +242,35 @@ __global__ __launch_bounds__(512) void se_bwd_hidden_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] += (double)p[((size_t)sl * 4 + k) * C];
       }
+      if (b0 + bl < B) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) P[((size_t)b * 4 + k) * C + c] = (float)a[k];
+        for (int k = 0; k < 4; ++k) P[((size_t)b * 4 + k) * C + c] = (float)a[k];
+      }
       dsv = (float)((double)gamma[c] * a[1] + (double)beta[c] * a[0]);
     } else {
       dsv = ds[(size_t)b * C + c];
     }
     const float s = scale[(size_t)b * C + c];
-    s_d2[i] = dsv * s * (1.f - s);
+    s_d2[threadIdx.x] = b0 + bl < B ? dsv * s * (1.f - s) : 0.f;      // utterances past the batch contribute nothing
   }
   __syncthreads();
-  // dW2 rows of the chunk: [32][H], consecutive threads along h
-  for (int i = threadIdx.x; i < kSeC1 * H; i += 512) {
+  // this utterance group's share of the chunk's dW2 rows: [32][H], consecutive threads along h
+  float* w2p = dW2_part + ((size_t)blockIdx.y * C + c0) * H;
+  for (int i = threadIdx.x; i < kSeC1 * H; i += 256) {
     const int cl = i / H, h = i - cl * H;
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc = fmaf(s_d2[b * kSeC1 + cl], s_hid[b * H + h], acc);
-    dW2[(size_t)c0 * H + i] = acc;
+#pragma unroll
+    for (int b = 0; b < kSeUtt; ++b) acc = fmaf(s_d2[b * kSeC1 + cl], s_hid[b * H + h], acc);
+    w2p[i] = acc;
   }
-  // this chunk's share of d(hidden pre-activation), before relu'
-  float* out = dh_part + (size_t)blockIdx.x * B * H;
-  for (int i = threadIdx.x; i < B * H; i += 512) {
-    const int b = i / H, h = i - b * H;
+  // this chunk's share of d(hidden pre-activation), before relu', for the group's utterances
+  float* out = dh_part + ((size_t)blockIdx.x * B + b0) * H;
+  for (int i = threadIdx.x; i < kSeUtt * H; i += 256) {
+    const int bl = i / H, h = i - bl * H;
     float acc = 0.f;
 #pragma unroll 8
-    for (int cl = 0; cl < kSeC1; ++cl) acc = fmaf(s_w2[cl * H + h], s_d2[b * kSeC1 + cl], acc);
-    out[i] = acc;
+    for (int cl = 0; cl < kSeC1; ++cl) acc = fmaf(s_w2[cl * H + h], s_d2[bl * kSeC1 + cl], acc);
+    if (b0 + bl < B) out[i] = acc;
   }
 }
 
@@ -272,8 +279,10 @@ __global__ __launch_bounds__(512) void se_bwd_hidden_kernel(const float* __restr
 //   d1 = dm*se + seg  =>  s1 = sum_b (se*P0 + T*seg),  s2 = sum_b (se*P1 + seg*X1),  X1[b][c] = sum_t xhat1 = (sum_t y - T*mean)*rstd
 __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restrict__ dh_part, int nchunk, const float* __restrict__ hidden,
                                                           const float* __restrict__ pooled, const float* __restrict__ W1,
-                                                          const float* __restrict__ scale, const float* __restrict__ P, int B, int Tt,
-                                                          int C, int H, float* __restrict__ seg, float* __restrict__ dW1, SeBwdBn bn) {
+                                                          const float* __restrict__ scale, const float* __restrict__ P,
+                                                          const float* __restrict__ dW2_part, int ngroup, int B, int Tt, int C, int H,
+                                                          float* __restrict__ seg, float* __restrict__ dW1, float* __restrict__ dW2,
+                                                          SeBwdBn bn) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dh[B][H] | w1[H][16] | pool[B][16] | seg[B][16] | red[4][32][16] f64
   float* s_dh = sm;
   float* s_w1 = s_dh + (size_t)B * H;
@@ -289,6 +298,12 @@ __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restric
   }
   for (int i = threadIdx.x; i < H * kSeC2; i += 512) s_w1[i] = W1[(size_t)(i >> 4) * C + c0 + (i & 15)];
   for (int i = threadIdx.x; i < B * kSeC2; i += 512) s_pool[i] = pooled[(size_t)(i >> 4) * C + c0 + (i & 15)];
+  // dW2 rows of the chunk ([16][H], contiguous): the utterance groups' partials in a fixed order
+  for (int i = threadIdx.x; i < kSeC2 * H; i += 512) {
+    float acc = 0.f;
+    for (int g = 0; g < ngroup; ++g) acc += dW2_part[((size_t)g * C + c0) * H + i];
+    dW2[(size_t)c0 * H + i] = acc;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < B * kSeC2; i += 512) {
     const int b = i >> 4, cl = i & 15;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restric
   // 32 utterance lanes x 16 channels, f64 sums, fixed-order fold
   size_t red_off = (size_t)(B * H + H * kSeC2 + 2 * B * kSeC2) * sizeof(float);
   red_off = (red_off + 7) & ~(size_t)7;
-  double* s_red = reinterpret_cast<double*>(reinterpret_cast<char*>(sm) + red_off);   // [4][32][16]
+  double* s_red = reinterpret_cast<double*>(reinterpret_cast<char*>(sm) + red_off);   // [4][32][16] | [4][16]
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, c = c0 + cl;
   const float mean = bn.saved[c], rstd = bn.saved[C + c];
   double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
@@ -325,14 +340,18 @@ __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restric
   s_red[(0 * 32 + bl) * kSeC2 + cl] = s1; s_red[(1 * 32 + bl) * kSeC2 + cl] = s2;
   s_red[(2 * 32 + bl) * kSeC2 + cl] = q1; s_red[(3 * 32 + bl) * kSeC2 + cl] = q2;
   __syncthreads();
-  if (threadIdx.x < kSeC2) {
-    double t[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      for (int l = 0; l < 32; ++l) t[q] += s_red[(q * 32 + l) * kSeC2 + cl];
-    bn_bwd_table_channel(c, C, (float)t[0], (float)t[1], (float)t[2], (float)t[3], bn.coef2 != nullptr, bn.coef, bn.saved, bn.gamma, bn.coef2,
-                         bn.saved2, bn.gamma2, bn.inv_n, bn.tab, bn.dgamma, bn.dbeta, bn.dgamma2, bn.dbeta2);
+  double* s_tot = s_red + 4 * 32 * kSeC2;
+  if (threadIdx.x < 4 * kSeC2) {                                // one thread per (quantity, channel): 32 terms in lane order
+    const int q = threadIdx.x >> 4;
+    double t = 0.0;
+    for (int l = 0; l < 32; ++l) t += s_red[(q * 32 + l) * kSeC2 + cl];
+    s_tot[q * kSeC2 + cl] = t;
   }
+  __syncthreads();
+  if (threadIdx.x < kSeC2)
+    bn_bwd_table_channel(c, C, (float)s_tot[cl], (float)s_tot[kSeC2 + cl], (float)s_tot[2 * kSeC2 + cl], (float)s_tot[3 * kSeC2 + cl],
+                         bn.coef2 != nullptr, bn.coef, bn.saved, bn.gamma, bn.coef2, bn.saved2, bn.gamma2, bn.inv_n, bn.tab, bn.dgamma, bn.dbeta,
+                         bn.dgamma2, bn.dbeta2);
 }
 
 }  // namespace lasr
@@ -341,34 +360,39 @@ namespace lasr {
 static size_t se_pool_smem(int64_t B, int64_t H) {
   size_t n = (size_t)(B * H + H * kSeC2 + 2 * B * kSeC2) * sizeof(float);
   n = (n + 7) & ~(size_t)7;
-  return n + (size_t)4 * 32 * kSeC2 * sizeof(double);
+  return n + (size_t)(4 * 32 * kSeC2 + 4 * kSeC2) * sizeof(double);
 }
-static size_t se_hidden_smem(int64_t B, int64_t H) { return (size_t)(B * kSeC1 + B * H + kSeC1 * H) * sizeof(float); }
+static size_t se_hidden_smem(int64_t H) { return (size_t)(kSeUtt * kSeC1 + kSeUtt * H + kSeC1 * H) * sizeof(float); }
 
-// work = P [B][4][C] | dh_part [C/32][B][C/8]
+// work = P [B][4][C] | dh_part [C/32][B][C/8] | dW2_part [ceil(B/8)][C][C/8]
 size_t se_bwd_work_bytes(int64_t B, int64_t C) {
-  return align_up((size_t)B * 4 * C * sizeof(float), 256) + align_up((size_t)(C / kSeC1) * B * (C / 8) * sizeof(float), 256);
+  return align_up((size_t)B * 4 * C * sizeof(float), 256) + align_up((size_t)(C / kSeC1) * B * (C / 8) * sizeof(float), 256) +
+         align_up((size_t)cdiv(B, kSeUtt) * C * (C / 8) * sizeof(float), 256);
 }
 
 int launch_se_bwd(const float* ds, const SeBwdBn* bn, const float* scale, const float* hidden, const float* pooled, const float* W1,
                   const float* W2, int64_t B, int64_t T_, int64_t C, float* seg, float* dW1, float* dW2, void* work, hipStream_t st) {
   const int H = (int)(C / 8);
-  if (C % 32 != 0 || se_pool_smem(B, H) > 64 * 1024 || se_hidden_smem(B, H) > 64 * 1024)
+  if (C % 32 != 0 || se_pool_smem(B, H) > 64 * 1024 || se_hidden_smem(H) > 64 * 1024 || B >= 65536 * kSeUtt)
     return fail(LASR_E_SHAPE, "lasr_se_bwd: C=%lld B=%lld (C a multiple of 32; the batch's excite vectors must fit 64 KB of LDS)",
                 (long long)C, (long long)B);
-  float* P = reinterpret_cast<float*>(work);
-  float* dh_part = reinterpret_cast<float*>(reinterpret_cast<char*>(work) + align_up((size_t)B * 4 * C * sizeof(float), 256));
-  const int nchunk = (int)(C / kSeC1);
+  char* w = reinterpret_cast<char*>(work);
+  float* P = reinterpret_cast<float*>(w);
+  w += align_up((size_t)B * 4 * C * sizeof(float), 256);
+  float* dh_part = reinterpret_cast<float*>(w);
+  w += align_up((size_t)(C / kSeC1) * B * H * sizeof(float), 256);
+  float* dW2_part = reinterpret_cast<float*>(w);
+  const int nchunk = (int)(C / kSeC1), ngroup = (int)cdiv(B, kSeUtt);
   const bool fused = bn && bn->partials;
-  hipLaunchKernelGGL(se_bwd_hidden_kernel, dim3((unsigned)nchunk), dim3(512), se_hidden_smem(B, H), st, ds, fused ? bn->partials : nullptr,
-                     fused ? bn->nslab : 0, fused ? bn->gamma : nullptr, fused ? bn->beta : nullptr, scale, hidden, W2, (int)B, (int)C, H, P, dW2,
-                     dh_part);
+  hipLaunchKernelGGL(se_bwd_hidden_kernel, dim3((unsigned)nchunk, (unsigned)ngroup), dim3(256), se_hidden_smem(H), st, ds,
+                     fused ? bn->partials : nullptr, fused ? bn->nslab : 0, fused ? bn->gamma : nullptr, fused ? bn->beta : nullptr, scale,
+                     hidden, W2, (int)B, (int)C, H, P, dW2_part, dh_part);
   LASR_LAUNCH_CHECK("se_bwd_hidden_kernel");
   SeBwdBn b2;
   if (fused) b2 = *bn;
   else { memset(&b2, 0, sizeof(b2)); }
   hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((unsigned)(C / kSeC2)), dim3(512), se_pool_smem(B, H), st, dh_part, nchunk, hidden, pooled, W1,
-                     scale, P, (int)B, (int)T_, (int)C, H, seg, dW1, b2);
+                     scale, P, dW2_part, ngroup, (int)B, (int)T_, (int)C, H, seg, dW1, dW2, b2);
   LASR_LAUNCH_CHECK("se_bwd_pool_kernel");
   return 0;
 }

@@ -411,6 +411,32 @@ def test_gemm_bf16_mfma_epilogue(dev):
     assert torch.all(got[T + 40:] == 0)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,tB", [(16032, 256, 160, True), (300, 256, 64, False), (257, 132, 100, True), (130, 28, 512, False)])
+def test_gemm_bf16_mfma_addend(dev, M, N, K, tB):
+    """C = round_bf16(A B^T + bias + addend) in the bf16-MFMA kernel's epilogue (the accumulating data-gradient GEMMs of the context
+    branch, models/QuartNetContext.py:171-173 backward: d(x) += dG W_ih).  Small integers: exact, so bit for bit; the in-place form
+    (addend == C) is the one the model uses."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    Bm = torch.randint(-3, 4, (K, N) if tB else (N, K), generator=g).float()
+    add = torch.randint(-8, 9, (M, N), generator=g).float()
+    bias = torch.randint(-2, 3, (N,), generator=g).float()
+    ref = A.double() @ (Bm if tB else Bm.t()).double() + add.double() + bias.double()
+    got, _ = ops.gemm(A.bfloat16().to(dev), Bm.bfloat16().to(dev), M, N, K, False, tB, bias=bias.to(dev), addend=add.bfloat16().to(dev))
+    assert got.dtype == torch.bfloat16
+    assert torch.equal(got.float().cpu().double(), ref.float().bfloat16().double())
+    # in place
+    Cm = add.bfloat16().to(dev)
+    nb = ops._lib.load().lasr_gemm_workspace_bytes(M, N, 1, 0)
+    ws = ops._ws(nb, dev)
+    Ag, Bg = A.bfloat16().to(dev), Bm.bfloat16().to(dev)
+    ops.call("lasr_gemm", ops._p(Ag), ops._p(Bg), ops._p(Cm), ops.BF16, ops.BF16, M, N, K, 0, int(tB), None, ops._p(Cm), None, 0, None, 1,
+             ops._p(ws), nb, ops._stream())
+    assert torch.equal(Cm.float().cpu().double(), (ref - bias.double()).float().bfloat16().double())
+
+
 # ----------------------------------------------------------------------------------------- 256x256-tile bf16 GEMM
 @pytest.mark.parametrize("M,N,K,tA,tB", [(16032, 512, 512, False, False), (16032, 512, 512, False, True),
                                          (8100, 768, 320, False, False), (8100, 776, 200, False, True),
