@@ -55,9 +55,15 @@ __global__ __launch_bounds__(256) void lse_gather_kernel(const bf16_t* __restric
   }
 }
 
-// RW rows per workgroup (RW/4 per wave).  grad [N][ldc] bf16 (pad columns written as zeros); bias_partials [grid][C] f32.
-template <int NS>
-__global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __restrict__ logits, int64_t ldc, const float* __restrict__ lse,
+// rows_per_wg rows per workgroup (a quarter per wave, one row at a time).  grad [N][ldc] bf16 (pad columns written as zeros);
+// bias_partials [grid][C] f32.  KV = 16-byte vectors per lane and row (9: C <= 4608, 18: C <= 9216).
+// A row is two HBM round trips (its logits; lse / alpha / beta / emissions) and three single-wave LDS phases.  Every global load
+// of row k + 1 is issued - unconditionally, from clamped addresses - before row k is processed, the per-utterance scalars and
+// label tables are (re)loaded only when the utterance changes, and the wave index is made scalar so that they are scalar loads:
+// the row loop itself waits on nothing but the previous iteration's prefetch.  (First form: loads inside `if (v < nvec)`,
+// vector loads of per-utterance scalars and label-chain hops from global memory in the middle of a row - 19 us per row and wave.)
+template <int NS, int KV>
+__global__ __launch_bounds__(256, 2) void ctc_grad_lean_kernel(const bf16_t* __restrict__ logits, int64_t ldc, const float* __restrict__ lse,
                                                             const float* __restrict__ E, int CE, const int64_t* __restrict__ targets,
                                                             const int32_t* __restrict__ in_lens, const int32_t* __restrict__ tgt_lens,
                                                             int64_t B, int64_t T, int64_t C, int64_t S_max, int blank,
@@ -66,48 +72,91 @@ __global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __rest
                                                             const float* __restrict__ gscale, bf16_t* __restrict__ grad,
                                                             float* __restrict__ bias_partials, int rows_per_wg) {
   constexpr int SP = 64 * NS;
-  constexpr int kMaxVec = 18;                         // 64 lanes x 8 columns x 18 = 9216 columns
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cpad = (int)((C + 7) & ~(int64_t)7);      // LDS row: C rounded up to whole 8-column vectors
-  float* s_row = smem + (size_t)wid * (cpad + S_max);
-  float* s_v = s_row + cpad;
+  const size_t pitch = (size_t)cpad + 4 * (size_t)S_max;
+  float* s_row = smem + (size_t)wid * pitch;
+  float* s_v = s_row + cpad;                                          // [S_max] occupancy of the label states
+  int32_t* s_tg = reinterpret_cast<int32_t*>(s_v + S_max);            // [S_max] labels of the current utterance, clamped
+  int32_t* s_nx = s_tg + S_max;                                       // [2 * S_max] same-label chains (ctc_lattice.h)
   const int nvec = (int)(ldc >> 3);                   // 16-byte vectors per row (ldc % 8 == 0)
-  float acc[kMaxVec][8];
+  float acc[KV][8];
 #pragma unroll
-  for (int j = 0; j < kMaxVec; ++j)
+  for (int j = 0; j < KV; ++j)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
   const int rpw = rows_per_wg >> 2;
+  const int64_t NT = B * T;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_wg + (int64_t)wid * rpw;
+
+  // prefetch registers of one row
+  uint4 xr[KV];
+  float pa[NS], pb[NS], pe[NS], pl;
+  auto issue = [&](int64_t row_) {
+    const int64_t r = row_ < NT ? row_ : NT - 1;
+    const bf16_t* x = logits + r * ldc;
+#pragma unroll
+    for (int j = 0; j < KV; ++j) xr[j] = Vec<bf16_t>::raw(x + (size_t)min(lane + 64 * j, nvec - 1) * 8);
+    pl = lse[r];
+    const float* al = alpha + r * SP;
+    const float* be = beta + r * SP;
+    const float* er = E + r * CE;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int st = lane * NS + i;
+      pa[i] = al[st]; pb[i] = be[st];
+      pe[i] = (st & 1) ? er[min(st >> 1, (int)S_max)] : er[S_max];
+    }
+  };
+  int64_t cached_b = -1;
+  int Tb = 0, S = 0;
+  float gs = 0.f, nl = 0.f;
+  if (r_begin < NT) issue(r_begin);
   for (int k = 0; k < rpw; ++k) {
     const int64_t row = r_begin + k;
-    if (row >= B * T) break;                          // wave-uniform
+    if (row >= NT) break;                             // wave-uniform
     const int64_t b = row / T, t = row - b * T;
-    const int Tb = in_lens[b];
+    if (b != cached_b) {                              // wave-uniform, once per utterance
+      cached_b = b;
+      Tb = in_lens[b]; S = tgt_lens[b];
+      gs = gscale ? gscale[b] : 1.0f / (float)B;
+      nl = nll[b];
+      const int64_t* tg = targets + b * S_max;
+      const int32_t* nx = next_same + b * S_max * 2;
+      for (int i = lane; i < (int)S_max; i += 64) s_tg[i] = (int)min(max(tg[i], (int64_t)0), C - 1);
+      for (int i = lane; i < 2 * (int)S_max; i += 64) s_nx[i] = nx[i];
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // this row's operands out of the prefetch registers, the next row's loads in flight behind them
+    uint4 cx[KV];
+    float ca[NS], cb[NS], ce[NS];
+#pragma unroll
+    for (int j = 0; j < KV; ++j) cx[j] = xr[j];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { ca[i] = pa[i]; cb[i] = pb[i]; ce[i] = pe[i]; }
+    const float l = pl;
+    issue(row + 1);
     bf16_t* g = grad + row * ldc;
     if (t >= Tb) {                                    // frames past the utterance: zero gradient
 #pragma unroll
-      for (int j = 0; j < kMaxVec; ++j) {
+      for (int j = 0; j < KV; ++j) {
         const int v = lane + 64 * j;
         if (v < nvec) *reinterpret_cast<uint4*>(g + (size_t)v * 8) = make_uint4(0u, 0u, 0u, 0u);
       }
       continue;
     }
-    const int S = tgt_lens[b];
     const int SS = 2 * S + 1;
-    const float gs = gscale ? gscale[b] : 1.0f / (float)B;
-    const float nl = nll[b];
     const bool infeasible = isinf(nl);
-    const float l = lse[row];
-    const bf16_t* x = logits + row * ldc;
     // softmax of the stored row -> LDS
 #pragma unroll
-    for (int j = 0; j < kMaxVec; ++j) {
+    for (int j = 0; j < KV; ++j) {
       const int v = lane + 64 * j;
       if (v < nvec) {
         float xv[8];
-        Vec<bf16_t>::load(x + (size_t)v * 8, xv);
+        Vec<bf16_t>::unpack(cx[j], xv);
         float4 lo, hi;
         lo.x = __expf(xv[0] - l); lo.y = __expf(xv[1] - l); lo.z = __expf(xv[2] - l); lo.w = __expf(xv[3] - l);
         hi.x = __expf(xv[4] - l); hi.y = __expf(xv[5] - l); hi.z = __expf(xv[6] - l); hi.w = __expf(xv[7] - l);
@@ -116,18 +165,13 @@ __global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __rest
       }
     }
     // occupancy of every lattice state (emissions of the states come from the compact matrix)
-    const float* al = alpha + (b * T + t) * SP;
-    const float* be = beta + (b * T + t) * SP;
-    const float* er = E + row * CE;
-    const int64_t* tg = targets + b * S_max;
     float blank_occ = 0.f;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      const int s = lane * NS + i;
-      if (s < SS) {
-        const float lp = (s & 1) ? er[s >> 1] : er[S_max];
-        const float v = expf(al[s] + be[s] + nl - lp);
-        if (s & 1) s_v[s >> 1] = v;
+      const int st = lane * NS + i;
+      if (st < SS) {
+        const float v = expf(ca[i] + cb[i] + nl - ce[i]);
+        if (st & 1) s_v[st >> 1] = v;
         else blank_occ += v;
       }
     }
@@ -135,18 +179,17 @@ __global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __rest
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes have landed (single-wave hand-off)
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) s_row[blank] -= blank_occ;
-    const int32_t* nx = next_same + b * S_max * 2;
     for (int i = lane; i < S; i += 64) {
-      if (nx[S_max + i]) {   // first occurrence of its label: sum the chain in target order (deterministic)
+      if (s_nx[S_max + i]) {   // first occurrence of its label: sum the chain in target order (deterministic)
         float a = 0.f;
-        for (int j = i; j >= 0; j = nx[j]) a += s_v[j];
-        s_row[min(max(tg[i], (int64_t)0), C - 1)] -= a;
+        for (int j = i; j >= 0; j = s_nx[j]) a += s_v[j];
+        s_row[s_tg[i]] -= a;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < kMaxVec; ++j) {
+    for (int j = 0; j < KV; ++j) {
       const int v = lane + 64 * j;
       if (v < nvec) {
         const float4 lo = *reinterpret_cast<const float4*>(s_row + (size_t)v * 8);
@@ -167,7 +210,7 @@ __global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __rest
   // column sums of the f32 gradient (decoder.bias): wave partial -> own LDS row -> fixed-order sum over the 4 waves
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < kMaxVec; ++j) {
+  for (int j = 0; j < KV; ++j) {
     const int v = lane + 64 * j;
     if (v < nvec) {
       *reinterpret_cast<float4*>(s_row + (size_t)v * 8) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
@@ -175,7 +218,6 @@ __global__ __launch_bounds__(256) void ctc_grad_lean_kernel(const bf16_t* __rest
     }
   }
   __syncthreads();
-  const size_t pitch = (size_t)cpad + S_max;
   for (int c = threadIdx.x; c < C; c += 256)
     bias_partials[(size_t)blockIdx.x * C + c] = (smem[c] + smem[pitch + c]) + (smem[2 * pitch + c] + smem[3 * pitch + c]);
 }
@@ -246,12 +288,13 @@ extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* 
   float* beta = alpha + ab;
   int32_t* next_same = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(lattice_ws) + align_up(2 * ab * sizeof(float), 256));
   const size_t em_bytes = (size_t)(T + 2) * CE * sizeof(float);
-  const bool em_lds = em_bytes <= 144 * 1024 && !getenv("LASR_CTC_NO_LDS");
+  // (160 KB of LDS per workgroup less the 2 KB of static label storage: T' = 801 with 46 emission columns needs 147.8 KB)
+  const bool em_lds = em_bytes <= 156 * 1024 && !getenv("LASR_CTC_NO_LDS");
 #define LASR_CTC_AB(NS_)                                                                                                       \
   do {                                                                                                                         \
     if (em_lds) {                                                                                                              \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_alpha_beta_compact_kernel<NS_, true>),                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);                                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);                                       \
       hipLaunchKernelGGL((ctc_alpha_beta_compact_kernel<NS_, true>), dim3((unsigned)B), dim3(128), em_bytes, st, E, targets, in_lens, \
                          tgt_lens, T, (int64_t)CE, sm, (int)sm, alpha, beta, next_same, nll);                                  \
     } else {                                                                                                                   \
@@ -263,18 +306,21 @@ extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* 
 #undef LASR_CTC_AB
   LASR_LAUNCH_CHECK("ctc_alpha_beta_compact_kernel");
   const int cpad = (int)((C + 7) & ~(int64_t)7);
-  const size_t shmem = 4 * (size_t)(cpad + sm) * sizeof(float);
-  LASR_CHECK_SHAPE(shmem <= 160 * 1024, "lasr_ctc_loss_lean: C=%lld too large for the LDS row buffers", (long long)C);
+  const size_t shmem = 4 * ((size_t)cpad + 4 * (size_t)sm) * sizeof(float);
+  LASR_CHECK_SHAPE(shmem <= 160 * 1024 && ldc / 8 <= 64 * 18, "lasr_ctc_loss_lean: C=%lld too large for the LDS row buffers", (long long)C);
   const int nwg = (int)cdiv(N, kLeanRowsPerWg);
-#define LASR_CTC_G(NS_)                                                                                                        \
+  const bool kv9 = ldc / 8 <= 64 * 9;
+#define LASR_CTC_G2(NS_, KV_)                                                                                                  \
   do {                                                                                                                         \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_grad_lean_kernel<NS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL(ctc_grad_lean_kernel<NS_>, dim3((unsigned)nwg), dim3(256), shmem, st, reinterpret_cast<const bf16_t*>(logits), ldc, lse, \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_grad_lean_kernel<NS_, KV_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((ctc_grad_lean_kernel<NS_, KV_>), dim3((unsigned)nwg), dim3(256), shmem, st, reinterpret_cast<const bf16_t*>(logits), ldc, lse, \
                        E, CE, targets, in_lens, tgt_lens, B, T, C, sm, blank, alpha, beta, next_same, nll, gscale,                \
                        reinterpret_cast<bf16_t*>(grad), bias_partials, kLeanRowsPerWg);                                       \
   } while (0)
+#define LASR_CTC_G(NS_) do { if (kv9) LASR_CTC_G2(NS_, 9); else LASR_CTC_G2(NS_, 18); } while (0)
   if (ns == 4) LASR_CTC_G(4); else if (ns == 8) LASR_CTC_G(8); else LASR_CTC_G(16);
 #undef LASR_CTC_G
+#undef LASR_CTC_G2
   LASR_LAUNCH_CHECK("ctc_grad_lean_kernel");
   return launch_reduce_partials(bias_partials, nwg, C, bias_grad, C, nullptr, st);   // f64, fixed order
 }

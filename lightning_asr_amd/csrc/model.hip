@@ -577,6 +577,24 @@ static int flush_wgrads(std::vector<lasr_gemm_problem>& probs, std::vector<float
   return 0;
 }
 
+// Split-K slices of the decoder's weight gradient dW = gl^T h ([C][1024], K = N rows) on the 128 x 128 tile (two workgroups
+// per CU): rounds of resident workgroups x K steps per slice, against the f32 slabs every slice writes and the reduction reads
+// back.  C = 28: 8 tiles, the cap of 16 slices (as before).  C = 4334: 272 tiles, where 16 slices meant 9 rounds and 284 MB of
+// slabs (214 us + an 84 us reduction at cfg5); the model's minimum is ~5 slices.
+static int dec_wgrad_split(int64_t C, int64_t N) {
+  const int64_t tiles = cdiv(C, 128) * 8;
+  const double t_k = 15.8e-9;                                     // one K element of one tile at ~1.06 PFLOP/s over 512 workgroups
+  const double t_slab = (double)C * 1024 * 8 / 4e12;              // one slab written and read back at ~4 TB/s
+  int best = 1;
+  double best_t = 1e30;
+  for (int sp = 1; sp <= 16; ++sp) {
+    const double rounds = (double)cdiv(tiles * sp, 512);
+    const double t = rounds * (double)cdiv(N, sp) * t_k + (sp > 1 ? sp * t_slab : 0.0);
+    if (t < best_t) { best_t = t; best = sp; }
+  }
+  return best;
+}
+
 // backward from d(loss)/d(logits) already in the workspace (o_glogits)
 // unit_stop: the unit loop runs from the last unit down to `unit_stop` (0 = the whole model); a later
 // lasr_model_backward_continue call picks up at unit_stop-1.  with_head: run the decoder part first.
@@ -604,8 +622,8 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
     gl_ab = at(ws, p.o_d1);
   }
-  LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr, 16,
-                        scratch, sb, stream));
+  LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr,
+                        dec_wgrad_split(C, N), scratch, sb, stream));
   if (!m->lean_active) LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, wptr(m, params, ws, m->w_dec), 1024, at(ws, p.o_g[cur]), 1024, dt, dt, N, 1024, C, 0, 1, nullptr,
                         1, scratch, sb, stream));
