@@ -542,7 +542,7 @@ def test_dwconv_wgrad_bf16_mfma(dev, C, k, T, B):
 def test_reduce_many_segments(dev):
     from lightning_asr_amd import ops
     g = torch.Generator().manual_seed(3)
-    shapes = [(16, 512 * 512), (1, 7), (32, 512 * 75), (5, 1000), (64, 33)]
+    shapes = [(16, 512 * 512), (1, 7), (32, 512 * 75), (5, 1000), (64, 33), (3, 2048), (7, 4096), (6, 100), (2, 1028), (4, 12)]
     segs, refs = [], []
     for (P, n) in shapes:
         pt = torch.randn(P, n, generator=g)
