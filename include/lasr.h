@@ -268,7 +268,8 @@ int lasr_seqsum(const void* x, int dtype, int64_t B, int64_t T, int64_t C, float
 int lasr_se_fwd(const float* sums, const float* coef, const float* W1, const float* W2, int64_t B, int64_t T, int64_t C,
                 float* pooled, float* hidden, float* scale, void* stream);
 /* Backward of the excite path: seg (B,C) = gradient reaching every frame of the BN output through the pooled
- * mean (feed it to lasr_bn_act_bwd_* as se_grad), dW1 (C/8,C), dW2 (C,C/8).                               */
+ * mean (feed it to lasr_bn_act_bwd_* as se_grad), dW1 (C/8,C), dW2 (C,C/8).  C a multiple of 32; the whole batch is
+ * handled by two launches whose per-workgroup tables (B x C/8 floats and change) must fit 64 KB of LDS (B <= ~200 at C = 512). */
 size_t lasr_se_bwd_workspace_bytes(int64_t B, int64_t C);
 int lasr_se_bwd(const void* dout, const void* y, const float* coef, const void* y2, const float* coef2, const float* scale,
                 const float* hidden, const float* pooled, const float* W1, const float* W2, int dtype, int64_t B, int64_t T,
