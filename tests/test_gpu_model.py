@@ -227,3 +227,43 @@ def test_dropout_kwarg_trains_and_is_off_in_eval(dev):
     m1.load_state_dict(m2.state_dict())
     e1, e2 = m1(x.to(dev), pct.to(dev)), m2(x.to(dev), pct.to(dev))
     assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("variant,B,T_in,pcts,S", [("plain", 1, 41, [1.0], 3), ("plain", 2, 33, [1.0, 0.3], 2),
+                                                  ("plain", 3, 201, [1.0, 0.1, 0.55], 6), ("context_se", 2, 65, [1.0, 0.4], 4),
+                                                  ("context", 1, 33, [0.8], 2)])
+def test_small_and_ragged_shapes_match_oracle(dev, variant, B, T_in, pcts, S):
+    """Edge shapes the kernels' tilings do not see at the BASELINE sizes: one utterance, T' = 17 (the shortest batch the library takes is T_in = 33
+    frames, one first_cnn window: shorter than every depthwise kernel and than one BN slab), utterances cut to a tenth of the batch's length.  f32 mode against the
+    f64 oracle end to end (forward log-probs tight; gradients at the end-to-end noise level of DESIGN §2), and the bf16 mode must
+    stay finite and close on the loss."""
+    from lightning_asr_amd import ops
+    from oracle import ref_bf16 as E
+    g = torch.Generator().manual_seed(B * 100 + T_in)
+    x = torch.randn(B, 1, 64, T_in, generator=g)
+    pct = torch.tensor(pcts, dtype=torch.float32)
+    lens_in = (T_in * pct).int()
+    x = x * (torch.arange(T_in).view(1, 1, 1, T_in) < lens_in.view(B, 1, 1, 1))
+    tg = torch.randint(0, 27, (B, S), generator=g)
+    for b in range(B):
+        for s in range(1, S):
+            if tg[b, s] == tg[b, s - 1]:
+                tg[b, s] = (tg[b, s] + 1) % 27
+    Tp = (T_in - 1) // 2 + 1
+    tl = (Tp * pct).int()
+    tsz = torch.minimum(torch.full((B,), S, dtype=torch.int32), torch.clamp(tl // 2, min=1).int())
+    o = E.Bf16OracleModel(variant, 28, mask=True, state=R.formula_state(variant, 28), dtype=torch.float64, emulate=False)
+    loss_ref, nll_ref, lp_ref, grads = E.loss_and_grads(o, x.double(), tg, pct, tsz)
+    m = _native(variant, 28, dev)
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    loss, nll, lp, am = m.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert torch.isfinite(lp).all() and torch.isfinite(m.grads).all()
+    assert (lp.cpu().double() - lp_ref).abs().max() < 2e-3
+    assert abs(loss.item() - loss_ref) / abs(loss_ref) < 1e-4
+    rels = {t.name: rel_l2(m.view(t, m.grads), gr) for t, gr in zip(m.param_infos(), grads)}
+    worst = max(rels.values())
+    assert worst < 2e-2, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    mb = _native(variant, 28, dev, dtype=torch.bfloat16)
+    lossb, _, lpb, _ = mb.loss_backward(feats.to(torch.bfloat16), pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert torch.isfinite(lpb).all() and torch.isfinite(mb.grads).all()
+    assert abs(lossb.item() - loss_ref) / abs(loss_ref) < 5e-2
