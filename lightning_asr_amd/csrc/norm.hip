@@ -101,13 +101,14 @@ __global__ __launch_bounds__(256) void bn_eval_coef_many_kernel(BnEvalMany a, fl
 // one partial lane's share of column c: rows pl, pl+8, ... in a fixed order.  The partials were written by the
 // previous kernel on other XCDs, so every load is a trip to the fabric: 16 rows are requested before the
 // first is added (a loop of 4 loads per trip exposed that latency ~16 times for 501 rows: 8.6 us per call).
+template <int LANES = 8>
 __device__ __forceinline__ double partial_lane_sum(const float* __restrict__ partials, int n_part, int64_t ncols, int64_t c, int pl) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  for (int p = pl; p < n_part; p += 128) {
+  for (int p = pl; p < n_part; p += 16 * LANES) {
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int r = p + 8 * i;
+      const int r = p + LANES * i;
       const float x = partials[(int64_t)min(r, n_part - 1) * ncols + c];   // clamped address, masked value: no branch around the load
       v[i] = r < n_part ? x : 0.f;
     }
@@ -427,26 +428,32 @@ __global__ __launch_bounds__(256) void bn_bwd_table_kernel(const float* __restri
 
 // the same table straight from the unreduced pass-1 partials ([blk][s1 | s2 | s1' | s2'][C]): four f64
 // column sums per channel, then the fold (one launch instead of two)
-__global__ __launch_bounds__(256) void bn_bwd_table_partials_kernel(const float* __restrict__ partials, int n_part,
-                                                                    const float* __restrict__ coef, const float* __restrict__ saved,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ coef2,
-                                                                    const float* __restrict__ saved2, const float* __restrict__ gamma2,
-                                                                    float inv_n, int C, float* __restrict__ tab,
-                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                    float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
-  // block = 8 channels x 4 sums = 32 columns x 8 partial lanes
-  __shared__ double s_acc[8][33];
+__global__ __launch_bounds__(1024) void bn_bwd_table_partials_kernel(const float* __restrict__ partials, int n_part,
+                                                                     const float* __restrict__ coef, const float* __restrict__ saved,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ coef2,
+                                                                     const float* __restrict__ saved2, const float* __restrict__ gamma2,
+                                                                     float inv_n, int C, float* __restrict__ tab,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                     float* __restrict__ dgamma2, float* __restrict__ dbeta2) {
+  // block = 8 channels x 4 sums = 32 columns x 32 partial lanes: the 501 partial rows of a cfg2 unit are ONE batch of 16 loads per
+  // thread (with 8 lanes they were four dependent trips to the fabric: 7.2 us per launch)
+  __shared__ double s_acc[32][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 8 + (cl & 7), k = cl >> 3;
   const bool has2 = coef2 != nullptr;
-  s_acc[pl][cl] = (c < C && (k < 2 || has2)) ? partial_lane_sum(partials, n_part, 4 * (int64_t)C, (int64_t)k * C + c, pl) : 0.0;
+  s_acc[pl][cl] = (c < C && (k < 2 || has2)) ? partial_lane_sum<32>(partials, n_part, 4 * (int64_t)C, (int64_t)k * C + c, pl) : 0.0;
+  __syncthreads();
+  if (pl < 4) {                                    // lanes 8*pl .. 8*pl+7 of every column, then the four quarter sums
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += s_acc[pl * 8 + i][cl];
+    s_acc[pl * 8][cl] = t;
+  }
   __syncthreads();
   if (pl == 0 && cl < 8 && c < C) {
-    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    double t[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t[q] += s_acc[i][q * 8 + cl];
+    for (int q = 0; q < 4; ++q) t[q] = (s_acc[0][q * 8 + cl] + s_acc[8][q * 8 + cl]) + (s_acc[16][q * 8 + cl] + s_acc[24][q * 8 + cl]);
     bn_bwd_table_channel(c, C, (float)t[0], (float)t[1], (float)t[2], (float)t[3], has2, coef, saved, gamma, coef2, saved2, gamma2,
                          inv_n, tab, dgamma, dbeta, dgamma2, dbeta2);
   }
@@ -534,6 +541,207 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+
+
+// ---- channel-sliced BN backward (bf16, residual or plain units without SE / dropout) -----------------------------------------
+// The row-major pair above needs a launch between its passes that folds 501 partial rows into per-channel constants, because a
+// workgroup that walks whole rows needs the constants of ALL channels.  Here a workgroup owns a SLICE of 64 channels (128 bytes of
+// every row: whole cache lines) and a chunk of rows, so the statistics pass leaves only `nchunk` partial rows per channel and
+// every workgroup of the apply pass folds the constants of its own 64 channels in its prologue (nchunk x 4 x 64 floats from L2):
+// statistics -> apply, nothing in between.  block = 8 column threads (16 bytes each) x 64 row lanes.
+static constexpr int kSlCh = 64, kSlThreads = 512, kSlLanes = 64;
+
+template <bool HAS2>
+__global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                                  const float* __restrict__ coef, const float* __restrict__ saved,
+                                                                  const bf16_t* __restrict__ y2, const float* __restrict__ coef2,
+                                                                  const float* __restrict__ saved2, float* __restrict__ partials,
+                                                                  int rows, int C, int act, int rpc) {
+  __shared__ float s_red[8][4][kSlCh];
+  constexpr int V = 8, RB = 4;
+  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3, lane = tid & 63, wid = tid >> 6;
+  const int c = blockIdx.x * kSlCh + cl * V;
+  const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, rows);
+  float a1[V], b1[V], m1[V], q1[V], a2[V], b2[V], m2[V], q2[V];
+  lds_vec8(coef + c, a1); lds_vec8(coef + C + c, b1); lds_vec8(saved + c, m1); lds_vec8(saved + C + c, q1);
+  if (HAS2) {
+    lds_vec8(coef2 + c, a2); lds_vec8(coef2 + C + c, b2); lds_vec8(saved2 + c, m2); lds_vec8(saved2 + C + c, q2);
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) a2[j] = b2[j] = m2[j] = q2[j] = 0.f;
+  }
+  float acc[4][V];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
+  for (int rb = r0 + rl; rb < r1; rb += RB * kSlLanes) {
+    uint4 rd[RB], ry[RB], rr[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const uint32_t off = (uint32_t)min(rb + i * kSlLanes, rows - 1) * (uint32_t)C + (uint32_t)c;
+      rd[i] = Vec<bf16_t>::raw(dout + off);
+      ry[i] = Vec<bf16_t>::raw(y + off);
+      if (HAS2) rr[i] = Vec<bf16_t>::raw(y2 + off);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      float dvi[V], yvi[V], rvi[V];
+      Vec<bf16_t>::unpack(rd[i], dvi);
+      Vec<bf16_t>::unpack(ry[i], yvi);
+      if (HAS2) Vec<bf16_t>::unpack(rr[i], rvi);
+      const float live = rb + i * kSlLanes < r1 ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float z = fmaf(yvi[j], a1[j], b1[j]) + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
+        const float d = dvi[j] * act_grad(z, act) * live;
+        acc[0][j] += d;
+        acc[1][j] = fmaf(d, (yvi[j] - m1[j]) * q1[j], acc[1][j]);
+        if (HAS2) {
+          acc[2][j] += d;
+          acc[3][j] = fmaf(d, (rvi[j] - m2[j]) * q2[j], acc[3][j]);
+        }
+      }
+    }
+  }
+  // the wave's 8 row lanes (lane bits 3-5), then the 8 waves through LDS in a fixed order
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float v = acc[k][j];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      acc[k][j] = v;
+    }
+  if (lane < 8) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < V; ++j) s_red[wid][k][cl * V + j] = acc[k][j];
+  }
+  __syncthreads();
+  if (tid < 4 * kSlCh) {
+    const int k = tid >> 6, ch = tid & 63;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += s_red[w][k][ch];
+    partials[((size_t)blockIdx.y * 4 + k) * C + blockIdx.x * kSlCh + ch] = t;
+  }
+}
+
+template <bool HAS2>
+__global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                                  const bf16_t* __restrict__ y2, const float* __restrict__ partials,
+                                                                  int nchunk, const float* __restrict__ coef, const float* __restrict__ saved,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ coef2,
+                                                                  const float* __restrict__ saved2, const float* __restrict__ gamma2,
+                                                                  float inv_n, const int32_t* __restrict__ row_lens, bf16_t* __restrict__ dy,
+                                                                  bf16_t* __restrict__ dy2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dgamma2, float* __restrict__ dbeta2, int rows, int Tt,
+                                                                  int C, int act, int rpc) {
+  __shared__ double s_sum[4][kSlCh];
+  __shared__ __attribute__((aligned(16))) float s_tab[10][kSlCh];
+  constexpr int V = 8;
+  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
+  const int c0 = blockIdx.x * kSlCh;
+  if (tid < 4 * kSlCh) {                               // waves 0-3: the slice's four sums over the chunks, f64, fixed order
+    const int k = tid >> 6, ch = tid & 63;
+    double a0 = 0.0, a1 = 0.0;
+    if (k < 2 || HAS2) {
+      const float* p = partials + (size_t)k * C + c0 + ch;
+      for (int q = 0; q < nchunk; q += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float x = p[(size_t)min(q + i, nchunk - 1) * 4 * C];
+          v[i] = q + i < nchunk ? x : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) { a0 += (double)v[i]; a1 += (double)v[i + 1]; }
+      }
+    }
+    s_sum[k][ch] = a0 + a1;
+  }
+  __syncthreads();
+  if (tid < kSlCh) {                                   // the constants of pass 2a (bn_bwd_table_channel), kept in LDS
+    const int c = c0 + tid;
+    const float s1 = (float)s_sum[0][tid], s2 = (float)s_sum[1][tid];
+    {
+      const float q = saved[C + c], w = s2 * inv_n, G = gamma[c] * q;
+      s_tab[0][tid] = coef[c]; s_tab[1][tid] = coef[C + c]; s_tab[2][tid] = G; s_tab[3][tid] = -G * q * w;
+      s_tab[4][tid] = G * (saved[c] * q * w - s1 * inv_n);
+      if (blockIdx.y == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+    }
+    if (HAS2) {
+      const float s1b = (float)s_sum[2][tid], s2b = (float)s_sum[3][tid];
+      const float q = saved2[C + c], w = s2b * inv_n, G = gamma2[c] * q;
+      s_tab[5][tid] = coef2[c]; s_tab[6][tid] = coef2[C + c]; s_tab[7][tid] = G; s_tab[8][tid] = -G * q * w;
+      s_tab[9][tid] = G * (saved2[c] * q * w - s1b * inv_n);
+      if (blockIdx.y == 0) { dbeta2[c] = s1b; dgamma2[c] = s2b; }
+    } else {
+#pragma unroll
+      for (int k = 5; k < 10; ++k) s_tab[k][tid] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int c = c0 + cl * V;
+  const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, rows);
+  for (int rb = r0 + rl; rb < r1; rb += 2 * kSlLanes) {
+    uint4 rd[2], ry[2], rr2[2];
+    uint32_t off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      off[u] = (uint32_t)min(rb + u * kSlLanes, rows - 1) * (uint32_t)C + (uint32_t)c;
+      rd[u] = Vec<bf16_t>::raw(dout + off[u]);
+      ry[u] = Vec<bf16_t>::raw(y + off[u]);
+      if (HAS2) rr2[u] = Vec<bf16_t>::raw(y2 + off[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = rb + u * kSlLanes;
+      const bool live = r < r1;
+      const int rc = min(r, rows - 1);
+      float dv[V], yv[V], rv[V], o1[V], o2[V];
+      Vec<bf16_t>::unpack(rd[u], dv);
+      Vec<bf16_t>::unpack(ry[u], yv);
+      if (HAS2) Vec<bf16_t>::unpack(rr2[u], rv);
+      const int ub = rc / Tt;
+      const bool masked = row_lens && (rc - ub * Tt) >= row_lens[ub];
+      float ca[V], cb[V], G[V], Bc[V], Cc[V], z[V], d[V];
+      lds_vec8(&s_tab[0][cl * V], ca); lds_vec8(&s_tab[1][cl * V], cb);
+#pragma unroll
+      for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], ca[j], cb[j]);
+      if (HAS2) {
+        lds_vec8(&s_tab[5][cl * V], ca); lds_vec8(&s_tab[6][cl * V], cb);
+#pragma unroll
+        for (int j = 0; j < V; ++j) z[j] += fmaf(rv[j], ca[j], cb[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
+      lds_vec8(&s_tab[2][cl * V], G); lds_vec8(&s_tab[3][cl * V], Bc); lds_vec8(&s_tab[4][cl * V], Cc);
+#pragma unroll
+      for (int j = 0; j < V; ++j) o1[j] = masked ? 0.f : fmaf(G[j], d[j], fmaf(Bc[j], yv[j], Cc[j]));
+      if (live) Vec<bf16_t>::store(dy + off[u], o1);
+      if (HAS2) {
+        lds_vec8(&s_tab[7][cl * V], G); lds_vec8(&s_tab[8][cl * V], Bc); lds_vec8(&s_tab[9][cl * V], Cc);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o2[j] = fmaf(G[j], d[j], fmaf(Bc[j], rv[j], Cc[j]));
+        if (live) Vec<bf16_t>::store(dy2 + off[u], o2);
+      }
+    }
+  }
+}
+
+// rows per chunk of the sliced pair for this shape (0: take the row-major kernels).  One 512-thread workgroup per CU (the
+// statistics kernel holds 222 registers per lane): 256 workgroups measured best at cfg2 (128: 2.339, 192: 2.298, 256: 2.262,
+// 384: 2.447, 512: 2.419 ms per step; row-major pair with its table launch: 2.372).  LASR_BN_SLICED=<n> sets the count, 0 disables.
+static int bn_sliced_rpc(int dtype, int64_t rows, int64_t C, bool se, bool drop, int per_utt, bool reduced_sums) {
+  static const int target = getenv("LASR_BN_SLICED") ? atoi(getenv("LASR_BN_SLICED")) : 256;
+  if (target <= 0 || dtype != LASR_BF16 || se || drop || per_utt || reduced_sums || C % kSlCh != 0 || rows < 4096) return 0;
+  const int64_t slices = C / kSlCh;
+  const int64_t nchunk = std::max<int64_t>(1, target / slices);
+  return (int)cdiv(rows, nchunk);
+}
 
 }  // namespace lasr
 
@@ -724,6 +932,16 @@ static int bn_bwd_stats_impl(const void* dout, const void* y, const float* coef,
   const int64_t rows = B * T_;
   const int nblk = per_utt ? (int)(B * cdiv(T_, kRowsPerBlock)) : (int)cdiv(rows, kRowsPerBlock);
   if (workspace_bytes < (size_t)nblk * 4 * C * sizeof(float)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_stats: workspace");
+  if (const int rpc = bn_sliced_rpc(dtype, rows, C, se_scale != nullptr, da.step != nullptr, per_utt, sums != nullptr)) {
+    const dim3 grid((unsigned)(C / kSlCh), (unsigned)cdiv(rows, rpc));
+    float* partials = reinterpret_cast<float*>(workspace);
+    if (y2) hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<true>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
+                               coef, saved, (const bf16_t*)y2, coef2, saved2, partials, (int)rows, (int)C, act, rpc);
+    else hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<false>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
+                            coef, saved, (const bf16_t*)y2, coef2, saved2, partials, (int)rows, (int)C, act, rpc);
+    LASR_LAUNCH_CHECK("bn_bwd_stats_sliced_kernel");
+    return 0;
+  }
   const int cv = (int)(C / (dtype == LASR_F32 ? 4 : 8));
   const int col_threads = cv < 256 ? cv : 256;
   const int row_lanes = 256 / col_threads;
@@ -780,6 +998,21 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
   LASR_TRY(check_bn_shape("lasr_bn_act_bwd_apply", dtype, B, T_, C));
   const int64_t rows = B * T_;
   hipStream_t st = as_stream(stream);
+  if (const int rpc = bn_sliced_rpc(dtype, rows, C, se_scale != nullptr, da.step != nullptr, 0, sums != nullptr)) {
+    if (workspace_bytes < lasr_bn_bwd_workspace_bytes(B, T_, C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
+    LASR_CHECK_ARG(dgamma && dbeta && (!y2 || (dgamma2 && dbeta2)), "lasr_bn_act_bwd_apply: parameter-gradient pointers");
+    const int nchunk = (int)cdiv(rows, rpc);
+    const dim3 grid((unsigned)(C / kSlCh), (unsigned)nchunk);
+    const float* partials = reinterpret_cast<const float*>(workspace);
+    if (y2) hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
+                               partials, nchunk, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
+                               dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, act, rpc);
+    else hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<false>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
+                            partials, nchunk, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
+                            dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, act, rpc);
+    LASR_LAUNCH_CHECK("bn_bwd_apply_sliced_kernel");
+    return 0;
+  }
   float* tab;
   if (sums) {
     if (workspace_bytes < lasr_bn_bwd_apply_workspace_bytes(C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
@@ -793,7 +1026,7 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
     const int nblk = (int)cdiv(rows, kRowsPerBlock);
     const float* partials = reinterpret_cast<const float*>(workspace);
     tab = reinterpret_cast<float*>(workspace) + (size_t)nblk * 4 * C;
-    hipLaunchKernelGGL(bn_bwd_table_partials_kernel, dim3((unsigned)cdiv(C, 8)), dim3(256), 0, st, partials, nblk, coef, saved, gamma,
+    hipLaunchKernelGGL(bn_bwd_table_partials_kernel, dim3((unsigned)cdiv(C, 8)), dim3(1024), 0, st, partials, nblk, coef, saved, gamma,
                        y2 ? coef2 : nullptr, saved2, gamma2, 1.0f / (float)rows, (int)C, tab, dgamma, dbeta, dgamma2, dbeta2);
     LASR_LAUNCH_CHECK("bn_bwd_table_partials_kernel");
   }
