@@ -551,12 +551,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // statistics -> apply, nothing in between.  block = 8 column threads (16 bytes each) x 64 row lanes.
 static constexpr int kSlCh = 64, kSlThreads = 512, kSlLanes = 64;
 
-template <bool HAS2>
+// SE (ContextSE units): a chunk is one utterance (rpc = T'), so the excite scale of the thread's 8 channels is a register constant
+// and the partial rows ARE the per-utterance sums P[b][4][C] the excite backward starts from (sums of the gradient at the BN
+// output without the SE factors, as bn_bwd_stats_kernel(per_utt)).
+template <bool HAS2, bool SE>
 __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                   const float* __restrict__ coef, const float* __restrict__ saved,
                                                                   const bf16_t* __restrict__ y2, const float* __restrict__ coef2,
-                                                                  const float* __restrict__ saved2, float* __restrict__ partials,
-                                                                  int rows, int C, int act, int rpc) {
+                                                                  const float* __restrict__ saved2, const float* __restrict__ se,
+                                                                  float* __restrict__ partials, int rows, int C, int act, int rpc) {
   __shared__ float s_red[8][4][kSlCh];
   constexpr int V = 8, RB = 4;
   const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3, lane = tid & 63, wid = tid >> 6;
@@ -570,6 +573,8 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
 #pragma unroll
     for (int j = 0; j < V; ++j) a2[j] = b2[j] = m2[j] = q2[j] = 0.f;
   }
+  float sev[V];
+  if (SE) lds_vec8(se + (size_t)blockIdx.y * C + c, sev);
   float acc[4][V];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
       const float live = rb + i * kSlLanes < r1 ? 1.f : 0.f;
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const float z = fmaf(yvi[j], a1[j], b1[j]) + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
+        const float z = fmaf(yvi[j], a1[j], b1[j]) * (SE ? sev[j] : 1.f) + (HAS2 ? fmaf(rvi[j], a2[j], b2[j]) : 0.f);
         const float d = dvi[j] * act_grad(z, act) * live;
         acc[0][j] += d;
         acc[1][j] = fmaf(d, (yvi[j] - m1[j]) * q1[j], acc[1][j]);
@@ -629,10 +634,14 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
   }
 }
 
-template <bool HAS2>
+// SE: the constants come folded from the excite backward (tab_in [10][C], se_bwd_pool_kernel); d1 = d*se + seg with the
+// utterance's scale and pooled-path gradient as register constants (a chunk is one utterance).
+template <bool HAS2, bool SE>
 __global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                   const bf16_t* __restrict__ y2, const float* __restrict__ partials,
-                                                                  int nchunk, const float* __restrict__ coef, const float* __restrict__ saved,
+                                                                  int nchunk, const float* __restrict__ tab_in, const float* __restrict__ se,
+                                                                  const float* __restrict__ seg, const float* __restrict__ coef,
+                                                                  const float* __restrict__ saved,
                                                                   const float* __restrict__ gamma, const float* __restrict__ coef2,
                                                                   const float* __restrict__ saved2, const float* __restrict__ gamma2,
                                                                   float inv_n, const int32_t* __restrict__ row_lens, bf16_t* __restrict__ dy,
@@ -644,48 +653,54 @@ __global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* 
   constexpr int V = 8;
   const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
   const int c0 = blockIdx.x * kSlCh;
-  if (tid < 4 * kSlCh) {                               // waves 0-3: the slice's four sums over the chunks, f64, fixed order
-    const int k = tid >> 6, ch = tid & 63;
-    double a0 = 0.0, a1 = 0.0;
-    if (k < 2 || HAS2) {
-      const float* p = partials + (size_t)k * C + c0 + ch;
-      for (int q = 0; q < nchunk; q += 16) {
-        float v[16];
+  if (SE) {
+    for (int i = tid; i < 10 * kSlCh; i += kSlThreads) s_tab[i >> 6][i & 63] = tab_in[(size_t)(i >> 6) * C + c0 + (i & 63)];
+  } else {
+    if (tid < 4 * kSlCh) {                               // waves 0-3: the slice's four sums over the chunks, f64, fixed order
+      const int k = tid >> 6, ch = tid & 63;
+      double a0 = 0.0, a1 = 0.0;
+      if (k < 2 || HAS2) {
+        const float* p = partials + (size_t)k * C + c0 + ch;
+        for (int q = 0; q < nchunk; q += 16) {
+          float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float x = p[(size_t)min(q + i, nchunk - 1) * 4 * C];
-          v[i] = q + i < nchunk ? x : 0.f;
+          for (int i = 0; i < 16; ++i) {
+            const float x = p[(size_t)min(q + i, nchunk - 1) * 4 * C];
+            v[i] = q + i < nchunk ? x : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) { a0 += (double)v[i]; a1 += (double)v[i + 1]; }
         }
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) { a0 += (double)v[i]; a1 += (double)v[i + 1]; }
       }
+      s_sum[k][ch] = a0 + a1;
     }
-    s_sum[k][ch] = a0 + a1;
-  }
-  __syncthreads();
-  if (tid < kSlCh) {                                   // the constants of pass 2a (bn_bwd_table_channel), kept in LDS
-    const int c = c0 + tid;
-    const float s1 = (float)s_sum[0][tid], s2 = (float)s_sum[1][tid];
-    {
-      const float q = saved[C + c], w = s2 * inv_n, G = gamma[c] * q;
-      s_tab[0][tid] = coef[c]; s_tab[1][tid] = coef[C + c]; s_tab[2][tid] = G; s_tab[3][tid] = -G * q * w;
-      s_tab[4][tid] = G * (saved[c] * q * w - s1 * inv_n);
-      if (blockIdx.y == 0) { dbeta[c] = s1; dgamma[c] = s2; }
-    }
-    if (HAS2) {
-      const float s1b = (float)s_sum[2][tid], s2b = (float)s_sum[3][tid];
-      const float q = saved2[C + c], w = s2b * inv_n, G = gamma2[c] * q;
-      s_tab[5][tid] = coef2[c]; s_tab[6][tid] = coef2[C + c]; s_tab[7][tid] = G; s_tab[8][tid] = -G * q * w;
-      s_tab[9][tid] = G * (saved2[c] * q * w - s1b * inv_n);
-      if (blockIdx.y == 0) { dbeta2[c] = s1b; dgamma2[c] = s2b; }
-    } else {
+    __syncthreads();
+    if (tid < kSlCh) {                                   // the constants of pass 2a (bn_bwd_table_channel), kept in LDS
+      const int c = c0 + tid;
+      const float s1 = (float)s_sum[0][tid], s2 = (float)s_sum[1][tid];
+      {
+        const float q = saved[C + c], w = s2 * inv_n, G = gamma[c] * q;
+        s_tab[0][tid] = coef[c]; s_tab[1][tid] = coef[C + c]; s_tab[2][tid] = G; s_tab[3][tid] = -G * q * w;
+        s_tab[4][tid] = G * (saved[c] * q * w - s1 * inv_n);
+        if (blockIdx.y == 0) { dbeta[c] = s1; dgamma[c] = s2; }
+      }
+      if (HAS2) {
+        const float s1b = (float)s_sum[2][tid], s2b = (float)s_sum[3][tid];
+        const float q = saved2[C + c], w = s2b * inv_n, G = gamma2[c] * q;
+        s_tab[5][tid] = coef2[c]; s_tab[6][tid] = coef2[C + c]; s_tab[7][tid] = G; s_tab[8][tid] = -G * q * w;
+        s_tab[9][tid] = G * (saved2[c] * q * w - s1b * inv_n);
+        if (blockIdx.y == 0) { dbeta2[c] = s1b; dgamma2[c] = s2b; }
+      } else {
 #pragma unroll
-      for (int k = 5; k < 10; ++k) s_tab[k][tid] = 0.f;
+        for (int k = 5; k < 10; ++k) s_tab[k][tid] = 0.f;
+      }
     }
   }
   __syncthreads();
   const int c = c0 + cl * V;
   const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, rows);
+  float sev[V], sgv[V];
+  if (SE) { lds_vec8(se + (size_t)blockIdx.y * C + c, sev); lds_vec8(seg + (size_t)blockIdx.y * C + c, sgv); }
   for (int rb = r0 + rl; rb < r1; rb += 2 * kSlLanes) {
     uint4 rd[2], ry[2], rr2[2];
     uint32_t off[2];
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* 
       float ca[V], cb[V], G[V], Bc[V], Cc[V], z[V], d[V];
       lds_vec8(&s_tab[0][cl * V], ca); lds_vec8(&s_tab[1][cl * V], cb);
 #pragma unroll
-      for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], ca[j], cb[j]);
+      for (int j = 0; j < V; ++j) z[j] = fmaf(yv[j], ca[j], cb[j]) * (SE ? sev[j] : 1.f);
       if (HAS2) {
         lds_vec8(&s_tab[5][cl * V], ca); lds_vec8(&s_tab[6][cl * V], cb);
 #pragma unroll
@@ -720,7 +735,10 @@ __global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* 
       for (int j = 0; j < V; ++j) d[j] = dv[j] * act_grad(z[j], act);
       lds_vec8(&s_tab[2][cl * V], G); lds_vec8(&s_tab[3][cl * V], Bc); lds_vec8(&s_tab[4][cl * V], Cc);
 #pragma unroll
-      for (int j = 0; j < V; ++j) o1[j] = masked ? 0.f : fmaf(G[j], d[j], fmaf(Bc[j], yv[j], Cc[j]));
+      for (int j = 0; j < V; ++j) {
+        const float d1 = SE ? fmaf(d[j], sev[j], sgv[j]) : d[j];
+        o1[j] = masked ? 0.f : fmaf(G[j], d1, fmaf(Bc[j], yv[j], Cc[j]));
+      }
       if (live) Vec<bf16_t>::store(dy + off[u], o1);
       if (HAS2) {
         lds_vec8(&s_tab[7][cl * V], G); lds_vec8(&s_tab[8][cl * V], Bc); lds_vec8(&s_tab[9][cl * V], Cc);
@@ -935,10 +953,10 @@ static int bn_bwd_stats_impl(const void* dout, const void* y, const float* coef,
   if (const int rpc = bn_sliced_rpc(dtype, rows, C, se_scale != nullptr, da.step != nullptr, per_utt, sums != nullptr)) {
     const dim3 grid((unsigned)(C / kSlCh), (unsigned)cdiv(rows, rpc));
     float* partials = reinterpret_cast<float*>(workspace);
-    if (y2) hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<true>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
-                               coef, saved, (const bf16_t*)y2, coef2, saved2, partials, (int)rows, (int)C, act, rpc);
-    else hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<false>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
-                            coef, saved, (const bf16_t*)y2, coef2, saved2, partials, (int)rows, (int)C, act, rpc);
+    if (y2) hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<true, false>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
+                               coef, saved, (const bf16_t*)y2, coef2, saved2, nullptr, partials, (int)rows, (int)C, act, rpc);
+    else hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<false, false>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
+                            coef, saved, (const bf16_t*)y2, coef2, saved2, nullptr, partials, (int)rows, (int)C, act, rpc);
     LASR_LAUNCH_CHECK("bn_bwd_stats_sliced_kernel");
     return 0;
   }
@@ -1004,11 +1022,11 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
     const int nchunk = (int)cdiv(rows, rpc);
     const dim3 grid((unsigned)(C / kSlCh), (unsigned)nchunk);
     const float* partials = reinterpret_cast<const float*>(workspace);
-    if (y2) hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
-                               partials, nchunk, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
+    if (y2) hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<true, false>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
+                               partials, nchunk, nullptr, nullptr, nullptr, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
                                dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, act, rpc);
-    else hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<false>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
-                            partials, nchunk, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
+    else hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<false, false>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
+                            partials, nchunk, nullptr, nullptr, nullptr, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
                             dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, act, rpc);
     LASR_LAUNCH_CHECK("bn_bwd_apply_sliced_kernel");
     return 0;
@@ -1085,6 +1103,32 @@ extern "C" int lasr_bn_se_bwd(const void* dout, const void* y, const float* coef
   float* tab = reinterpret_cast<float*>(w);
   w += align_up((size_t)10 * C * sizeof(float), 256);
   void* se_work = w;
+  // channel-sliced form: one workgroup per (64 channels, utterance) in both passes - the statistics pass then leaves the
+  // per-utterance sums themselves (nslab = 1: nothing for the excite backward to fold)
+  static const bool se_sliced_off = getenv("LASR_BN_SLICED") && atoi(getenv("LASR_BN_SLICED")) <= 0;
+  const bool sliced = !se_sliced_off && dtype == LASR_BF16 && !(dropout && dropout->step && dropout->p > 0.f) && C % kSlCh == 0 &&
+                      B * (C / kSlCh) >= 128 && T_ >= 64;
+  if (sliced) {
+    const dim3 grid((unsigned)(C / kSlCh), (unsigned)B);
+    if (y2) hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<true, true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, coef,
+                               saved, (const bf16_t*)y2, coef2, saved2, se_scale, partials, (int)(B * T_), (int)C, act, (int)T_);
+    else hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<false, true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, coef,
+                            saved, (const bf16_t*)y2, coef2, saved2, se_scale, partials, (int)(B * T_), (int)C, act, (int)T_);
+    LASR_LAUNCH_CHECK("bn_bwd_stats_sliced_kernel");
+    SeBwdBn bn;
+    bn.partials = partials; bn.nslab = 1; bn.gamma = gamma; bn.beta = beta; bn.ysum = ysum;
+    bn.coef = coef; bn.saved = saved; bn.coef2 = y2 ? coef2 : nullptr; bn.saved2 = saved2; bn.gamma2 = gamma2;
+    bn.inv_n = 1.0f / (float)(B * T_); bn.tab = tab; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.dgamma2 = dgamma2; bn.dbeta2 = dbeta2;
+    LASR_TRY(launch_se_bwd(nullptr, &bn, se_scale, se_hidden, se_pooled, W1, W2, B, T_, C, seg_out, dW1, dW2, se_work, st));
+    if (y2) hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<true, true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y,
+                               (const bf16_t*)y2, nullptr, 0, tab, se_scale, seg_out, coef, saved, gamma, coef2, saved2, gamma2, 0.f, row_lens,
+                               (bf16_t*)dy, (bf16_t*)dy2, dgamma, dbeta, dgamma2, dbeta2, (int)(B * T_), (int)T_, (int)C, act, (int)T_);
+    else hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<false, true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y,
+                            (const bf16_t*)y2, nullptr, 0, tab, se_scale, seg_out, coef, saved, gamma, coef2, saved2, gamma2, 0.f, row_lens,
+                            (bf16_t*)dy, (bf16_t*)dy2, dgamma, dbeta, dgamma2, dbeta2, (int)(B * T_), (int)T_, (int)C, act, (int)T_);
+    LASR_LAUNCH_CHECK("bn_bwd_apply_sliced_kernel");
+    return 0;
+  }
   // pass 1: raw per-(utterance, slab) sums (the SE scale enters the pre-activation z only)
   LASR_TRY(bn_bwd_stats_impl(dout, y, coef, saved, y2, coef2, saved2, se_scale, nullptr, nullptr, nullptr, dtype, B, T_, C, act, dropout,
                              partials, (size_t)B * nslab * 4 * C * sizeof(float), stream, 1));
