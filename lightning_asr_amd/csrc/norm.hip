@@ -757,7 +757,9 @@ static int bn_sliced_rpc(int dtype, int64_t rows, int64_t C, bool se, bool drop,
   static const int target = getenv("LASR_BN_SLICED") ? atoi(getenv("LASR_BN_SLICED")) : 256;
   if (target <= 0 || dtype != LASR_BF16 || se || drop || per_utt || reduced_sums || C % kSlCh != 0 || rows < 4096) return 0;
   const int64_t slices = C / kSlCh;
-  const int64_t nchunk = std::max<int64_t>(1, target / slices);
+  // at least one row per row lane in a chunk: the partial rows ([nchunk][4][C]) then also fit the workspace the row-major pair
+  // is sized for ([rows / 32][4][C])
+  const int64_t nchunk = std::max<int64_t>(1, std::min<int64_t>(target / slices, rows / kSlLanes));
   return (int)cdiv(rows, nchunk);
 }
 

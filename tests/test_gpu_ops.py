@@ -925,3 +925,48 @@ def test_se_layer_fwd_bwd_batched(dev, B, T, C, dtype, has_res):
     assert rel(seg, seg_ref) < 2e-5, rel(seg, seg_ref)
     assert rel(dW1, W1d.grad) < 2e-5, rel(dW1, W1d.grad)
     assert rel(dW2, W2d.grad) < 2e-5, rel(dW2, W2d.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,has_res,masked", [(32, 501, 512, True, True), (16, 300, 256, True, False), (8, 801, 1024, False, False),
+                                                  (5, 1000, 64, True, True)])
+def test_bn_bwd_channel_sliced_pair_equals_row_major_pair(dev, B, T, C, has_res, masked):
+    """The channel-sliced BN backward (workgroup = 64 channels x a chunk of rows, constants folded in the apply pass's prologue: no
+    table launch) against the row-major pair with its reduced sums, on the same bf16 tensors: same arithmetic per element, the
+    channel sums only differ in summation order.  Shapes with >= 4096 rows take the sliced kernels (sums = NULL path)."""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(B + T + C)
+    N = B * T
+    assert N >= 4096
+    y = torch.randn(B, T, C, generator=g).bfloat16().to(dev)
+    y2 = torch.randn(B, T, C, generator=g).bfloat16().to(dev) if has_res else None
+    dout = torch.randn(B, T, C, generator=g).bfloat16().to(dev)
+    lens = torch.randint(T // 3, T + 1, (B,), generator=g).int().to(dev) if masked else None
+    gam = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    bet = (0.1 * torch.randn(C, generator=g)).to(dev)
+    gam2 = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    bet2 = (0.1 * torch.randn(C, generator=g)).to(dev)
+
+    def stats_of(t):
+        f = t.reshape(N, C).double()
+        return torch.cat([f.sum(0), (f * f).sum(0)]).float()
+    coef, saved = ops.bn_finalize(stats_of(y), gam, bet, torch.zeros(C, device=dev), torch.ones(C, device=dev), N)
+    coef2 = saved2 = None
+    if has_res:
+        coef2, saved2 = ops.bn_finalize(stats_of(y2), gam2, bet2, torch.zeros(C, device=dev), torch.ones(C, device=dev), N)
+    a = ops.bn_act_bwd(dout, y, coef, saved, gam, y2, coef2, saved2, gam2 if has_res else None, row_lens=lens, act="relu", fused=False)
+    b = ops.bn_act_bwd(dout, y, coef, saved, gam, y2, coef2, saved2, gam2 if has_res else None, row_lens=lens, act="relu", fused=True)
+    names = ["dy", "dy2", "dgamma", "dbeta", "dgamma2", "dbeta2"]
+    for name, ta, tb in zip(names, a, b):
+        if ta is None:
+            assert tb is None
+            continue
+        r = rel_l2(tb.float(), ta.float().cpu())
+        if name.startswith("dy"):
+            # bf16 outputs: equal except where the constants' last bits move a value across a rounding boundary
+            assert r < 3e-4, (name, r)
+            if masked and name == "dy":
+                keep = (torch.arange(T, device=dev).view(1, T) < lens.view(B, 1))
+                assert (tb[~keep] == 0).all()
+        else:
+            assert r < 2e-6, (name, r)
