@@ -58,6 +58,25 @@ int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dit
                  int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,
                  int32_t* frames_out, float* pct_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* lasr_mel_fwd with the samples as they sit in the wav file and the dither drawn on the device:
+ *   wave_dtype LASR_WAVE_PCM16: wave is (B, L) int16 PCM; the kernel scales by 1/32768 (exact in f32 - the values
+ *     torchaudio.load's normalisation hands data_module.py:153), so the H2D copy moves half the bytes;
+ *   dither != NULL: explicit (B, L) N(0,1) noise, as lasr_mel_fwd;
+ *   dither == NULL and dither_step != NULL: `y += 1e-5 * randn_like(y)` (data_module.py:155) is generated inside the kernel -
+ *     Philox4x32-10 keyed by dither_seed with counter (sample / 4, utterance, *dither_step), Box-Muller - and *dither_step
+ *     (device scalar, uint64) is incremented by the call, so a step replayed from a hipGraph draws fresh noise;
+ *   both NULL: no dither.
+ * lasr_dither_noise writes the noise a call with the same (seed, *step) uses: out (B, L) f32 (verification; the counter is
+ * left untouched).                                                                                                   */
+enum { LASR_WAVE_F32 = 0, LASR_WAVE_PCM16 = 1 };
+typedef struct {
+  const void* wave; int32_t wave_dtype; const float* dither; uint64_t dither_seed; uint64_t* dither_step;
+} lasr_wave_src;
+int lasr_mel_fwd_src(const lasr_wave_src* src, const int32_t* sample_lens, const int32_t* aug, int64_t B, int64_t L,
+                     int normalize, float* out_bft, void* out_btf, int dtype, int32_t* frames_out, float* pct_out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int lasr_dither_noise(uint64_t seed, const uint64_t* step, int64_t B, int64_t L, float* out, void* stream);
+
 /* (B, C, T) f32 reference layout -> [B][T][C] channels-last `dtype`   (models/QuartNet.py:154 squeeze) */
 int lasr_bct_to_btc(const float* in, void* out, int dtype, int64_t B, int64_t C, int64_t T, void* stream);
 int lasr_btc_to_bct(const void* in, int dtype, float* out, int64_t B, int64_t C, int64_t T, void* stream);
@@ -350,8 +369,12 @@ int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float*
  * roofline leg; off by default, costs two event records per instrumented launch when on).
  * lasr_prof_collect synchronises the recorded events and returns, per class: summed milliseconds,
  * summed algorithmic FLOPs and bytes (operands + result, each counted once) and launch count.     */
-#define LASR_PROF_KINDS 4
-enum { LASR_PROF_GEMM = 0, LASR_PROF_DWCONV = 1, LASR_PROF_BN = 2, LASR_PROF_OTHER = 3 };
+#define LASR_PROF_KINDS 5
+enum { LASR_PROF_GEMM = 0,    /* every 1x1-conv GEMM launch (forward, data gradient, weight gradient, decoder) */
+       LASR_PROF_DWCONV = 1,  /* depthwise conv forward / fused backward */
+       LASR_PROF_BN = 2,      /* BatchNorm finalize + apply (+SE) forward, statistics + apply backward: one bracket per unit and direction */
+       LASR_PROF_HEAD = 3,    /* log_softmax / CTC lattice + gradient (+ the next batch's features in its grid) / bias sums / loss mean */
+       LASR_PROF_OTHER = 4 }; /* weight casts, length masks, deferred reductions, BiLSTM, column copies */
 int lasr_prof_enable(int on);
 int lasr_prof_collect(double* ms, double* flops, double* bytes, int64_t* count);
 /* mean elapsed ms of n empty event pairs on `stream`: the bracketing overhead included in every ms[] entry */
@@ -393,6 +416,11 @@ void lasr_model_destroy(lasr_model_t* m);
 int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
                             const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
                             int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes);
+/* the same with a lasr_wave_src (int16 PCM, dither generated on the device) */
+int lasr_model_set_prefetch_src(lasr_model_t* m, const lasr_wave_src* src, const int32_t* sample_lens, const int32_t* aug,
+                                int64_t B, int64_t L, int normalize, void* out_btf, int dtype, int32_t* frames_out,
+                                float* pct_out, void* mel_workspace, size_t mel_workspace_bytes);
+int lasr_model_clear_prefetch(lasr_model_t* m);   /* forget an armed request */
 /* Tensors in reference state_dict order.  kind: 0 = parameter (lives in the flat param buffer at
  * `offset` elements), 1 = f32 buffer (running_mean/var, flat buffer array), 2 = num_batches_tracked
  * (int64, kept by the host).  Returns the number of tensors; fills row i when i >= 0.            */
@@ -479,6 +507,26 @@ int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* row_stat, c
 int lasr_edit_distance_batch(const int32_t* hyp_tokens, const int32_t* hyp_lens, int64_t ld_hyp, const int64_t* ref_tokens,
                              const int32_t* ref_lens, int64_t ld_ref, int64_t B, int space_id, int32_t* dist, int32_t* ref_units,
                              int64_t* totals, void* stream);
+
+/* One training step's logged scalars (train.py:79-81: self.log('train_loss', loss) / self.log('train_wer', wer), on_step +
+ * on_epoch) folded into DEVICE accumulators, so logging costs no D2H per step: with wer = sum(dist) / sum(ref_units) of the batch
+ * (utils/asr_metrics.py:225-228; inf when the batch has no reference units),
+ *   acc[0] += loss, acc[1] += wer, acc[2] += 1, acc[3] = loss, acc[4] = wer, acc[5] += sum(dist), acc[6] += sum(ref_units)
+ * (7 doubles).  The host reads acc when it logs (every log_every_n_steps steps and at the end of the epoch).               */
+int lasr_step_metrics(const float* loss, const int32_t* dist, const int32_t* ref_units, int64_t B, double* acc, void* stream);
+
+/* ---- host ingest: wav files -> one int16 batch buffer -------------------------------------------------------------------
+ * Replaces torchaudio.load in the reference's DataLoader workers (data_module.py:153; conf/conf.yaml:14 num_worker) and the
+ * training-time random sub-sequence (data_module.py:138-148,158-159): n 16-bit PCM RIFF/WAVE files are decoded by up to
+ * n_threads host threads straight into `out` (typically a pinned buffer) as rows of channel-0 samples,
+ *   out[i][0 .. lens_out[i]) = the file's samples (or its crop), zeros up to the row pitch *ld_out = max length rounded up to 8,
+ * ready for ONE H2D copy and lasr_mel_fwd_src(LASR_WAVE_PCM16).  crop_u (n, 2) doubles in [0,1) or NULL: per file,
+ *   target = int(length * (crop_weight + (1 - crop_weight) * u0)); first = int(u1 * (length - target)); slice [first, target)
+ * - the reference's sub_secquence, slice end included as it is there.  expect_rate > 0: fail on another sample rate.
+ * No device work; returns LASR_E_WORKSPACE when n * ld exceeds out_capacity (elements).                                 */
+int lasr_wav_info(const char* path, int64_t* n_frames, int32_t* n_channels, int32_t* sample_rate, int32_t* bits);
+int lasr_wav_read_batch(const char* const* paths, int64_t n, const double* crop_u, double crop_weight, int16_t* out,
+                        int64_t out_capacity, int64_t* ld_out, int32_t* lens_out, int32_t expect_rate, int n_threads);
 
 /* ---- data-parallel gradient exchange: RCCL over xGMI, called by the library itself ------------------------------
  * Replaces the NCCL all-reduce the reference gets from Lightning's DDP plugin (conf/conf.yaml:30-31 `accelerator: ddp`,

@@ -20,6 +20,15 @@ class Dropout(C.Structure):
     _fields_ = [("step", C.c_void_p), ("seed", C.c_uint64), ("unit", C.c_uint32), ("p", C.c_float)]
 
 
+class WaveSrc(C.Structure):
+    """lasr_wave_src: samples (f32 or int16 PCM) + explicit dither noise or (seed, device step counter) for generated noise"""
+    _fields_ = [("wave", C.c_void_p), ("wave_dtype", C.c_int32), ("dither", C.c_void_p), ("dither_seed", C.c_uint64),
+                ("dither_step", C.c_void_p)]
+
+
+WAVE_F32, WAVE_PCM16 = 0, 1
+
+
 class ModelConfig(C.Structure):
     _fields_ = [("variant", C.c_int32), ("n_class", C.c_int32), ("in_c", C.c_int32),
                 ("mask", C.c_int32), ("act", C.c_int32), ("dtype", C.c_int32)]
@@ -32,6 +41,8 @@ SIGNATURES = {
     "lasr_mel_num_frames": (_i64, [_i64]),
     "lasr_mel_workspace_bytes": (_sz, [_i64, _i64]),
     "lasr_mel_fwd": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _p, _sz, _p]),
+    "lasr_mel_fwd_src": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _p, _sz, _p]),
+    "lasr_dither_noise": (_i32, [C.c_uint64, _p, _i64, _i64, _p, _p]),
     "lasr_bct_to_btc": (_i32, [_p, _p, _i32, _i64, _i64, _i64, _p]),
     "lasr_btc_to_bct": (_i32, [_p, _i32, _p, _i64, _i64, _i64, _p]),
     "lasr_mask_lengths": (_i32, [_p, _i64, _i64, _p, _p]),
@@ -89,6 +100,8 @@ SIGNATURES = {
     "lasr_model_create": (_i32, [C.POINTER(ModelConfig), C.POINTER(_p)]),
     "lasr_model_destroy": (None, [_p]),
     "lasr_model_set_prefetch": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _sz]),
+    "lasr_model_set_prefetch_src": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _i32, _p, _p, _p, _sz]),
+    "lasr_model_clear_prefetch": (_i32, [_p]),
     "lasr_model_tensor_info": (_i64, [_p, _i64, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.POINTER(_i64)]),
     "lasr_model_param_elems": (_i64, [_p]),
@@ -120,6 +133,9 @@ SIGNATURES = {
     "lasr_ctc_lean_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "lasr_ctc_loss_lean": (_i32, [_p, _i64, _p, _p, _i32, _p, _p, _p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "lasr_edit_distance_batch": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
+    "lasr_step_metrics": (_i32, [_p, _p, _p, _i64, _p, _p]),
+    "lasr_wav_info": (_i32, [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lasr_wav_read_batch": (_i32, [_p, _i64, _p, C.c_double, _p, _i64, C.POINTER(_i64), _p, C.c_int32, _i32]),
     "lasr_comm_unique_id": (_i32, [_p, _sz]),
     "lasr_comm_init": (_i32, [C.POINTER(_p), _p, _sz, _i32, _i32, _i32]),
     "lasr_comm_destroy": (_i32, [_p]),

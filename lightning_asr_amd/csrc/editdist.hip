@@ -127,9 +127,30 @@ __global__ __launch_bounds__(64) void edit_totals_kernel(const int32_t* __restri
   if (threadIdx.x == 0) { totals[0] += s; totals[1] += w; }
 }
 
+// one training step's logged scalars folded into device accumulators (no D2H per step)
+__global__ __launch_bounds__(64) void step_metrics_kernel(const float* __restrict__ loss, const int32_t* __restrict__ dist,
+                                                          const int32_t* __restrict__ ref_units, int64_t B, double* __restrict__ acc) {
+  long long s = 0, w = 0;
+  for (int64_t i = threadIdx.x; i < B; i += 64) { s += dist[i]; w += ref_units[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); w += __shfl_xor(w, o, 64); }
+  if (threadIdx.x == 0) {
+    const double wer = w != 0 ? (double)s / (double)w : (double)INFINITY;    // utils/asr_metrics.py:59 (inf when no reference units)
+    const double l = (double)loss[0];
+    acc[0] += l; acc[1] += wer; acc[2] += 1.0; acc[3] = l; acc[4] = wer; acc[5] += (double)s; acc[6] += (double)w;
+  }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
+
+extern "C" int lasr_step_metrics(const float* loss, const int32_t* dist, const int32_t* ref_units, int64_t B, double* acc, void* stream) {
+  LASR_CHECK_ARG(loss && dist && ref_units && acc && B > 0, "lasr_step_metrics: bad argument");
+  hipLaunchKernelGGL(step_metrics_kernel, dim3(1), dim3(64), 0, as_stream(stream), loss, dist, ref_units, B, acc);
+  LASR_LAUNCH_CHECK("step_metrics_kernel");
+  return 0;
+}
 
 extern "C" int lasr_edit_distance_batch(const int32_t* hyp_tokens, const int32_t* hyp_lens, int64_t ld_hyp, const int64_t* ref_tokens,
                                         const int32_t* ref_lens, int64_t ld_ref, int64_t B, int space_id, int32_t* dist, int32_t* ref_units,

@@ -9,6 +9,8 @@
 // channels-last store is a full 256-byte row per wave.
 #include "common.h"
 #include "ctc_lattice.h"
+#include "dropout.h"
+#include "mel.h"
 #include <math.h>
 #include <mutex>
 
@@ -20,6 +22,31 @@ static constexpr int kFramesPerBlock = 16;
 static constexpr int kWaves = 4;
 static constexpr int kSigLen = kFramesPerBlock * kHop + kNfft;   // 3072 samples staged per block
 static constexpr int kMaxBins = 24;   // widest triangular filter of the 64-band HTK bank over 257 bins is 20 bins (checked at init)
+
+static constexpr int kNoiseTab = kFramesPerBlock * kHop + kNfft + 8;   // 3080: the block's samples + the left neighbour, whole groups of 4
+
+// Dither noise generated in the kernel (data_module.py:155 `y += 1e-5 * randn_like(y)`): N(0,1) by Box-Muller from
+// Philox4x32-10 keyed by the seed, counter = (sample index / 4, utterance, step): one call serves 4 consecutive samples and
+// the values depend on nothing but (seed, step, b, j) - whatever grid computes them (lasr_dither_noise writes the same values).
+__device__ __forceinline__ void dither4(unsigned long long seed, unsigned long long step, uint32_t b, uint32_t grp, float (&z)[4]) {
+  uint32_t r[4];
+  philox4x32_10(grp, b, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed ^ 0x6d656c21u, (uint32_t)(seed >> 32), r);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    const float rad = sqrtf(-2.0f * __logf(u1));
+    const float ang = 6.28318530717958647692f * u2;
+    z[2 * h] = rad * __cosf(ang);
+    z[2 * h + 1] = rad * __sinf(ang);
+  }
+}
+__device__ __forceinline__ float dither1(unsigned long long seed, unsigned long long step, uint32_t b, int64_t j) {
+  float z[4];
+  dither4(seed, step, b, (uint32_t)(j >> 2), z);
+  const int q = (int)(j & 3);
+  return q == 0 ? z[0] : (q == 1 ? z[1] : (q == 2 ? z[2] : z[3]));
+}
 
 struct MelTables {
   double window[kWin];
@@ -117,8 +144,8 @@ struct MelSmem {
   float sig[kSigLen];
 };   // 55 872 bytes
 // (bx, by) of (nbx, B): frame tile and utterance - the kernel's own grid, or a slice of the fused feature + lattice grid
-__device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, const int32_t* __restrict__ sample_lens,
-                                            const float* __restrict__ dither, const int32_t* __restrict__ aug,
+__device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __restrict__ sample_lens,
+                                            const int32_t* __restrict__ aug,
                                             int64_t L, int64_t T, float* __restrict__ db_out,
                                             double* __restrict__ partials, int32_t* __restrict__ frames_out,
                                             float* __restrict__ pct_out, int bx, int by, int nbx, MelSmem& sm) {
@@ -135,8 +162,10 @@ __device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, cons
   const int64_t Lb = sample_lens ? (int64_t)sample_lens[b] : L;
   const int64_t Lp = Lb + 2 * kPad;
   const int64_t Tb = 1 + Lp / kHop;
-  const float* y = wave + (int64_t)b * L;
-  const float* nz = dither ? dither + (int64_t)b * L : nullptr;
+  const float* y = reinterpret_cast<const float*>(src.wave) + (int64_t)b * L;
+  const int16_t* y16 = reinterpret_cast<const int16_t*>(src.wave) + (int64_t)b * L;
+  const float* nz = src.dither ? src.dither + (int64_t)b * L : nullptr;
+  const bool gen = !nz && src.dstep != nullptr;      // noise generated here (workgroup-uniform)
   for (int i = threadIdx.x; i < kNfft; i += 256) { s_twr[i] = g_mel.tw_re[i]; s_twi[i] = g_mel.tw_im[i]; }
   for (int i = threadIdx.x; i < kWin; i += 256) s_win[i] = g_mel.window[i];
   // this lane's mel filter (lane = mel channel): its <= kMaxBins weights live in registers for all of the block's
@@ -162,7 +191,21 @@ __device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, cons
   {
     constexpr int kSigIt = kSigLen / 256;          // 12
     const int64_t i0 = (int64_t)bx * kFramesPerBlock * kHop - kNfft / 2;   // padded-signal index of s_sig[0]
+    // generated dither: the noise of utterance samples [jbase, jbase + kNoiseTab) goes through LDS first (one Philox call
+    // per 4 samples; the FFT rows are not in use yet), the few reflected samples outside that stretch are computed directly
+    float* s_nz = reinterpret_cast<float*>(&sm.re[0][0]);
+    const int64_t jbase = i0 - kPad - 4;           // a multiple of 4
+    const unsigned long long dstep = gen ? *src.dstep : 0ull;
+    if (gen) {
+      for (int g = threadIdx.x; g < kNoiseTab / 4; g += 256) {
+        float z[4];
+        dither4(src.dseed, dstep, (uint32_t)b, (uint32_t)((jbase >> 2) + g), z);
+        *reinterpret_cast<float4*>(s_nz + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+      }
+      __syncthreads();
+    }
     float cur[kSigIt], prv[kSigIt], ncur[kSigIt], nprv[kSigIt];
+    int64_t jcs[kSigIt], jps[kSigIt];
 #pragma unroll
     for (int u = 0; u < kSigIt; ++u) {
       int64_t i = i0 + threadIdx.x + 256 * u;
@@ -170,10 +213,34 @@ __device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, cons
       i = i >= Lp ? 2 * (Lp - 1) - i : i;
       const int64_t j = i - kPad;                           // index into the utterance
       const int64_t jmax = max(Lb - 1, (int64_t)0);
-      const int64_t jc = min(max(j, (int64_t)0), jmax), jp = min(max(j - 1, (int64_t)0), jmax);
-      cur[u] = y[jc]; prv[u] = y[jp];
-      ncur[u] = nz ? nz[jc] : 0.f; nprv[u] = nz ? nz[jp] : 0.f;
+      jcs[u] = min(max(j, (int64_t)0), jmax);
+      jps[u] = min(max(j - 1, (int64_t)0), jmax);
     }
+    if (src.pcm16) {   // 16-bit PCM as stored in the wav file: /32768 is exact in f32 (what torchaudio.load's normalisation yields)
+      int16_t c16[kSigIt], p16[kSigIt];
+#pragma unroll
+      for (int u = 0; u < kSigIt; ++u) { c16[u] = y16[jcs[u]]; p16[u] = y16[jps[u]]; }
+#pragma unroll
+      for (int u = 0; u < kSigIt; ++u) { cur[u] = (float)c16[u] * (1.0f / 32768.0f); prv[u] = (float)p16[u] * (1.0f / 32768.0f); }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kSigIt; ++u) { cur[u] = y[jcs[u]]; prv[u] = y[jps[u]]; }
+    }
+    if (nz) {
+#pragma unroll
+      for (int u = 0; u < kSigIt; ++u) { ncur[u] = nz[jcs[u]]; nprv[u] = nz[jps[u]]; }
+    } else if (gen) {
+#pragma unroll
+      for (int u = 0; u < kSigIt; ++u) {
+        const int64_t dc = jcs[u] - jbase, dp = jps[u] - jbase;
+        ncur[u] = (dc >= 0 && dc < kNoiseTab) ? s_nz[dc] : dither1(src.dseed, dstep, (uint32_t)b, jcs[u]);
+        nprv[u] = (dp >= 0 && dp < kNoiseTab) ? s_nz[dp] : dither1(src.dseed, dstep, (uint32_t)b, jps[u]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kSigIt; ++u) { ncur[u] = 0.f; nprv[u] = 0.f; }
+    }
+    const bool noisy = nz || gen;
 #pragma unroll
     for (int u = 0; u < kSigIt; ++u) {
       int64_t i = i0 + threadIdx.x + 256 * u;
@@ -182,7 +249,7 @@ __device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, cons
       const int64_t j = i - kPad;
       // f32 steps, as the reference computes them (data_module.py:155,157)
       float c = cur[u], p = prv[u];
-      if (nz) { c += 1e-5f * ncur[u]; p += 1e-5f * nprv[u]; }
+      if (noisy) { c += 1e-5f * ncur[u]; p += 1e-5f * nprv[u]; }
       const float v = j == 0 ? c : c - 0.97f * p;
       s_sig[threadIdx.x + 256 * u] = (j < 0 || j >= Lb || i < 0) ? 0.f : v;
     }
@@ -296,13 +363,13 @@ __device__ __forceinline__ void mel_db_body(const float* __restrict__ wave, cons
   }
 }
 
-__global__ __launch_bounds__(256) void mel_db_kernel(const float* __restrict__ wave, const int32_t* __restrict__ sample_lens,
-                                                     const float* __restrict__ dither, const int32_t* __restrict__ aug,
+__global__ __launch_bounds__(256) void mel_db_kernel(const WaveSrc src, const int32_t* __restrict__ sample_lens,
+                                                     const int32_t* __restrict__ aug,
                                                      int64_t L, int64_t T, float* __restrict__ db_out,
                                                      double* __restrict__ partials, int32_t* __restrict__ frames_out,
                                                      float* __restrict__ pct_out) {
   __shared__ MelSmem sm;
-  mel_db_body(wave, sample_lens, dither, aug, L, T, db_out, partials, frames_out, pct_out, blockIdx.x, blockIdx.y, gridDim.x, sm);
+  mel_db_body(src, sample_lens, aug, L, T, db_out, partials, frames_out, pct_out, blockIdx.x, blockIdx.y, gridDim.x, sm);
 }
 
 // The CTC lattice (one workgroup of two busy waves per utterance, ~0.1 ms of dependent steps) and the log-mel transform
@@ -314,7 +381,7 @@ struct MelCtcArgs {
   const float* logp; const int64_t* targets; const int32_t* in_lens; const int32_t* tgt_lens;
   int64_t T, C, S_max; int blank; float* alpha; float* beta; int32_t* next_same; float* nll; int n_ctc;
   // features
-  const float* wave; const int32_t* sample_lens; const float* dither; const int32_t* aug;
+  WaveSrc src; const int32_t* sample_lens; const int32_t* aug;
   int64_t L, Tm; float* db_out; double* partials; int32_t* frames_out; float* pct_out; int nbx;
 };
 template <int NS>
@@ -327,7 +394,7 @@ __global__ __launch_bounds__(256) void mel_ctc_kernel(MelCtcArgs a) {
                                        a.nll, (int)blockIdx.x, s_tg, s_lp);
   } else {
     const int id = (int)blockIdx.x - a.n_ctc;
-    mel_db_body(a.wave, a.sample_lens, a.dither, a.aug, a.L, a.Tm, a.db_out, a.partials, a.frames_out, a.pct_out, id % a.nbx, id / a.nbx,
+    mel_db_body(a.src, a.sample_lens, a.aug, a.L, a.Tm, a.db_out, a.partials, a.frames_out, a.pct_out, id % a.nbx, id / a.nbx,
                 a.nbx, *reinterpret_cast<MelSmem*>(smem_raw));
   }
 }
@@ -336,8 +403,11 @@ __global__ __launch_bounds__(256) void mel_ctc_kernel(MelCtcArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void mel_norm_kernel(const float* __restrict__ db, const double* __restrict__ partials,
                                                        const int32_t* __restrict__ frames, int64_t Tt, int nblk,
-                                                       int normalize, float* __restrict__ out_bft, T* __restrict__ out_btf) {
+                                                       int normalize, float* __restrict__ out_bft, T* __restrict__ out_btf,
+                                                       unsigned long long* __restrict__ dither_step) {
   __shared__ float tile[kFramesPerBlock][kMel + 1];
+  // generated dither: this batch's transform is done (the kernel runs behind it), the next call draws fresh noise
+  if (dither_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dither_step += 1ull;
   __shared__ float s_mu, s_rstd;
   const int b = blockIdx.y;
   const int64_t Tb = frames[b];
@@ -390,10 +460,34 @@ extern "C" size_t lasr_mel_workspace_bytes(int64_t B, int64_t T) {
   return align_up((size_t)B * T * kMel * sizeof(float), 256) + align_up((size_t)B * nblk * 2 * sizeof(double), 256);
 }
 
-extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dither, const int32_t* aug,
-                            int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,
-                            int32_t* frames_out, float* pct_out, void* workspace, size_t workspace_bytes, void* stream) {
-  LASR_CHECK_ARG(wave && frames_out && pct_out && workspace, "lasr_mel_fwd: null pointer");
+namespace lasr {
+
+int wave_src_from_c(const lasr_wave_src* s, WaveSrc* out, const char* who) {
+  LASR_CHECK_ARG(s && s->wave, "%s: null wave", who);
+  LASR_CHECK_ARG(s->wave_dtype == LASR_WAVE_F32 || s->wave_dtype == LASR_WAVE_PCM16, "%s: bad wave dtype %d", who, s->wave_dtype);
+  out->wave = s->wave;
+  out->pcm16 = s->wave_dtype == LASR_WAVE_PCM16;
+  out->dither = s->dither;
+  out->dstep = s->dither ? nullptr : reinterpret_cast<const unsigned long long*>(s->dither_step);
+  out->dseed = s->dither_seed;
+  return 0;
+}
+
+static void launch_norm(int dtype, dim3 grid, hipStream_t st, const float* db, const double* partials, const int32_t* frames_out, int64_t T,
+                        int nblk, int normalize, float* out_bft, void* out_btf, const WaveSrc& src) {
+  unsigned long long* bump = const_cast<unsigned long long*>(src.dstep);
+  if (dtype == LASR_F32)
+    hipLaunchKernelGGL(mel_norm_kernel<float>, grid, dim3(256), 0, st, db, partials, frames_out, T, nblk, normalize, out_bft,
+                       reinterpret_cast<float*>(out_btf), bump);
+  else
+    hipLaunchKernelGGL(mel_norm_kernel<bf16_t>, grid, dim3(256), 0, st, db, partials, frames_out, T, nblk, normalize, out_bft,
+                       reinterpret_cast<bf16_t*>(out_btf), bump);
+}
+
+int mel_fwd_src(const WaveSrc& src, const int32_t* sample_lens, const int32_t* aug, int64_t B, int64_t L, int normalize,
+                float* out_bft, void* out_btf, int dtype, int32_t* frames_out, float* pct_out, void* workspace,
+                size_t workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(src.wave && frames_out && pct_out && workspace, "lasr_mel_fwd: null pointer");
   LASR_CHECK_ARG(out_bft || out_btf, "lasr_mel_fwd: no output requested");
   LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_mel_fwd: bad dtype %d", dtype);
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && L >= 2 && L < (1ll << 30), "lasr_mel_fwd: B=%lld L=%lld", (long long)B, (long long)L);
@@ -404,26 +498,19 @@ extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const
   double* partials = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)B * T * kMel * sizeof(float), 256));
   const int nblk = (int)cdiv(T, kFramesPerBlock);
   dim3 grid(nblk, (unsigned)B);
-  hipLaunchKernelGGL(mel_db_kernel, grid, dim3(256), 0, as_stream(stream), wave, sample_lens, dither, aug, L, T, db,
-                     partials, frames_out, pct_out);
+  hipLaunchKernelGGL(mel_db_kernel, grid, dim3(256), 0, as_stream(stream), src, sample_lens, aug, L, T, db, partials, frames_out, pct_out);
   LASR_LAUNCH_CHECK("mel_db_kernel");
-  if (dtype == LASR_F32)
-    hipLaunchKernelGGL(mel_norm_kernel<float>, grid, dim3(256), 0, as_stream(stream), db, partials, frames_out, T, nblk,
-                       normalize, out_bft, reinterpret_cast<float*>(out_btf));
-  else
-    hipLaunchKernelGGL(mel_norm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), db, partials, frames_out, T, nblk,
-                       normalize, out_bft, reinterpret_cast<bf16_t*>(out_btf));
+  launch_norm(dtype, grid, as_stream(stream), db, partials, frames_out, T, nblk, normalize, out_bft, out_btf, src);
   LASR_LAUNCH_CHECK("mel_norm_kernel");
   return 0;
 }
 
-extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B,
-                                 int64_t T, int64_t C, int64_t S_max, int blank, float* nll, float* grad, const float* gscale,
-                                 void* ctc_workspace, size_t ctc_workspace_bytes, const float* wave, const int32_t* sample_lens,
-                                 const float* dither, const int32_t* aug, int64_t Bm, int64_t L, int normalize, float* out_bft,
-                                 void* out_btf, int dtype, int32_t* frames_out, float* pct_out, void* mel_workspace,
-                                 size_t mel_workspace_bytes, void* stream) {
-  LASR_CHECK_ARG(logp && targets && in_lens && tgt_lens && nll && ctc_workspace && wave && frames_out && pct_out && mel_workspace,
+int ctc_loss_mel_src(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T,
+                     int64_t C, int64_t S_max, int blank, float* nll, float* grad, const float* gscale, void* ctc_workspace,
+                     size_t ctc_workspace_bytes, const WaveSrc& src, const int32_t* sample_lens, const int32_t* aug, int64_t Bm,
+                     int64_t L, int normalize, float* out_bft, void* out_btf, int dtype, int32_t* frames_out, float* pct_out,
+                     void* mel_workspace, size_t mel_workspace_bytes, void* stream) {
+  LASR_CHECK_ARG(logp && targets && in_lens && tgt_lens && nll && ctc_workspace && src.wave && frames_out && pct_out && mel_workspace,
                  "lasr_ctc_loss_mel: null pointer");
   const int64_t sm = S_max > 0 ? S_max : 1;
   const size_t em_bytes = (size_t)(T + 2) * C * sizeof(float);
@@ -436,8 +523,8 @@ extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, cons
                      mel_workspace_bytes >= lasr_mel_workspace_bytes(Bm, lasr_mel_num_frames(L));
   if (!fused) {
     LASR_TRY(lasr_ctc_loss(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, ctc_workspace_bytes, stream));
-    return lasr_mel_fwd(wave, sample_lens, dither, aug, Bm, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, mel_workspace,
-                        mel_workspace_bytes, stream);
+    return mel_fwd_src(src, sample_lens, aug, Bm, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, mel_workspace,
+                       mel_workspace_bytes, stream);
   }
   LASR_CHECK_SHAPE(blank >= 0 && blank < C, "lasr_ctc_loss_mel: blank");
   LASR_TRY(init_tables());
@@ -449,7 +536,7 @@ extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, cons
   a.beta = a.alpha + ab;
   a.next_same = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctc_workspace) + align_up(2 * ab * sizeof(float), 256));
   a.nll = nll; a.n_ctc = (int)B;
-  a.wave = wave; a.sample_lens = sample_lens; a.dither = dither; a.aug = aug; a.L = L; a.Tm = Tm;
+  a.src = src; a.sample_lens = sample_lens; a.aug = aug; a.L = L; a.Tm = Tm;
   a.db_out = reinterpret_cast<float*>(mel_workspace);
   a.partials = reinterpret_cast<double*>(reinterpret_cast<char*>(mel_workspace) + align_up((size_t)Bm * Tm * kMel * sizeof(float), 256));
   a.frames_out = frames_out; a.pct_out = pct_out;
@@ -460,12 +547,56 @@ extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, cons
   LASR_LAUNCH_CHECK("mel_ctc_kernel");
   if (grad) LASR_TRY(launch_ctc_grad(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, stream));
   dim3 grid(nblk, (unsigned)Bm);
-  if (dtype == LASR_F32)
-    hipLaunchKernelGGL(mel_norm_kernel<float>, grid, dim3(256), 0, as_stream(stream), a.db_out, a.partials, frames_out, Tm, nblk, normalize,
-                       out_bft, reinterpret_cast<float*>(out_btf));
-  else
-    hipLaunchKernelGGL(mel_norm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), a.db_out, a.partials, frames_out, Tm, nblk, normalize,
-                       out_bft, reinterpret_cast<bf16_t*>(out_btf));
+  launch_norm(dtype, grid, as_stream(stream), a.db_out, a.partials, frames_out, Tm, nblk, normalize, out_bft, out_btf, src);
   LASR_LAUNCH_CHECK("mel_norm_kernel");
   return 0;
+}
+
+__global__ __launch_bounds__(256) void dither_noise_kernel(unsigned long long seed, const unsigned long long* __restrict__ step,
+                                                           int64_t L, float* __restrict__ out) {
+  const uint32_t b = blockIdx.y;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (4 * g >= L) return;
+  float z[4];
+  dither4(seed, *step, b, (uint32_t)g, z);
+  for (int q = 0; q < 4; ++q)
+    if (4 * g + q < L) out[(int64_t)b * L + 4 * g + q] = z[q];
+}
+
+}  // namespace lasr
+
+extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dither, const int32_t* aug,
+                            int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,
+                            int32_t* frames_out, float* pct_out, void* workspace, size_t workspace_bytes, void* stream) {
+  const WaveSrc src = {wave, 0, dither, nullptr, 0ull};
+  return mel_fwd_src(src, sample_lens, aug, B, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lasr_mel_fwd_src(const lasr_wave_src* wsrc, const int32_t* sample_lens, const int32_t* aug, int64_t B, int64_t L,
+                                int normalize, float* out_bft, void* out_btf, int dtype, int32_t* frames_out, float* pct_out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  WaveSrc src;
+  LASR_TRY(wave_src_from_c(wsrc, &src, "lasr_mel_fwd_src"));
+  return mel_fwd_src(src, sample_lens, aug, B, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int lasr_dither_noise(uint64_t seed, const uint64_t* step, int64_t B, int64_t L, float* out, void* stream) {
+  LASR_CHECK_ARG(step && out, "lasr_dither_noise: null pointer");
+  LASR_CHECK_SHAPE(B > 0 && B < 65536 && L >= 1 && L < (1ll << 30), "lasr_dither_noise: B=%lld L=%lld", (long long)B, (long long)L);
+  hipLaunchKernelGGL(dither_noise_kernel, dim3((unsigned)cdiv(cdiv(L, 4), 256), (unsigned)B), dim3(256), 0, as_stream(stream),
+                     (unsigned long long)seed, reinterpret_cast<const unsigned long long*>(step), L, out);
+  LASR_LAUNCH_CHECK("dither_noise_kernel");
+  return 0;
+}
+
+extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B,
+                                 int64_t T, int64_t C, int64_t S_max, int blank, float* nll, float* grad, const float* gscale,
+                                 void* ctc_workspace, size_t ctc_workspace_bytes, const float* wave, const int32_t* sample_lens,
+                                 const float* dither, const int32_t* aug, int64_t Bm, int64_t L, int normalize, float* out_bft,
+                                 void* out_btf, int dtype, int32_t* frames_out, float* pct_out, void* mel_workspace,
+                                 size_t mel_workspace_bytes, void* stream) {
+  const WaveSrc src = {wave, 0, dither, nullptr, 0ull};
+  return ctc_loss_mel_src(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, ctc_workspace_bytes, src,
+                          sample_lens, aug, Bm, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, mel_workspace,
+                          mel_workspace_bytes, stream);
 }

@@ -3,6 +3,7 @@
 // over caller-owned flat buffers.  No tracing, no autograd: the plan is static per (B, T_in), so
 // the whole step can be captured into a hipGraph by the host.
 #include "common.h"
+#include "mel.h"
 #include <string>
 #include <vector>
 #include <math.h>
@@ -125,7 +126,7 @@ struct lasr_model {
   // one-shot feature prefetch consumed by the next loss_backward call (lasr_model_set_prefetch)
   struct Prefetch {
     bool armed = false;
-    const float* wave; const int32_t* sample_lens; const float* dither; const int32_t* aug;
+    WaveSrc src; const int32_t* sample_lens; const int32_t* aug;
     int64_t B, L; int normalize; void* out_btf; int dtype; int32_t* frames_out; float* pct_out; void* ws; size_t ws_bytes;
   } prefetch;
 
@@ -343,18 +344,39 @@ extern "C" int lasr_model_set_dropout(lasr_model_t* m, float p, uint64_t seed, u
   return 0;
 }
 
-extern "C" int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
-                                       const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
-                                       int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes) {
-  LASR_CHECK_ARG(m && wave && out_btf && frames_out && pct_out && mel_workspace, "lasr_model_set_prefetch: null pointer");
+static int set_prefetch(lasr_model_t* m, const WaveSrc& src, const int32_t* sample_lens, const int32_t* aug, int64_t B, int64_t L,
+                        int normalize, void* out_btf, int dtype, int32_t* frames_out, float* pct_out, void* mel_workspace,
+                        size_t mel_workspace_bytes) {
+  LASR_CHECK_ARG(m && src.wave && out_btf && frames_out && pct_out && mel_workspace, "lasr_model_set_prefetch: null pointer");
   LASR_CHECK_ARG(dtype == LASR_F32 || dtype == LASR_BF16, "lasr_model_set_prefetch: bad dtype");
   LASR_CHECK_SHAPE(B > 0 && B < 65536 && L >= 2 && L < (1ll << 30), "lasr_model_set_prefetch: B=%lld L=%lld", (long long)B, (long long)L);
   if (mel_workspace_bytes < lasr_mel_workspace_bytes(B, lasr_mel_num_frames(L))) return fail(LASR_E_WORKSPACE, "lasr_model_set_prefetch: workspace");
   m->prefetch.armed = true;
-  m->prefetch.wave = wave; m->prefetch.sample_lens = sample_lens; m->prefetch.dither = dither; m->prefetch.aug = aug;
+  m->prefetch.src = src; m->prefetch.sample_lens = sample_lens; m->prefetch.aug = aug;
   m->prefetch.B = B; m->prefetch.L = L; m->prefetch.normalize = normalize; m->prefetch.out_btf = out_btf; m->prefetch.dtype = dtype;
   m->prefetch.frames_out = frames_out; m->prefetch.pct_out = pct_out; m->prefetch.ws = mel_workspace; m->prefetch.ws_bytes = mel_workspace_bytes;
   return 0;
+}
+
+extern "C" int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
+                                       const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
+                                       int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes) {
+  const WaveSrc src = {wave, 0, dither, nullptr, 0ull};
+  return set_prefetch(m, src, sample_lens, aug, B, L, normalize, out_btf, dtype, frames_out, pct_out, mel_workspace, mel_workspace_bytes);
+}
+
+extern "C" int lasr_model_clear_prefetch(lasr_model_t* m) {
+  LASR_CHECK_ARG(m, "lasr_model_clear_prefetch: null model");
+  m->prefetch.armed = false;
+  return 0;
+}
+
+extern "C" int lasr_model_set_prefetch_src(lasr_model_t* m, const lasr_wave_src* wsrc, const int32_t* sample_lens, const int32_t* aug,
+                                           int64_t B, int64_t L, int normalize, void* out_btf, int dtype, int32_t* frames_out,
+                                           float* pct_out, void* mel_workspace, size_t mel_workspace_bytes) {
+  WaveSrc src;
+  LASR_TRY(wave_src_from_c(wsrc, &src, "lasr_model_set_prefetch_src"));
+  return set_prefetch(m, src, sample_lens, aug, B, L, normalize, out_btf, dtype, frames_out, pct_out, mel_workspace, mel_workspace_bytes);
 }
 
 extern "C" int64_t lasr_model_tensor_info(const lasr_model_t* m, int64_t i, char* name, size_t name_cap, int64_t shape[4],
@@ -413,6 +435,13 @@ extern "C" int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, 
   return -1;
 }
 
+// bench.py's per-class table: one event pair around a group of consecutive launches of one class (off unless lasr_prof_enable(1))
+struct ProfScope {
+  int tok; hipStream_t st;
+  ProfScope(int kind, void* stream, double bytes) : tok(prof_begin(kind, as_stream(stream), 0.0, bytes)), st(as_stream(stream)) {}
+  ~ProfScope() { prof_end(tok, st); }
+};
+
 static inline char* at(void* ws, size_t off) { return reinterpret_cast<char*>(ws) + off; }
 static inline float* atf(void* ws, size_t off) { return reinterpret_cast<float*>(at(ws, off)); }
 
@@ -452,8 +481,11 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
   const int64_t T = p.T, N = B * T;
   int32_t* lens = reinterpret_cast<int32_t*>(at(ws, p.o_lens));
   const bool dropping = training && m->drop_p > 0.f;
-  LASR_TRY(lasr_mask_lengths_step(pct, B, T, lens, dropping ? m->drop_step : nullptr, stream));   // (bumps the masks' step counter)
-  if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
+  {
+    ProfScope ps(LASR_PROF_OTHER, stream, dt == LASR_BF16 ? 6.0 * m->n_param : 0.0);
+    LASR_TRY(lasr_mask_lengths_step(pct, B, T, lens, dropping ? m->drop_step : nullptr, stream));   // (bumps the masks' step counter)
+    if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
+  }
   void* scratch = at(ws, p.o_scratch);
   if (!training) {   // eval: BN coefficients of all layers from the running statistics, one launch
     std::vector<lasr_bn_eval_desc> descs;
@@ -520,6 +552,7 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
         if (u.has_res)
           br[1] = {parts[1], tiles[1], params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
                    buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), stats2};
+        ProfScope ps(LASR_PROF_BN, stream, 0.0);
         LASR_TRY(lasr_bn_finalize_partials(br, np, u.co, N, kBnEps, kBnMom, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, np, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
@@ -533,6 +566,7 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
         }
       }
     }
+    ProfScope ps_bn(LASR_PROF_BN, stream, (double)N * u.co * dtype_size(dt) * (u.has_res ? 3 : 2) + (u.has_se ? (double)N * u.co * dtype_size(dt) : 0.0));
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
       LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
       LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
@@ -558,6 +592,7 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
   const int dec_split = (dt == LASR_BF16 && C <= 128) ? dec_split_k() : 1;
   LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->w_dec), atf(ws, p.o_logits), dt, LASR_F32, N, C, 1024, 0, 0, params + m->b_dec,
                      nullptr, nullptr, 0, nullptr, dec_split, scratch, p.scratch_bytes, stream));
+  ProfScope ps(LASR_PROF_HEAD, stream, 2.0 * N * C * sizeof(float));
   LASR_TRY(lasr_log_softmax(atf(ws, p.o_logits), logp_out, argmax_out, N, C, stream));
   return 0;
 }
@@ -619,12 +654,16 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     gl_ab = at(ws, p.o_d1);
   } else if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient, rows padded to 16-byte multiples
     ld_gl = (C + 7) / 8 * 8;
+    ProfScope ps(LASR_PROF_HEAD, stream, (double)N * C * 6);
     LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
     gl_ab = at(ws, p.o_d1);
   }
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr,
                         dec_wgrad_split(C, N), scratch, sb, stream));
-  if (!m->lean_active) LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
+  if (!m->lean_active) {
+    ProfScope ps(LASR_PROF_HEAD, stream, (double)N * C * 4);
+    LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
+  }
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, wptr(m, params, ws, m->w_dec), 1024, at(ws, p.o_g[cur]), 1024, dt, dt, N, 1024, C, 0, 1, nullptr,
                         1, scratch, sb, stream));
   }
@@ -653,6 +692,8 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     const lasr_dropout* dq = m->drop_p > 0.f ? &drop : nullptr;
     static const bool se_unfused = getenv("LASR_SE_UNFUSED_BWD") != nullptr;    // A/B switch: the three-pass form
     const bool se_fused = u.has_se && !se_unfused && !no_fuse();
+    {   // BatchNorm (+ activation, residual add, SE) backward of the unit: two passes over (dout, y[, y2]), writes dy[, dy2]
+    ProfScope ps_bn(LASR_PROF_BN, stream, (double)N * u.co * dtype_size(dt) * (u.has_res ? 8 : 5));
     if (se_fused) {
       // SE units: statistics, SE-scale gradient, excite-MLP backward and BN apply in two passes over (dout, y, y2)
       LASR_TRY(lasr_bn_se_bwd(dout, at(ws, u.o_y), atf(ws, u.o_coef), atf(ws, u.o_saved), params + u.bn.gamma, params + u.bn.beta,
@@ -680,6 +721,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
                                         se_grad, fsum, fsum2, u.masked ? lens : nullptr, dy, dy2,
                                         grads + u.bn.gamma, grads + u.bn.beta, u.has_res ? grads + u.bn_res.gamma : nullptr,
                                         u.has_res ? grads + u.bn_res.beta : nullptr, dt, B, T, u.co, act, dq, scratch, sb, stream));
+    }
     }
     // weight gradients of the main and residual 1x1: dW[co][ci] = dy^T gin, dWr = dy2^T x  (one split-K launch)
     const void* gin = u.has_dw ? at(ws, u.o_u) : x_in;
@@ -762,7 +804,12 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     }
   }
   if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
-  if (!pending.empty()) LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));   // the stage's gradients are final
+  if (!pending.empty()) {   // the stage's gradients are final
+    double rb = 0;
+    for (const lasr_reduce_desc& d : pending) rb += (double)d.n * (d.n_partials + 1) * sizeof(float);
+    ProfScope ps(LASR_PROF_OTHER, stream, rb);
+    LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));
+  }
   m->bwd_cur = cur;
   m->bwd_next = unit_stop - 1;
   return 0;
@@ -800,6 +847,8 @@ static int forward_and_loss(lasr_model_t* m, const float* params, float* buffers
   // log-probs is (softmax - occupancy)/B, which log_softmax backward maps to itself.
   const lasr_model::Prefetch pf = m->prefetch;
   m->prefetch.armed = false;
+  // loss head: the lattice reads the log-probs and writes their gradient (dense: 2 x N x C f32; lean: bf16 logits in, bf16 gradient out)
+  ProfScope ps_head(LASR_PROF_HEAD, stream, lean ? 2.0 * B * p.T * lean_ldc(m) * 2 : 2.0 * B * p.T * C * sizeof(float));
   if (lean) {
     const int64_t N = B * p.T;
     const float* rs = atf(ws, p.o_rowstat);
@@ -807,12 +856,12 @@ static int forward_and_loss(lasr_model_t* m, const float* params, float* buffers
     LASR_TRY(lasr_ctc_loss_lean(at(ws, p.o_logits), lean_ldc(m), rs, ra, m->lean_tiles, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1,
                                 nll_out, argmax_out, at(ws, p.o_d1), grads + m->b_dec, nullptr, at(ws, p.o_lean), p.lean_bytes, stream));
     if (pf.armed)   // (the lattice of a large vocabulary does not share a grid with the feature transform)
-      LASR_TRY(lasr_mel_fwd(pf.wave, pf.sample_lens, pf.dither, pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out,
-                            pf.pct_out, pf.ws, pf.ws_bytes, stream));
+      LASR_TRY(mel_fwd_src(pf.src, pf.sample_lens, pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out,
+                           pf.pct_out, pf.ws, pf.ws_bytes, stream));
   } else if (pf.armed) {   // this step's loss and the next step's features in one grid
-    LASR_TRY(lasr_ctc_loss_mel(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
-                               at(ws, p.o_ctc), p.ctc_bytes, pf.wave, pf.sample_lens, pf.dither, pf.aug, pf.B, pf.L, pf.normalize, nullptr,
-                               pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws, pf.ws_bytes, stream));
+    LASR_TRY(ctc_loss_mel_src(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
+                              at(ws, p.o_ctc), p.ctc_bytes, pf.src, pf.sample_lens, pf.aug, pf.B, pf.L, pf.normalize, nullptr,
+                              pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws, pf.ws_bytes, stream));
   } else {
     LASR_TRY(lasr_ctc_loss(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
                            at(ws, p.o_ctc), p.ctc_bytes, stream));

@@ -144,6 +144,9 @@ extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_
   float* denom = reinterpret_cast<float*>(workspace);
   double* norm2 = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + align_up((size_t)n_tensors * sizeof(float), 256));
   hipStream_t st = as_stream(stream);
+  // (bench.py's class table) gradients read twice, parameters and momentum read and written
+  const int tok = prof_begin(LASR_PROF_OTHER, st, 0.0, 6.0 * (double)n_elems * sizeof(float));
+  struct End { int t; hipStream_t s; ~End() { prof_end(t, s); } } end_{tok, st};
   hipError_t me = hipMemsetAsync(norm2, 0, (size_t)n_tensors * sizeof(double), st);
   if (me != hipSuccess) return hip_fail(me, "lasr_novograd_step memset");
   hipLaunchKernelGGL(novograd_norm_kernel, dim3((unsigned)cdiv(n_elems, kNormChunk)), dim3(256), 0, st, grads, offsets, (int)n_tensors,

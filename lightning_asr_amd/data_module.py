@@ -71,26 +71,56 @@ class AudioParser:
             y = self.sub_secquence(y, weight=0.98)
         return self.features([y[0]], mask)[0]
 
+    # ---- the batched device front-end ---------------------------------------------------------------------------------------
+    def device_dither(self):
+        """``y += 1e-5 * randn_like(y)`` (:155) is drawn inside the mel kernel (Philox keyed by the process seed)"""
+        if getattr(self, "_dither", None) is None:
+            self._dither = ops.DeviceDither(int(torch.initial_seed()), self.device)
+        return self._dither
+
+    def draw_aug_batch(self, sample_lens) -> torch.Tensor:
+        """(B, 4) int32 SpecAugment rectangles for utterances of `sample_lens` samples (host draws, as the reference)"""
+        return torch.tensor([self.draw_spec_augment(1 + (int(l) + 64) // 160) for l in sample_lens], dtype=torch.int32)
+
+    def features_device(self, wave: torch.Tensor, lens: Optional[torch.Tensor], aug: Optional[torch.Tensor] = None, dither: bool = True):
+        """wave (B, L) f32 or int16 PCM ALREADY in HBM -> (inputs (B,1,64,Tmax) f32 with its channels-last twin attached,
+        input_percentages (B,)); frames past each utterance are zero (collate, :222-248)."""
+        bft, btf, frames, pct = ops.mel(wave, lens, self.device_dither() if dither else None, aug, True, self._act_dtype())
+        inputs = bft.unsqueeze(1)
+        inputs._lasr_btf = btf                                           # channels-last twin for the model
+        return inputs, pct
+
+    def _staging(self, n: int) -> torch.Tensor:
+        """two alternating pinned f32 staging buffers, reused across batches (a buffer is rewritten only after its last H2D copy
+        has completed)"""
+        st = getattr(self, "_stage", None)
+        if st is None:
+            st = self._stage = {"buf": [None, None], "ev": [None, None], "k": 0}
+        k = st["k"] = st["k"] ^ 1
+        if st["ev"][k] is not None:
+            st["ev"][k].synchronize()
+        if st["buf"][k] is None or st["buf"][k].numel() < n:
+            st["buf"][k] = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32).pin_memory()
+        return st["buf"][k][:n]
+
     def features(self, waves: Sequence[torch.Tensor], mask: bool, dither: bool = True):
-        """list of (L_i,) f32 waves -> (inputs (B,1,64,Tmax) f32 with its channels-last twin attached,
-        input_percentages (B,)) on the GPU; frames past each utterance are zero."""
+        """list of (L_i,) f32 host waves -> (inputs, input_percentages) on the GPU: padded into a reused pinned buffer, ONE H2D
+        copy for the batch, then ``features_device``."""
         B = len(waves)
         L = max(int(w.numel()) for w in waves)
-        host = torch.zeros(B, L, pin_memory=True)       # pad on the host, ONE H2D copy for the batch
+        host = self._staging(B * L).view(B, L)
+        host.zero_()
         lens = torch.empty(B, dtype=torch.int32)
         for i, w in enumerate(waves):
             host[i, :w.numel()] = w.cpu() if w.is_cuda else w
             lens[i] = w.numel()
         dev = self.device
         wave = host.to(dev, non_blocking=True)
-        noise = torch.randn(B, L, device=dev) if dither else None          # y += 1e-5*randn_like(y)  (:155)
-        aug = None
-        if mask:
-            aug = torch.tensor([self.draw_spec_augment(1 + (int(l) + 64) // 160) for l in lens], dtype=torch.int32).to(dev)
-        bft, btf, frames, pct = ops.mel(wave, lens.to(dev), noise, aug, True, self._act_dtype())
-        inputs = bft.unsqueeze(1)
-        inputs._lasr_btf = btf                                           # channels-last twin for the model
-        return inputs, pct
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stage["ev"][self._stage["k"]] = ev
+        aug = self.draw_aug_batch(lens).to(dev) if mask else None
+        return self.features_device(wave, lens.to(dev), aug, dither)
 
     def _act_dtype(self):
         return getattr(self, "act_dtype", torch.float32)
@@ -183,7 +213,7 @@ class WaveBatch(tuple):
 class LibriDataModule(LightningDataModule):
     def __init__(self, train_manifest, dev_manifest, test_manifest, labels: list, train_bs=16, dev_bs=16, num_worker=0,
                  train_max_duration=16.7, dev_max_duration=40, device="cuda", act_dtype=torch.float32,
-                 bucket_by_length: bool = False):
+                 bucket_by_length: bool = False, bucket_batches: int = 50, train_crop: bool = True):
         super().__init__()
         as_list = lambda m: list(m) if isinstance(m, (list, tuple)) else [m]  # noqa: E731
         self.train_manifest, self.dev_manifest, self.test_manifest = as_list(train_manifest), as_list(dev_manifest), as_list(test_manifest)
@@ -193,7 +223,9 @@ class LibriDataModule(LightningDataModule):
         self.train_max_duration, self.dev_max_duration = train_max_duration, dev_max_duration
         self.audio_parser = AudioParser(device=device)
         self.audio_parser.act_dtype = act_dtype
-        self.bucket_by_length = bucket_by_length
+        self.bucket_by_length = bool(bucket_by_length)       # BASELINE cfg5: length-bucketed batches (conf key data.bucket_by_length)
+        self.bucket_batches = int(bucket_batches)            # batches per sorted mega-chunk (conf key data.bucket_batches)
+        self.train_crop = bool(train_crop)                   # the reference's random sub-sequence of every training clip (data_module.py:158-159); conf key data.train_crop
 
     def setup(self, stage=None):
         self.train_datasets = MyAudioDataset(self.train_manifest, self.labels, mask=True, max_duration=self.train_max_duration)
@@ -203,7 +235,7 @@ class LibriDataModule(LightningDataModule):
     def _loader(self, ds, bs, train, distributed=None):
         if train and getattr(self, "bucket_by_length", False):
             world, rank = distributed if distributed is not None else (1, 0)
-            bs_ = BucketBatchSampler([d["duration"] for d in ds.datasets], bs, rank=rank, world=world)
+            bs_ = BucketBatchSampler([d["duration"] for d in ds.datasets], bs, bucket_batches=self.bucket_batches, rank=rank, world=world)
             return DataLoader(ds, batch_sampler=bs_, num_workers=self.num_worker, collate_fn=self._collate_train)
         sampler = None
         if distributed is not None:
@@ -228,7 +260,7 @@ class LibriDataModule(LightningDataModule):
     # ---- host half of the collate: ragged waves + padded targets (data_module.py:231-247) ---------
     def _collate_wave(self, batch, mask: bool) -> WaveBatch:
         waves = [b[0] for b in batch]
-        if mask:   # training-time random sub-sequence (data_module.py:158-159)
+        if mask and getattr(self, "train_crop", True):   # training-time random sub-sequence (data_module.py:158-159)
             waves = [self.audio_parser.sub_secquence(w.unsqueeze(0), weight=0.98)[0] for w in waves]
         max_trans = max(len(b[1]) for b in batch)
         targets = torch.zeros(len(batch), max_trans, dtype=torch.int64)

@@ -178,10 +178,17 @@ class NativeModel:
         frames = torch.empty(B, dtype=torch.int32, device=self.device)
         nb = int(self._lib.lasr_mel_workspace_bytes(B, T))
         ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.device)
-        call("lasr_model_set_prefetch", self._h, _p(wave), _p(sample_lens), _p(dither), _p(aug), B, L, int(normalize), _p(feats),
+        from .ops import wave_src
+        src = wave_src(wave, dither)
+        call("lasr_model_set_prefetch_src", self._h, C.byref(src), _p(sample_lens), _p(aug), B, L, int(normalize), _p(feats),
              _lib.F32 if self.act_dtype == torch.float32 else _lib.BF16, _p(frames), _p(pct), _p(ws), nb)
         self._prefetch_keep = (wave, sample_lens, dither, aug, frames, ws)       # alive until the call consumed them
         return feats, pct
+
+    def disarm_prefetch(self) -> None:
+        """forget an armed feature prefetch (a capture that failed between arm_prefetch and its loss call)"""
+        self._prefetch_keep = None
+        call("lasr_model_clear_prefetch", self._h)
 
     def bucket_bounds(self) -> List[int]:
         """Element offsets cutting the flat gradient into the all-reduce buckets of SURVEY §8e, in layer

@@ -1,0 +1,265 @@
+"""``Trainer.fit``'s hot loop for the stock ``LightingModule``: the reference's ``training_step`` + Lightning's
+backward / DDP all-reduce / ``optimizer.step`` / ``scheduler.step`` (train.py:64-86,233-252, conf/conf.yaml:30) executed as the
+fused native step - the path ``bench.py`` measures:
+
+    manifest --host threads--> int16 PCM in a pinned ring --copy stream--> HBM
+      -> TrainStep.step: features of batch i+1 inside the CTC launch of batch i, lasr_model_loss_backward (lean head for
+         large vocabularies: no (B, T', C) f32 log-probs), bucketed RCCL all-reduce on the library's side stream overlapped
+         with backward (world > 1), fused NovoGrad, LR schedule on the device; replayed from a hipGraph once a batch shape repeats
+      -> greedy decode + edit distance + loss/WER accumulation on the device (train_loss / train_wer as the reference logs them,
+         read back every ``log_every_n_steps`` steps instead of every step).
+
+A module that overrides ``training_step`` / ``forward`` / ``configure_optimizers`` with something else keeps the autograd route
+of ``Trainer.fit`` (``training_step`` -> ``loss.backward()`` -> ``optimizer.step()``)."""
+from __future__ import annotations
+
+import logging
+import os
+from collections import deque
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .ingest import BatchProducer, DevBatch, DeviceFeeder, PinnedRing, SR, fast_ingest_ok
+from .step import GraphedTrainStep, TrainStep, graph_dp_enabled
+
+logger = logging.getLogger(__name__)
+
+
+def fused_eligible(model, optimizer, scheduler) -> bool:
+    """the stock module (train.py's training_step / forward untouched) over a native encoder, optimised by the HIP NovoGrad
+    with the cosine-warm-up schedule (or none)"""
+    if os.environ.get("LASR_TRAINER_FUSED", "1") == "0":
+        return False
+    from .schedule import CosineAnnealingWarmupRestarts
+    from .scheduler.novograd import Novograd
+    from .train import LightingModule as LM
+    if not isinstance(model, LM):
+        return False
+    if type(model).training_step is not LM.training_step or type(model).forward is not LM.forward or type(model)._shared is not LM._shared:
+        return False
+    if getattr(getattr(model, "encoder", None), "native", None) is None:
+        return False
+    if not isinstance(optimizer, Novograd) or (scheduler is not None and not isinstance(scheduler, CosineAnnealingWarmupRestarts)):
+        return False
+    return True
+
+
+class HostWaveSource:
+    """Fallback ingest for a custom dataset: the DataLoader's WaveBatch (ragged f32 waves) padded on the host and uploaded as f32"""
+
+    def __init__(self, loader, device, limit: int):
+        self.loader, self.device, self.limit = loader, torch.device(device), limit
+
+    def __iter__(self):
+        for k, batch in enumerate(self.loader):
+            if k >= self.limit:
+                return
+            waves, targets, sizes, paths, mask = batch
+            B, L = len(waves), max(int(w.numel()) for w in waves)
+            host = torch.zeros(B, L).pin_memory()
+            lens = torch.empty(B, dtype=torch.int32)
+            for i, w in enumerate(waves):
+                host[i, :w.numel()] = w
+                lens[i] = w.numel()
+            db = DevBatch()
+            db.pcm = host.to(self.device, non_blocking=True)
+            db.lens, db.sizes, db.targets = lens.to(self.device), sizes.to(self.device), targets.to(self.device)
+            db.aug = None
+            db.paths, db.B, db.ld, db.S, db.seconds = paths, B, L, targets.shape[1], float(lens.sum()) / SR
+            db.ready, db.dslot, db.index, db.key = None, -1, k, (B, L, targets.shape[1], False)
+            db.mask = mask
+            yield db
+
+    def release(self, db) -> None:
+        pass
+
+    def close(self) -> None:
+        pass
+
+
+class NativeSource:
+    """manifest -> pinned ring -> device ring (ingest.py), ``depth`` batches ahead of the consumer"""
+
+    def __init__(self, dataset, index_batches, audio_parser, device, batch_size: int, max_seconds: float, mask: bool,
+                 n_threads: int, limit: int, crop: Optional[bool] = None):
+        index_batches = list(index_batches)[:limit]
+        cap = int(batch_size * (int(max_seconds * SR) + 64))
+        self.ring = PinnedRing(4, cap, 8 * batch_size + 2 * batch_size * 256)
+        self.feeder = DeviceFeeder(self.ring, device, n_slots=4)
+        self.producer = BatchProducer(dataset, index_batches, self.ring, mask, audio_parser, n_threads=n_threads, crop=crop)
+        self.mask = mask
+        self.n = len(index_batches)
+
+    def __iter__(self):
+        self.producer.start()
+        try:
+            while True:
+                hb = self.producer.out.get()
+                if hb is None:
+                    return
+                if isinstance(hb, BaseException):
+                    raise hb
+                db = self.feeder.upload(hb)
+                db.mask = self.mask
+                yield db
+        finally:
+            self.producer.stop()
+
+    def release(self, db) -> None:
+        self.feeder.release(db)
+
+    def close(self) -> None:
+        self.producer.stop()
+        self.feeder.close()
+
+
+def make_source(datamodule, loader, device, mask: bool, limit: int, max_seconds: float, batch_size: int, crop: Optional[bool] = None):
+    ds = loader.dataset
+    if fast_ingest_ok(ds) and os.environ.get("LASR_NATIVE_INGEST", "1") != "0":
+        n_threads = max(1, int(getattr(datamodule, "num_worker", 0) or 0)) if os.environ.get("LASR_INGEST_THREADS") is None \
+            else int(os.environ["LASR_INGEST_THREADS"])
+        return NativeSource(ds, loader.batch_sampler, datamodule.audio_parser, device, batch_size, max_seconds, mask,
+                            n_threads=max(n_threads, 1), limit=limit, crop=crop)
+    return HostWaveSource(loader, device, limit)
+
+
+class FusedLoop:
+    def __init__(self, trainer, model, datamodule, optimizer, scheduler):
+        self.trainer, self.model, self.dm = trainer, model, datamodule
+        self.native = model.encoder.native
+        dev = self.native.device
+        self.ts = TrainStep.from_optimizer(self.native, optimizer, scheduler)
+        if scheduler is not None:
+            self.ts.use_device_schedule()
+        self.dither = ops.DeviceDither(int(torch.initial_seed()) ^ (0x9E3779B97F4A7C15 * (trainer.rank + 1)), dev)
+        self.acc = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.use_graph = os.environ.get("LASR_TRAINER_GRAPH", "1") != "0" and (self.ts.world == 1 or graph_dp_enabled())
+        self.graphs: Dict[tuple, GraphedTrainStep] = {}
+        self.seen: Dict[tuple, int] = {}
+        self._pf = None            # (batch index, feats, pct): features of the next batch, computed by the previous step
+        self.graph_steps = self.eager_steps = 0
+        self.audio_seconds = 0.0
+        self.samples_real = self.samples_padded = 0      # padding bookkeeping: sum of valid samples / of B * row pitch
+        self.on_host_batch = getattr(trainer, "_fused_on_batch", None)  # test hook: called with every DevBatch before it is trained on
+
+    # ---- one step ------------------------------------------------------------------------------------------------------
+    def _feats_for(self, cur: DevBatch):
+        pf, self._pf = self._pf, None
+        if pf is not None and pf[0] == cur.index:
+            return pf[1], pf[2]
+        return self.ts.features(cur.pcm, cur.lens, self.dither, cur.aug)
+
+    def _graph_for(self, cur: DevBatch, nxt: DevBatch) -> Optional[GraphedTrainStep]:
+        key = cur.key
+        if not self.use_graph or nxt is None or nxt.key != key or cur.pcm.dtype != nxt.pcm.dtype:
+            return None
+        g = self.graphs.get(key)
+        if g is not None:
+            return g if g.graph is not None else None
+        self.seen[key] = self.seen.get(key, 0) + 1
+        if self.seen[key] < 3 or len(self.graphs) >= 16:       # capture once a shape keeps coming back
+            return None
+        B, L, S, with_aug = key
+        g = GraphedTrainStep(self.ts, B, L, S, ragged=True, prefetch=True, want_logp=False, wave_dtype=cur.pcm.dtype,
+                             with_aug=with_aug, dither=self.dither)
+        self.graphs[key] = g
+        try:
+            g.targets.copy_(cur.targets)
+            g.tgt_lens.copy_(cur.sizes)
+            g.capture(first_wave=cur.pcm, first_lens=cur.lens, first_aug=cur.aug)
+        except Exception as e:  # noqa: BLE001 - a runtime that refuses the capture: this shape stays eager
+            logger.warning("hipGraph capture failed for batch shape %s (%s): eager launches", key, e)
+            g.graph = None
+            return None
+        return g
+
+    def step(self, cur: DevBatch, nxt: Optional[DevBatch], batch_idx: int):
+        ts, native = self.ts, self.native
+        stream = torch.cuda.current_stream()
+        for b in (cur, nxt):
+            if b is not None and b.ready is not None:
+                stream.wait_event(b.ready)
+        if self.on_host_batch is not None:
+            self.on_host_batch(cur)
+        feats, pct = self._feats_for(cur)
+        g = self._graph_for(cur, nxt)
+        if g is not None:
+            g.prime(feats, pct)
+            loss, nll, _, am = g.step(nxt.pcm, cur.targets, cur.sizes, nxt.lens, nxt.aug)
+            self._pf = (nxt.index, g.F_cur, g.pct_cur)
+            self.graph_steps += 1
+        else:
+            nf = None
+            if nxt is not None:
+                nf = native.arm_prefetch(nxt.pcm, nxt.lens, self.dither, nxt.aug)
+            loss, nll, _, am = ts.step_features(feats, pct, cur.targets, cur.sizes, want_logp=False)
+            self._pf = (nxt.index, nf[0], nf[1]) if nf is not None else None
+            self.eager_steps += 1
+        self.audio_seconds += cur.seconds
+        self.samples_real += int(round(cur.seconds * SR))
+        self.samples_padded += cur.B * cur.ld
+        # train.py:79-81: self.log('train_loss'), self.log('train_wer') - decode, distance and accumulation stay on the device
+        wer = self.model.wer
+        t_lens = native.tap("lens")
+        if wer.device_path(am, cur.targets):
+            dist, units = wer.device_distances(am, cur.targets, cur.sizes, t_lens)
+            ops.step_metrics(loss, dist, units, self.acc)
+            host_wer = None
+        else:        # labels the device units cannot express: the host path of the metric, once per step like the reference
+            host_wer = float(wer(am, cur.targets, cur.sizes, t_lens))
+            self.trainer._record("train_wer", host_wer)
+            self.trainer._record("train_loss", float(loss.item()))
+        if batch_idx % 50 == 0:     # train.py:82-85
+            logging.info("pred:" + wer.ctc_decoder_predictions_tensor(am, t_lens)[0])
+            logging.info("true:" + wer.decode_reference(cur.targets, cur.sizes)[0])
+        return loss
+
+    def read_metrics(self, reset: bool = False) -> Dict[str, float]:
+        a = self.acc.cpu()
+        out = {}
+        if a[2] > 0:
+            out = {"train_loss": float(a[0] / a[2]), "train_wer": float(a[1] / a[2]), "train_loss_step": float(a[3]),
+                   "train_wer_step": float(a[4])}
+        if reset:
+            self.acc.zero_()
+        return out
+
+    # ---- one epoch -----------------------------------------------------------------------------------------------------
+    def run_epoch(self, loader, n_batches: int, on_step=None) -> None:
+        tr, dm = self.trainer, self.dm
+        src = make_source(dm, loader, self.native.device, True, n_batches, getattr(dm, "train_max_duration", 16.7) or 16.7,
+                          getattr(dm, "train_bs", 32), crop=getattr(dm, "train_crop", True))
+        self.source_kind = type(src).__name__
+        self._pf = None
+        window = deque()
+        it = iter(src)
+        try:
+            for _ in range(2):                      # two batches in flight ahead of the step: H2D of i+2 rides under step i
+                b = next(it, None)
+                if b is not None:
+                    window.append(b)
+            batch_idx = 0
+            while window:
+                if tr.max_steps and tr.global_step >= tr.max_steps:
+                    break
+                cur = window.popleft()
+                nxt = window[0] if window else None
+                b = next(it, None)
+                if b is not None:
+                    window.append(b)
+                self.step(cur, nxt, batch_idx)
+                src.release(cur)
+                tr.global_step += 1
+                batch_idx += 1
+                if tr.log_every_n_steps and tr.global_step % tr.log_every_n_steps == 0:
+                    m = self.read_metrics()
+                    for k in ("train_loss", "train_wer"):
+                        if k + "_step" in m:
+                            tr.callback_metrics[k] = m[k + "_step"]
+                if on_step is not None:
+                    on_step(tr)
+        finally:
+            it.close()
+            src.close()

@@ -1,0 +1,249 @@
+"""Manifest -> GPU at training speed: what the reference's 6 DataLoader workers + pin_memory + H2D do (data_module.py:16-56,
+199-201,222-248; conf/conf.yaml:14), rebuilt around ONE int16 batch buffer.
+
+* ``read_wav_batch``: liblasr's host threads (``lasr_wav_read_batch``) decode a batch of 16-bit wav files - and take the
+  training-time random sub-sequence as a slice of the file - straight into a pinned ring slot (GIL released).
+* ``BatchProducer``: a background thread that walks the sampler's index lists, fills ring slots, builds the padded targets and
+  draws the SpecAugment rectangles (host ``random.Random``, as the reference).
+* ``DeviceFeeder``: two H2D copies per batch (PCM as int16, one packed metadata block) on a copy stream into a small ring of
+  device buffers, one batch ahead of the training step, ordered by events only.
+
+The samples are scaled (1/32768), dithered, pre-emphasised and turned into log-mel features on the device
+(``lasr_mel_fwd_src``)."""
+from __future__ import annotations
+
+import ctypes as C
+import queue
+import threading
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SR = 16000
+
+
+def wav_info(path: str):
+    """(n_frames, channels, sample_rate, bits) of a RIFF/WAVE file"""
+    n, ch, sr, bits = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.call("lasr_wav_info", path.encode(), C.byref(n), C.byref(ch), C.byref(sr), C.byref(bits))
+    return n.value, ch.value, sr.value, bits.value
+
+
+def read_wav_batch(paths: Sequence[str], out: torch.Tensor, lens_out: torch.Tensor, crop_u: Optional[np.ndarray] = None,
+                   crop_weight: float = 0.98, n_threads: int = 8, expect_rate: int = SR) -> int:
+    """Decode ``paths`` into ``out`` (1-D int16 host tensor, normally pinned) as rows of pitch ``ld`` (returned);
+    ``lens_out`` (>= len(paths) int32 host tensor) receives the valid samples per row.  crop_u: (n, 2) float64 uniforms for the
+    training-time sub-sequence (data_module.py:138-148), or None."""
+    n = len(paths)
+    if out.dtype != torch.int16 or out.is_cuda or not out.is_contiguous():
+        raise TypeError("read_wav_batch writes a contiguous int16 host tensor")
+    if lens_out.dtype != torch.int32 or lens_out.is_cuda or lens_out.numel() < n:
+        raise TypeError("lens_out must be an int32 host tensor with one entry per file")
+    arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+    ld = C.c_int64(0)
+    cu = None
+    if crop_u is not None:
+        crop_u = np.ascontiguousarray(crop_u, dtype=np.float64)
+        if crop_u.shape != (n, 2):
+            raise ValueError("crop_u must have shape (n, 2)")
+        cu = crop_u.ctypes.data_as(C.c_void_p)
+    _lib.call("lasr_wav_read_batch", arr, n, cu, float(crop_weight), out.data_ptr(), out.numel(), C.byref(ld), lens_out.data_ptr(),
+              int(expect_rate), int(n_threads))
+    return int(ld.value)
+
+
+class HostBatch:
+    """one batch on the host: PCM rows in ring slot ``slot`` + the packed metadata block"""
+    __slots__ = ("slot", "B", "ld", "S", "lens", "sizes", "aug", "targets", "meta", "meta_words", "paths", "mask", "seconds", "index")
+
+
+def _meta_layout(B: int, S: int, with_aug: bool):
+    """int32 word offsets of [lens B][sizes B][aug 4B]...[targets B*S int64] inside the metadata block"""
+    o_lens, o_sizes, o_aug = 0, B, 2 * B
+    o_tg = 2 * B + (4 * B if with_aug else 0)
+    o_tg += o_tg & 1                                  # int64 view needs an even word offset
+    return o_lens, o_sizes, o_aug, o_tg, o_tg + 2 * B * S
+
+
+class PinnedRing:
+    """n_slots host buffers of `capacity` int16 samples + `meta_words` int32 words each, pinned when a GPU is present"""
+
+    def __init__(self, n_slots: int, capacity: int, meta_words: int, pin: bool = True):
+        self.pin = pin and torch.cuda.is_available()
+        self.n_slots, self.capacity, self.meta_words = n_slots, int(capacity), int(meta_words)
+        mk = (lambda n, dt: torch.empty(n, dtype=dt).pin_memory()) if self.pin else (lambda n, dt: torch.empty(n, dtype=dt))
+        self._mk = mk
+        self.pcm = [mk(self.capacity, torch.int16) for _ in range(n_slots)]
+        self.meta = [mk(self.meta_words, torch.int32) for _ in range(n_slots)]
+        self.free: "queue.Queue[int]" = queue.Queue()
+        for i in range(n_slots):
+            self.free.put(i)
+
+    def grow(self, slot: int, capacity: int = 0, meta_words: int = 0) -> None:
+        if capacity > self.pcm[slot].numel():
+            self.pcm[slot] = self._mk(int(capacity), torch.int16)
+        if meta_words > self.meta[slot].numel():
+            self.meta[slot] = self._mk(int(meta_words), torch.int32)
+
+
+class BatchProducer(threading.Thread):
+    """Walks ``index_batches`` (lists of dataset indices, e.g. a DataLoader's batch_sampler) over a stock ``MyAudioDataset``
+    and puts ``HostBatch`` objects on ``self.out`` (None at the end, an Exception on failure).  ``ring.free`` gets a slot back
+    from the consumer once its H2D copies are done."""
+
+    def __init__(self, dataset, index_batches: Iterable[List[int]], ring: PinnedRing, mask: bool, audio_parser, n_threads: int = 8,
+                 crop_weight: float = 0.98, depth: int = 2, crop: Optional[bool] = None):
+        super().__init__(daemon=True)
+        self.ds, self.batches, self.ring, self.mask, self.ap = dataset, index_batches, ring, mask, audio_parser
+        self.n_threads, self.crop_weight = max(1, int(n_threads)), crop_weight
+        self.crop = mask if crop is None else crop
+        self.out: "queue.Queue" = queue.Queue(maxsize=depth)
+        self._halt = threading.Event()
+
+    def stop(self) -> None:
+        self._halt.set()
+        try:                                   # unblock a producer waiting for a slot
+            self.ring.free.put_nowait(-1)
+        except queue.Full:
+            pass
+
+    def _put(self, item) -> bool:
+        while not self._halt.is_set():
+            try:
+                self.out.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def run(self) -> None:
+        try:
+            for k, idx in enumerate(self.batches):
+                if self._halt.is_set():
+                    return
+                slot = self.ring.free.get()
+                if slot < 0 or self._halt.is_set():
+                    return
+                if not self._put(self.make(list(idx), slot, k)):
+                    return
+            self._put(None)
+        except BaseException as e:  # noqa: BLE001 - handed to the consumer, which re-raises
+            self._put(e)
+
+    def make(self, idx: List[int], slot: int, index: int = 0) -> HostBatch:
+        ds, ring = self.ds, self.ring
+        items = [ds.datasets[i] for i in idx]
+        B = len(items)
+        paths = [d["audio_filepath"] for d in items]
+        ids = [[ds.char2index[ch] for ch in d["text"]] for d in items]
+        S = max(1, max(len(t) for t in ids))
+        o_lens, o_sizes, o_aug, o_tg, words = _meta_layout(B, S, self.mask)
+        ring.grow(slot, meta_words=words)
+        meta = ring.meta[slot]
+        crop_u = np.random.uniform(0.0, 1.0, size=(B, 2)) if self.crop else None      # the two draws of sub_secquence per clip
+        lens = meta[o_lens:o_lens + B]
+        while True:
+            try:
+                ld = read_wav_batch(paths, ring.pcm[slot], lens, crop_u, self.crop_weight, self.n_threads)
+                break
+            except _lib.LasrError as e:
+                if "do not fit the buffer" not in str(e):
+                    raise
+                ring.grow(slot, capacity=int(ring.pcm[slot].numel() * 1.5) + 8 * B)    # a file longer than its manifest duration
+        sizes = meta[o_sizes:o_sizes + B]
+        tg = meta[o_tg:o_tg + 2 * B * S].view(torch.int64).view(B, S)
+        tg.zero_()
+        for i, t in enumerate(ids):
+            sizes[i] = len(t)
+            if t:
+                tg[i, :len(t)] = torch.tensor(t, dtype=torch.int64)
+        aug = None
+        if self.mask:       # spec_augment(27, 0.07) rectangles, drawn per clip in the reference's order (data_module.py:97-122,165)
+            aug = meta[o_aug:o_aug + 4 * B].view(B, 4)
+            for i in range(B):
+                n_time = 1 + (int(lens[i]) + 64) // 160
+                aug[i] = torch.tensor(self.ap.draw_spec_augment(n_time), dtype=torch.int32)
+        hb = HostBatch()
+        hb.slot, hb.B, hb.ld, hb.S, hb.lens, hb.sizes, hb.aug, hb.targets = slot, B, ld, S, lens, sizes, aug, tg
+        hb.meta, hb.meta_words, hb.paths, hb.mask, hb.index = meta, words, paths, self.mask, index
+        hb.seconds = float(lens.sum()) / SR
+        return hb
+
+
+class DevBatch:
+    """one batch resident in HBM (views of a device ring slot), valid for the compute stream once ``ready`` has been waited on"""
+    __slots__ = ("pcm", "lens", "sizes", "aug", "targets", "paths", "B", "ld", "S", "seconds", "ready", "dslot", "index", "key", "mask")
+
+
+class DeviceFeeder:
+    """Host batches -> device ring slots on a copy stream.  ``upload`` never blocks the host on the GPU: the copy stream waits
+    for the compute-stream event of the step that last read the slot (``release``), copies PCM + metadata, records ``ready``;
+    a helper thread returns the pinned slot to the producer once the copies are done."""
+
+    def __init__(self, ring: PinnedRing, device, n_slots: int = 3):
+        self.ring, self.device = ring, torch.device(device)
+        self.n_slots = n_slots
+        self.pcm = [torch.empty(ring.capacity, dtype=torch.int16, device=self.device) for _ in range(n_slots)]
+        self.meta = [torch.empty(ring.meta_words, dtype=torch.int32, device=self.device) for _ in range(n_slots)]
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.released: List[Optional[torch.cuda.Event]] = [None] * n_slots
+        self._next = 0
+        self._done_q: "queue.Queue" = queue.Queue()
+        self._recycler = threading.Thread(target=self._recycle, daemon=True)
+        self._recycler.start()
+
+    def _recycle(self) -> None:
+        while True:
+            item = self._done_q.get()
+            if item is None:
+                return
+            ev, slot = item
+            ev.synchronize()                   # H2D copies out of the pinned slot are done
+            self.ring.free.put(slot)
+
+    def close(self) -> None:
+        self._done_q.put(None)
+
+    def upload(self, hb: HostBatch) -> DevBatch:
+        k = self._next
+        self._next = (k + 1) % self.n_slots
+        n = hb.B * hb.ld
+        if n > self.pcm[k].numel():
+            self.pcm[k] = torch.empty(n, dtype=torch.int16, device=self.device)
+        if hb.meta_words > self.meta[k].numel():
+            self.meta[k] = torch.empty(hb.meta_words, dtype=torch.int32, device=self.device)
+        cs = self.copy_stream
+        if self.released[k] is not None:
+            cs.wait_event(self.released[k])     # the step that read this device slot has finished with it
+        with torch.cuda.stream(cs):
+            self.pcm[k][:n].copy_(self.ring.pcm[hb.slot][:n], non_blocking=True)
+            self.meta[k][:hb.meta_words].copy_(hb.meta[:hb.meta_words], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        self._done_q.put((ev, hb.slot))
+        B, S = hb.B, hb.S
+        o_lens, o_sizes, o_aug, o_tg, _ = _meta_layout(B, S, hb.aug is not None)
+        m = self.meta[k]
+        db = DevBatch()
+        db.pcm = self.pcm[k][:n].view(B, hb.ld)
+        db.lens, db.sizes = m[o_lens:o_lens + B], m[o_sizes:o_sizes + B]
+        db.aug = m[o_aug:o_aug + 4 * B].view(B, 4) if hb.aug is not None else None
+        db.targets = m[o_tg:o_tg + 2 * B * S].view(torch.int64).view(B, S)
+        db.paths, db.B, db.ld, db.S, db.seconds, db.ready, db.dslot, db.index = hb.paths, B, hb.ld, S, hb.seconds, ev, k, hb.index
+        db.key = (B, hb.ld, S, hb.aug is not None)
+        return db
+
+    def release(self, db: DevBatch) -> None:
+        """call after the last kernel that reads ``db`` has been enqueued on the current stream"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.released[db.dslot] = ev
+
+
+def fast_ingest_ok(dataset) -> bool:
+    """the native reader applies to the stock dataset (manifest of 16-bit PCM wav paths)"""
+    from .data_module import MyAudioDataset
+    return type(dataset).__getitem__ is MyAudioDataset.__getitem__ and hasattr(dataset, "datasets") and hasattr(dataset, "char2index")

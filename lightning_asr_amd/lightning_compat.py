@@ -138,8 +138,11 @@ class Trainer:
                  check_val_every_n_epoch: int = 1, limit_train_batches=1.0, limit_val_batches=1.0,
                  accelerator: Optional[str] = None, num_nodes: int = 1, default_root_dir: str = ".",
                  callbacks=None, logger=None, save_top_k: int = 3, monitor: str = "val_wer", max_steps: Optional[int] = None,
-                 device: Optional[str] = None, **ignored):
+                 device: Optional[str] = None, log_every_n_steps: int = 50, **ignored):
         self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.log_every_n_steps = log_every_n_steps      # how often the fused loop reads its device-side metric accumulators
+        self.callbacks = list(callbacks or [])          # objects with on_train_batch_end(trainer) / on_train_epoch_end(trainer)
+        self.fused = None                               # the FusedLoop of the last fit (None: autograd route)
         self.resume_from_checkpoint = resume_from_checkpoint
         self.check_val_every_n_epoch = check_val_every_n_epoch
         self.limit_train_batches, self.limit_val_batches = limit_train_batches, limit_val_batches
@@ -198,6 +201,29 @@ class Trainer:
             batch = dm.on_after_batch_transfer(batch, idx)
         return batch
 
+    def _eval_batches(self, loader, dm, n: int):
+        """the reference's 5-tuples (data_module.py:248) for a validation / test loader: through the native ingest (wav files ->
+        pinned ring -> int16 H2D -> device front-end) when the dataset is the stock one, else through the DataLoader"""
+        from .ingest import fast_ingest_ok
+        if self.device.type == "cuda" and hasattr(dm, "audio_parser") and fast_ingest_ok(getattr(loader, "dataset", None)) \
+                and getattr(loader, "batch_sampler", None) is not None and os.environ.get("LASR_NATIVE_INGEST", "1") != "0":
+            from .fused_fit import make_source
+            src = make_source(dm, loader, self.device, False, n, getattr(dm, "dev_max_duration", 40) or 40, getattr(dm, "dev_bs", 16))
+            try:
+                for db in src:
+                    if db.ready is not None:
+                        torch.cuda.current_stream().wait_event(db.ready)
+                    inputs, pct = dm.audio_parser.features_device(db.pcm, db.lens, None)
+                    yield inputs, db.targets, pct, db.sizes, db.paths
+                    src.release(db)          # (after the consumer has enqueued everything that reads the slot's targets / sizes)
+            finally:
+                src.close()
+            return
+        for k, batch in enumerate(loader):
+            if k >= n:
+                return
+            yield self._batch(batch, dm, k)
+
     def _save(self, model, opt, sched, name: str) -> str:
         d = os.path.join(self.root, "checkpoints")
         os.makedirs(d, exist_ok=True)
@@ -235,37 +261,62 @@ class Trainer:
             start_epoch, self.global_step = ckpt["epoch"] + 1, ckpt["global_step"]
         native = getattr(getattr(model, "encoder", None), "native", None)
         sync = None
-        if self.world > 1:
+        from .fused_fit import FusedLoop, fused_eligible
+        fused = None
+        if fused_eligible(model, opt, sched):
+            # the stock module: training_step + backward + DDP all-reduce + optimizer.step + scheduler.step run as the fused
+            # native step (fused_fit.py); parameters / buffers are broadcast from rank 0 like Lightning's DDP wrap does
+            fused = FusedLoop(self, model, datamodule, opt, sched)
+            fused.ts.broadcast_parameters()
+            if fused.ts.world > 1:
+                self._install_metric_reduce(model, fused.ts)
+        elif self.world > 1:
             dist.broadcast(native.params, 0)
             dist.broadcast(native.buffers, 0)
             sync = GradSync(native.bucket_bounds(), None)
             opt.grad_scale = sync.grad_scale
+            self._install_metric_reduce(model, None)
+        self.fused = fused
         loader = datamodule.train_dataloader()
         if self.world > 1:
             loader = datamodule.train_dataloader(distributed=(self.world, self.rank))
         os.makedirs(self.root, exist_ok=True)
         log_path = os.path.join(self.root, "metrics.jsonl")
+
+        def on_step(tr):
+            for cb in tr.callbacks:
+                if hasattr(cb, "on_train_batch_end"):
+                    cb.on_train_batch_end(tr)
+
         for epoch in range(start_epoch, self.max_epochs):
             self.current_epoch = epoch
             self._epoch_metrics = {}
             model.train()
-            if hasattr(loader, "sampler") and hasattr(loader.sampler, "set_epoch"):
-                loader.sampler.set_epoch(epoch)
+            for smp in (getattr(loader, "sampler", None), getattr(loader, "batch_sampler", None)):
+                if smp is not None and hasattr(smp, "set_epoch"):
+                    smp.set_epoch(epoch)
             n = self._limit(len(loader), self.limit_train_batches)
             t0 = time.time()
-            for batch_idx, batch in enumerate(loader):
-                if batch_idx >= n or (self.max_steps and self.global_step >= self.max_steps):
-                    break
-                batch = self._batch(batch, datamodule)
-                loss = model.training_step(batch, batch_idx)
-                opt.zero_grad()
-                loss.backward()
-                if sync is not None:
-                    sync.all_reduce(native.grads)
-                opt.step()
-                if sched is not None:
-                    sched.step()
-                self.global_step += 1
+            if fused is not None:
+                fused.run_epoch(loader, n, on_step)
+                for k, v in fused.read_metrics(reset=True).items():
+                    if not k.endswith("_step"):
+                        self._record(k, v)
+            else:
+                for batch_idx, batch in enumerate(loader):
+                    if batch_idx >= n or (self.max_steps and self.global_step >= self.max_steps):
+                        break
+                    batch = self._batch(batch, datamodule)
+                    loss = model.training_step(batch, batch_idx)
+                    opt.zero_grad()
+                    loss.backward()
+                    if sync is not None:
+                        sync.all_reduce(native.grads)
+                    opt.step()
+                    if sched is not None:
+                        sched.step()
+                    self.global_step += 1
+                    on_step(self)
             rec = {"epoch": epoch, "global_step": self.global_step, "train_time_s": time.time() - t0,
                    "lr": opt.param_groups[0]["lr"]}
             rec.update({k: float(np.mean(v)) for k, v in self._epoch_metrics.items()})
@@ -292,16 +343,65 @@ class Trainer:
     def validate(self, model, datamodule) -> Dict[str, float]:
         model.eval()
         self._epoch_metrics = {}
+        wer = getattr(model, "wer", None)
+        if wer is not None and hasattr(wer, "reset"):
+            wer.reset()
         loader = datamodule.val_dataloader()
         n = self._limit(len(loader), self.limit_val_batches)
         outs = []
-        for batch_idx, batch in enumerate(loader):
-            if batch_idx >= n:
-                break
-            outs.append(model.validation_step(self._batch(batch, datamodule), batch_idx))
+        for batch_idx, batch in enumerate(self._eval_batches(loader, datamodule, n)):
+            outs.append(model.validation_step(batch, batch_idx))
         model.validation_epoch_end(outs)
         model.train()
-        return {k: float(np.mean(v)) for k, v in self._epoch_metrics.items()}
+        rec = {k: float(np.mean(v)) for k, v in self._epoch_metrics.items()}
+        rec = self._sync_epoch_metrics(rec)
+        if wer is not None and hasattr(wer, "compute_total") and outs:
+            rec["val_wer_total"] = float(wer.compute_total())     # corpus-level: summed edit distances / summed reference units, all ranks
+        return rec
+
+    # ---- data-parallel metric agreement -----------------------------------------------------------------------------------
+    def _all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        """SUM of a small f32 device vector over the ranks: the library's RCCL communicator when the fused step owns one,
+        torch.distributed otherwise (gloo rehearsals, the autograd route)"""
+        comm = getattr(getattr(self.fused, "ts", None), "comm", None)
+        if comm is not None:
+            comm.all_reduce(t)
+            comm.wait()
+        else:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                if dist.get_backend() == "gloo" and t.is_cuda:
+                    h = t.cpu()
+                    dist.all_reduce(h)
+                    t.copy_(h)
+                else:
+                    dist.all_reduce(t)
+        return t
+
+    def _install_metric_reduce(self, model, ts) -> None:
+        """utils/asr_metrics.py:114-115 dist_reduce_fx='sum' on `scores` / `words`: WER.compute() sums both over the ranks"""
+        wer = getattr(model, "wer", None)
+        if wer is None or self.world <= 1:
+            return
+
+        def reduce(scores, words):
+            dev = self.device if self.device.type == "cuda" else scores.device
+            v = torch.stack([scores.to(dev).float(), words.to(dev).float()])
+            self._all_reduce_sum(v)
+            return v[0], v[1]
+        wer.world_reduce = reduce               # used by WER.compute_total() at the end of an epoch, not on every step
+
+    def _sync_epoch_metrics(self, rec: Dict[str, float]) -> Dict[str, float]:
+        """world > 1: every rank reports the MEAN over the ranks of its epoch metrics, so `val_wer` (what ModelCheckpoint
+        monitors, train.py:210-212) and the checkpoints it selects agree across the ranks"""
+        if self.world <= 1 or not rec:
+            return rec
+        keys = sorted(rec)
+        dev = self.device if self.device.type == "cuda" else torch.device("cpu")
+        v = torch.tensor([rec[k] for k in keys], dtype=torch.float32, device=dev)
+        self._all_reduce_sum(v)
+        v = (v / self.world).cpu()
+        return {k: float(v[i]) for i, k in enumerate(keys)}
 
     @torch.no_grad()
     def test(self, model, test_dataloaders=None, datamodule=None):
@@ -312,6 +412,6 @@ class Trainer:
             dm.trainer = self
             dm.setup("test")                       # PL calls setup('test') on a datamodule handed to .test()
         loader = test_dataloaders if test_dataloaders is not None else dm.test_dataloader()
-        outs = [model.test_step(self._batch(batch, dm), i) for i, batch in enumerate(loader)]
+        outs = [model.test_step(batch, i) for i, batch in enumerate(self._eval_batches(loader, dm, len(loader)))]
         model.test_epoch_end(outs)
         return outs

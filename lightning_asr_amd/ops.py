@@ -48,20 +48,58 @@ def mel_num_frames(n_samples: int) -> int:
     return int(_lib.load().lasr_mel_num_frames(n_samples))
 
 
-def mel(wave: torch.Tensor, sample_lens: Optional[torch.Tensor] = None, dither: Optional[torch.Tensor] = None,
+class DeviceDither:
+    """``y += 1e-5 * randn_like(y)`` (data_module.py:155) drawn inside the mel kernel: Philox keyed by ``seed``, counter =
+    (sample / 4, utterance, step); ``step`` is a device scalar every mel call increments (a replayed graph draws fresh noise)."""
+
+    def __init__(self, seed: int, device):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def noise(self, B: int, L: int) -> torch.Tensor:
+        """the (B, L) N(0,1) noise the NEXT mel call draws (verification)"""
+        out = torch.empty(B, L, dtype=torch.float32, device=self.step.device)
+        call("lasr_dither_noise", self.seed, _p(self.step), B, L, _p(out), _stream())
+        return out
+
+
+def wave_src(wave: torch.Tensor, dither=None) -> "_lib.WaveSrc":
+    """lasr_wave_src for a (B, L) float32 or int16 (PCM) waveform tensor; dither: None | (B, L) f32 noise | DeviceDither"""
+    if wave.dtype == torch.float32:
+        wd = _lib.WAVE_F32
+    elif wave.dtype == torch.int16:
+        wd = _lib.WAVE_PCM16
+    else:
+        raise TypeError("waveforms must be float32 or int16 PCM, got %s" % wave.dtype)
+    if isinstance(dither, DeviceDither):
+        return _lib.WaveSrc(_p(wave), wd, None, dither.seed, _p(dither.step))
+    if dither is not None and (dither.dtype != torch.float32 or tuple(dither.shape) != tuple(wave.shape)):
+        raise TypeError("dither noise must be a float32 tensor of the waveform's shape")
+    return _lib.WaveSrc(_p(wave), wd, _p(dither), 0, None)
+
+
+def mel(wave: torch.Tensor, sample_lens: Optional[torch.Tensor] = None, dither=None,
         aug: Optional[torch.Tensor] = None, normalize: bool = True, dtype=torch.float32, want_bft: bool = True,
-        want_btf: bool = True):
-    """wave (B, L) f32 -> (feats_bft (B,64,T) f32 | None, feats_btf (B,T,64) dtype | None, frames (B) i32, pct (B) f32)."""
+        want_btf: bool = True, out_btf: Optional[torch.Tensor] = None, out_pct: Optional[torch.Tensor] = None):
+    """wave (B, L) f32 or int16 PCM -> (feats_bft (B,64,T) f32 | None, feats_btf (B,T,64) dtype | None, frames (B) i32, pct (B) f32).
+    dither: None, a (B, L) N(0,1) tensor, or a DeviceDither (noise generated inside the kernel)."""
     B, L = wave.shape
     T = mel_num_frames(L)
     dev = wave.device
     bft = torch.empty(B, 64, T, dtype=torch.float32, device=dev) if want_bft else None
-    btf = torch.empty(B, T, 64, dtype=dtype, device=dev) if want_btf else None
+    btf = None
+    if out_btf is not None:
+        if tuple(out_btf.shape) != (B, T, 64) or out_btf.dtype != dtype or not out_btf.is_contiguous():
+            raise ValueError("out_btf must be a contiguous (%d, %d, 64) %s tensor" % (B, T, dtype))
+        btf = out_btf
+    elif want_btf:
+        btf = torch.empty(B, T, 64, dtype=dtype, device=dev)
     frames = torch.empty(B, dtype=torch.int32, device=dev)
-    pct = torch.empty(B, dtype=torch.float32, device=dev)
+    pct = out_pct if out_pct is not None else torch.empty(B, dtype=torch.float32, device=dev)
     nb = _lib.load().lasr_mel_workspace_bytes(B, T)
     ws = _ws(nb, dev)
-    call("lasr_mel_fwd", _p(wave), _p(sample_lens), _p(dither), _p(aug), B, L, int(normalize), _p(bft), _p(btf),
+    src = wave_src(wave, dither)
+    call("lasr_mel_fwd_src", _lib.C.byref(src), _p(sample_lens), _p(aug), B, L, int(normalize), _p(bft), _p(btf),
          F32 if dtype == torch.float32 else BF16, _p(frames), _p(pct), _p(ws), nb, _stream())
     return bft, btf, frames, pct
 
@@ -387,3 +425,10 @@ def edit_distance_batch(tokens: torch.Tensor, n_tokens: torch.Tensor, targets: t
     call("lasr_edit_distance_batch", _p(tokens), _p(n_tokens), tokens.shape[1], _p(targets), _p(target_lens), targets.shape[1], B,
          int(space_id), _p(dist), _p(units), _p(totals), _stream())
     return dist, units
+
+
+def step_metrics(loss: torch.Tensor, dist: torch.Tensor, units: torch.Tensor, acc: torch.Tensor) -> None:
+    """fold one step's loss and batch WER into the device accumulators acc (7 f64): see lasr_step_metrics"""
+    if acc.dtype != torch.float64 or acc.numel() < 7:
+        raise TypeError("acc must hold 7 float64 values")
+    call("lasr_step_metrics", _p(loss), _p(dist), _p(units), dist.numel(), _p(acc), _stream())

@@ -54,6 +54,31 @@ class TrainStep:
             (self.comm is not None or torch.distributed.is_initialized())
         self._prefetched = None    # (key, feats, pct) of the batch announced by the previous step(prefetch_wave=...)
         self._lr_state = None      # device image of the schedule (use_device_schedule)
+        self._lr_epoch = None      # host schedule position the device image corresponds to
+
+    @classmethod
+    def from_optimizer(cls, model: NativeModel, optimizer, schedule=None, process_group=None, comm: Optional[Communicator] = None):
+        """The fused step over the state of a ``scheduler.novograd.Novograd`` (+ its ``CosineAnnealingWarmupRestarts``): the
+        moments and the device learning rate ARE the optimizer's tensors, so ``optimizer.state_dict()`` / checkpoints / resume
+        keep working while ``Trainer.fit`` drives this step instead of ``loss.backward(); optimizer.step()``."""
+        g = optimizer.param_groups[0]
+        ts = cls(model, learning_rate=float(g["lr"]), weight_decay=g["weight_decay"], betas=tuple(g["betas"]), eps=g["eps"],
+                 schedule=schedule, process_group=process_group, comm=comm)
+        ts.exp_avg, ts.exp_avg_sq, ts.lr_dev = optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.lr_dev
+        ts.lr = float(g["lr"])
+        ts.lr_dev.fill_(ts.lr)
+        ts._optimizer = optimizer
+        return ts
+
+    def sync_device_schedule(self) -> None:
+        """Re-upload the schedule after its host state changed behind the device twin's back (``load_state_dict`` on resume,
+        an assignment to ``ts.lr``): the rate the optimiser reads and the device state restart from the host object."""
+        if self.schedule is not None:
+            self.lr = self.schedule.lr
+        self.lr_dev.fill_(float(self.lr))
+        if self._lr_state is not None:
+            self._lr_state = None
+            self.use_device_schedule()
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP wrap-time broadcast of parameters and buffers from rank 0."""
@@ -83,7 +108,10 @@ class TrainStep:
         ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
                           self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         if self.schedule is not None:
+            if self._lr_state is not None and self.schedule.last_epoch != self._lr_epoch:
+                self.sync_device_schedule()                # the host schedule was loaded / reset since the last step
             self.lr = self.schedule.step()                 # host copy of the schedule: bookkeeping / logging / checkpoints
+            self._lr_epoch = self.schedule.last_epoch
             if self._lr_state is not None:                 # the rate the next step uses is computed on the device
                 _lib.call("lasr_lr_schedule_step", self._lr_state.data_ptr(), self.lr_dev.data_ptr(),
                           torch.cuda.current_stream().cuda_stream)
@@ -104,6 +132,7 @@ class TrainStep:
                   float(sc.min_lr), int(sc.warmup_steps), float(sc.gamma), int(sc.cycle), int(sc.step_in_cycle),
                   int(sc.cur_cycle_steps), int(sc.last_epoch))
         self._lr_state = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.model.device)
+        self._lr_epoch = int(sc.last_epoch)
 
     def step_features(self, feats, pct, targets, tgt_lens, want_logp: bool = True):
         m = self.model
@@ -132,7 +161,8 @@ class TrainStep:
 
     @staticmethod
     def _prefetch_key(wave, sample_lens, dither, aug):
-        return tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None for t in (wave, sample_lens, dither, aug))
+        return tuple(None if t is None else ((t.data_ptr(), tuple(t.shape), t._version) if torch.is_tensor(t) else ("obj", id(t)))
+                     for t in (wave, sample_lens, dither, aug))
 
     def step(self, wave, targets, tgt_lens, sample_lens=None, dither=None, aug=None, prefetch_wave=None, prefetch_lens=None,
              prefetch_dither=None, prefetch_aug=None, want_logp: bool = True):
@@ -161,25 +191,30 @@ class GraphedTrainStep:
 
     ``step(next_wave, targets, tgt_lens)``: like the prefetching ``TrainStep.step`` - the replay trains on the features the
     PREVIOUS replay computed and computes the features of ``next_wave`` inside its CTC launch; ``targets`` belong to the batch
-    being trained on.  prefetch=False: features and training step of the same ``wave`` in one replay (ragged buckets).
+    being trained on.  prefetch=False: features and training step of the same ``wave`` in one replay.
     Shapes are fixed at construction; one instance per (B, L, S)."""
 
     def __init__(self, ts: TrainStep, B: int, L: int, S: int, ragged: bool = False, prefetch: bool = True, want_logp: bool = False,
-                 inputs=None, feats_in=None, feats_out=None):
-        """inputs = (wave, sample_lens | None, targets, tgt_lens): tensors already resident in HBM that the graph reads IN PLACE
-        (``replay()`` then takes no data and nothing is copied); otherwise static buffers are allocated and ``step()`` copies
-        into them.  feats_in / feats_out = (feats, pct) pairs: the features this graph trains on and where it writes the
-        prefetched ones - two graphs with the pairs swapped ping-pong without the end-of-step copy."""
+                 inputs=None, feats_in=None, feats_out=None, wave_dtype=torch.float32, with_aug: bool = False, dither=None):
+        """inputs = (wave, sample_lens | None, targets, tgt_lens[, aug]): tensors already resident in HBM that the graph reads IN
+        PLACE (``replay()`` then takes no data and nothing is copied); otherwise static buffers are allocated and ``step()``
+        copies into them.  feats_in / feats_out = (feats, pct) pairs: the features this graph trains on and where it writes the
+        prefetched ones - two graphs with the pairs swapped ping-pong without the end-of-step copy.
+        wave_dtype: torch.float32 or torch.int16 (PCM); with_aug: a static (B, 4) SpecAugment block; dither: None, a static
+        (B, L) noise tensor or an ``ops.DeviceDither`` (fresh noise per replay)."""
         self.ts, self.prefetch, self.want_logp = ts, prefetch, want_logp
         dev = ts.model.device
         self.bound = inputs is not None
+        self.dither = dither
         if self.bound:
-            self.wave, self.lens, self.targets, self.tgt_lens = inputs
+            self.wave, self.lens, self.targets, self.tgt_lens = inputs[:4]
+            self.aug = inputs[4] if len(inputs) > 4 else None
         else:
-            self.wave = torch.zeros(B, L, dtype=torch.float32, device=dev)
+            self.wave = torch.zeros(B, L, dtype=wave_dtype, device=dev)
             self.lens = torch.full((B,), L, dtype=torch.int32, device=dev) if ragged else None
             self.targets = torch.zeros(B, S, dtype=torch.int64, device=dev)
             self.tgt_lens = torch.ones(B, dtype=torch.int32, device=dev)
+            self.aug = torch.zeros(B, 4, dtype=torch.int32, device=dev) if with_aug else None
         self.graph = None
         self.out = None
         self.F_cur, self.pct_cur = feats_in if feats_in is not None else (None, None)
@@ -188,67 +223,98 @@ class GraphedTrainStep:
     def _body(self):
         ts, m = self.ts, self.ts.model
         if self.prefetch:
-            nf, npct = m.arm_prefetch(self.wave, self.lens, out=self.feats_out)
+            nf, npct = m.arm_prefetch(self.wave, self.lens, self.dither, self.aug, out=self.feats_out)
             out = ts.step_features(self.F_cur, self.pct_cur, self.targets, self.tgt_lens, want_logp=self.want_logp)
             if self.feats_out is None:
                 self.F_cur.copy_(nf)
                 self.pct_cur.copy_(npct)
             return out
-        feats, pct = ts.features(self.wave, self.lens)
+        feats, pct = ts.features(self.wave, self.lens, self.dither, self.aug)
         return ts.step_features(feats, pct, self.targets, self.tgt_lens, want_logp=self.want_logp)
 
-    def capture(self, first_wave: Optional[torch.Tensor] = None, first_lens: Optional[torch.Tensor] = None, warmup: int = 2) -> None:
+    def capture(self, first_wave: Optional[torch.Tensor] = None, first_lens: Optional[torch.Tensor] = None, warmup: int = 2,
+                first_aug: Optional[torch.Tensor] = None) -> None:
         """first_wave: the batch the first replay trains on (prefetch mode: its features are computed eagerly here; not needed
-        with bound inputs + feats_in, whose features the caller provides).
+        with bound inputs + feats_in, or when ``prime()`` hands the features over).
         The eager warm-up passes and the capture pass leave the training state (parameters, BN buffers, optimiser moments,
-        schedule) exactly as it was: it is snapshotted before and restored after."""
+        schedule, dither / dropout counters) exactly as it was - also when the capture fails: it is snapshotted before and
+        restored in a ``finally``."""
         ts, m = self.ts, self.ts.model
-        if ts.world > 1 and not int(os.environ.get("LASR_GRAPH_DP", "0")):
-            raise RuntimeError("graph capture of the data-parallel step (RCCL inside the graph) is opt-in: LASR_GRAPH_DP=1")
+        if ts.world > 1 and not graph_dp_enabled():
+            raise RuntimeError("graph capture of the data-parallel step (RCCL inside the graph) is switched off: LASR_GRAPH_DP=0")
         ts.use_device_schedule()
         dev_state = [m.params, m.buffers, ts.exp_avg, ts.exp_avg_sq, ts.lr_dev] + ([ts._lr_state] if ts._lr_state is not None else [])
+        if hasattr(self.dither, "step"):
+            dev_state.append(self.dither.step)
+        if getattr(m, "drop_step", None) is not None:
+            dev_state.append(m.drop_step)
         snap = [t.clone() for t in dev_state]
         sched_sd = dict(ts.schedule.state_dict()) if ts.schedule is not None else None
-        gstep, bump = ts.global_step, m._bump
+        gstep, bump, lr_epoch = ts.global_step, m._bump, ts._lr_epoch
         counters = {k: v.clone() for k, v in m.counters.items()}
-        if not self.bound:
-            self.wave.copy_(first_wave)              # warm-up needs real audio (an all-zero wave has zero variance)
-            if self.lens is not None and first_lens is not None:
-                self.lens.copy_(first_lens)
         f = p_ = None
-        if self.prefetch and self.F_cur is None:
-            f, p_ = ts.features(first_wave, first_lens)
-            self.F_cur, self.pct_cur = f.clone(), p_.clone()
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream(device=m.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):            # eager warm-up on a side stream (allocator / lazy-init settle before capture)
-            for _ in range(warmup):
-                self._body()
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):       # records the launches; nothing executes
-            self.out = self._body()
-        for t, s_ in zip(dev_state, snap):
-            t.copy_(s_)
-        if f is not None:
-            self.F_cur.copy_(f)
-            self.pct_cur.copy_(p_)
-        if sched_sd is not None:
-            ts.schedule.load_state_dict(sched_sd)
-            ts.lr = ts.schedule.lr
-        ts.global_step, m._bump = gstep, bump
-        m.counters.update(counters)
-        torch.cuda.synchronize()
+        try:
+            if not self.bound and first_wave is not None:
+                self.wave.copy_(first_wave)              # warm-up needs real audio (an all-zero wave has zero variance)
+                if self.lens is not None and first_lens is not None:
+                    self.lens.copy_(first_lens)
+                if self.aug is not None and first_aug is not None:
+                    self.aug.copy_(first_aug)
+            if self.prefetch and self.F_cur is None:
+                f, p_ = ts.features(first_wave, first_lens, None, first_aug)
+                self.F_cur, self.pct_cur = f.clone(), p_.clone()
+            elif self.prefetch and not self.bound and self.feats_out is None:
+                f, p_ = self.F_cur.clone(), self.pct_cur.clone()     # (the warm-up passes overwrite the primed features)
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream(device=m.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):            # eager warm-up on a side stream (allocator / lazy-init settle before capture)
+                for _ in range(warmup):
+                    self._body()
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):            # records the launches; nothing executes
+                self.out = self._body()
+            self.graph = graph
+        finally:
+            torch.cuda.synchronize()
+            for t, s_ in zip(dev_state, snap):
+                t.copy_(s_)
+            if f is not None:
+                self.F_cur.copy_(f)
+                self.pct_cur.copy_(p_)
+            if sched_sd is not None:
+                ts.schedule.load_state_dict(sched_sd)
+                ts.lr = ts.schedule.lr
+                ts.schedule._publish()
+            ts.global_step, m._bump, ts._lr_epoch = gstep, bump, lr_epoch
+            m.counters.update(counters)
+            ts._prefetched = None
+            m.disarm_prefetch()
+            torch.cuda.synchronize()
 
-    def step(self, wave: torch.Tensor, targets: torch.Tensor, tgt_lens: torch.Tensor, lens: Optional[torch.Tensor] = None):
+    def prime(self, feats: torch.Tensor, pct: torch.Tensor) -> None:
+        """the features of the batch the next replay trains on (prefetch mode with the graph's own feature buffers)"""
+        if self.F_cur is None:
+            self.F_cur, self.pct_cur = feats.clone(), pct.clone()
+        elif feats.data_ptr() != self.F_cur.data_ptr():
+            self.F_cur.copy_(feats)
+            self.pct_cur.copy_(pct)
+
+    def step(self, wave: torch.Tensor, targets: torch.Tensor, tgt_lens: torch.Tensor, lens: Optional[torch.Tensor] = None,
+             aug: Optional[torch.Tensor] = None):
         """copies the inputs into the graph's static buffers and replays; returns the static (loss, nll, logp, argmax) tensors"""
         if self.bound:
             raise RuntimeError("this graph reads its inputs in place (inputs=...): use replay()")
         self.wave.copy_(wave, non_blocking=True)
         if self.lens is not None and lens is not None:
             self.lens.copy_(lens, non_blocking=True)
+        if self.aug is not None:
+            if aug is not None:
+                self.aug.copy_(aug, non_blocking=True)
+            else:
+                self.aug.zero_()
         self.targets.copy_(targets, non_blocking=True)
         self.tgt_lens.copy_(tgt_lens, non_blocking=True)
         return self.replay()
@@ -260,5 +326,12 @@ class GraphedTrainStep:
         ts.model.bump_counters(1)
         if ts.schedule is not None:
             ts.lr = ts.schedule.step()
+            ts._lr_epoch = ts.schedule.last_epoch
         ts.global_step += 1
         return self.out
+
+
+def graph_dp_enabled() -> bool:
+    """hipGraph capture of the data-parallel step (ncclAllReduce on the library's side stream inside the capture): on by default,
+    ``LASR_GRAPH_DP=0`` keeps multi-rank steps eager"""
+    return os.environ.get("LASR_GRAPH_DP", "1") != "0"

@@ -161,7 +161,10 @@ def main(argv=None):
                                   test_manifest=data_cfg.get("test_manifest"), num_worker=data_cfg.get("num_worker"),
                                   train_max_duration=data_cfg.get("train_max_duration"),
                                   dev_max_duration=data_cfg.get("dev_max_duration"),
-                                  act_dtype=torch.float32 if dtype == "f32" else torch.bfloat16, device=device)
+                                  act_dtype=torch.float32 if dtype == "f32" else torch.bfloat16, device=device,
+                                  bucket_by_length=bool(data_cfg.get("bucket_by_length", False)),
+                                  bucket_batches=int(data_cfg.get("bucket_batches", 50)),
+                                  train_crop=bool(data_cfg.get("train_crop", True)))
     model = LightingModule(learning_rate=tran_cfg.get("learning_rate"), weight_decay=tran_cfg.get("weight_decay"), labels=labels,
                            total_epoch=tran_cfg.get("total_epoch"), drop_rate=model_cfg.get("drop_rate"), mask=model_cfg.get("mask"),
                            use_cer=use_cer, variant=model_cfg.get("variant", "plain"), act=model_cfg.get("act", "relu"), dtype=dtype,
@@ -169,7 +172,7 @@ def main(argv=None):
     trainer = Trainer(gpus=tran_cfg.get("gpus"), resume_from_checkpoint=tran_cfg.get("checkpoint"), accelerator=tran_cfg.get("accelerator"),
                       max_epochs=tran_cfg.get("total_epoch"), check_val_every_n_epoch=tran_cfg.get("check_val_every_n_epoch", 1),
                       num_nodes=tran_cfg.get("num_nodes"), default_root_dir=cfg.get("output_dir", "."),
-                      max_steps=tran_cfg.get("max_steps"))
+                      max_steps=tran_cfg.get("max_steps"), log_every_n_steps=tran_cfg.get("log_every_n_steps", 50))
     trainer.fit(model, datamodule=data_module)
     trainer.test(model, test_dataloaders=data_module.test_dataloader())
     return trainer

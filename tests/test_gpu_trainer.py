@@ -1,0 +1,178 @@
+"""GPU tier: the reference's surface (LightingModule + LibriDataModule + Trainer.fit, train.py:64-86,233-252) drives the FUSED
+native step - the path bench.py measures - and lands bit for bit where a hand-driven TrainStep lands on the same batches."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LABELS = [c.strip() for c in open(os.path.join(ROOT, "data", "labels.txt")).readlines()]
+
+
+def _corpus(tmp_path, n_train=16, seconds=2.0, ragged=False, labels=None, n_dev=4):
+    data = tmp_path / "synth"
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "make_synth_data.py"), "--out", str(data), "--n-train", str(n_train),
+           "--n-dev", str(n_dev), "--seconds", str(seconds)] + (["--ragged"] if ragged else [])
+    if labels:
+        cmd += ["--labels", labels]
+    subprocess.run(cmd, check=True)
+    return data
+
+
+def test_mel_pcm16_device_dither_is_bit_identical_to_f32_with_noise_tensor(dev):
+    """int16 PCM + dither generated in the kernel == the f32 waveform (pcm / 32768) + the same noise as a tensor"""
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, L = 3, 16000 + 123
+    pcm = torch.randint(-20000, 20000, (B, L), generator=g, dtype=torch.int16)
+    lens = torch.tensor([L, 9000, 777], dtype=torch.int32)
+    for i in range(B):
+        pcm[i, lens[i]:] = 0
+    pcm_d, lens_d = pcm.to(dev), lens.to(dev)
+    f32 = (pcm.float() / 32768.0).to(dev)
+    dd = ops.DeviceDither(1234, dev)
+    noise = dd.noise(B, L)
+    n = noise.cpu()
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 1.0) < 0.02 and float(n.abs().max()) < 7.0
+    assert abs(float((n[:, 1:] * n[:, :-1]).mean())) < 0.02                       # neighbouring samples uncorrelated
+    bft_a, btf_a, fr_a, pct_a = ops.mel(pcm_d, lens_d, dd, None, True, torch.float32)
+    assert int(dd.step.item()) == 1                                               # the call consumed one draw
+    bft_b, btf_b, fr_b, pct_b = ops.mel(f32, lens_d, noise, None, True, torch.float32)
+    assert torch.equal(bft_a, bft_b) and torch.equal(btf_a, btf_b) and torch.equal(fr_a, fr_b) and torch.equal(pct_a, pct_b)
+    # no dither at all: the int16 path equals the f32 path; and dither moves the features by ~1e-5-sized noise only
+    bft_c = ops.mel(pcm_d, lens_d, None, None, True, torch.float32)[0]
+    bft_d = ops.mel(f32, lens_d, None, None, True, torch.float32)[0]
+    assert torch.equal(bft_c, bft_d)
+    assert 0 < float((bft_a - bft_c).abs().max()) < 0.05
+    noise2 = dd.noise(B, L)
+    assert not torch.equal(noise, noise2)                                         # next step, fresh noise
+    # the prefetch route (features inside the CTC launch) draws the same noise as the stand-alone call
+    from lightning_asr_amd.engine import NativeModel
+    m = NativeModel("plain", 28, mask=True, dtype=torch.float32, device=dev)
+    m.init_parameters(0)
+    step_before = dd.step.clone()
+    want = ops.mel(pcm_d, lens_d, dd, None, True, torch.float32, want_bft=False)[1]
+    dd.step.copy_(step_before)
+    f0 = ops.mel(pcm_d, lens_d, None, None, True, torch.float32, want_bft=False)
+    nf, npct = m.arm_prefetch(pcm_d, lens_d, dd, None)
+    tg = torch.randint(0, 27, (B, 5), generator=g).to(dev)
+    m.loss_backward(f0[1], f0[3], tg, torch.full((B,), 5, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    assert torch.equal(nf, want)
+
+
+def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph):
+    from lightning_asr_amd import ops
+    from lightning_asr_amd.data_module import LibriDataModule
+    from lightning_asr_amd.engine import NativeModel
+    from lightning_asr_amd.lightning_compat import Trainer, seed_everything
+    from lightning_asr_amd.schedule import CosineAnnealingWarmupRestarts
+    from lightning_asr_amd.step import TrainStep
+    from lightning_asr_amd.train import LightingModule
+    monkeypatch.setenv("LASR_TRAINER_GRAPH", "1" if graph else "0")
+    data = _corpus(tmp_path, n_train=4 * steps, seconds=2.0)
+    seed_everything(0)
+    act = torch.float32 if dtype == "f32" else torch.bfloat16
+    dm = LibriDataModule([str(data / "train.json")], str(data / "dev.json"), str(data / "dev.json"), LABELS, train_bs=4, dev_bs=4,
+                         num_worker=2, device=str(dev), act_dtype=act, train_crop=crop)
+    model = LightingModule(learning_rate=1e-2, weight_decay=1e-3, labels=LABELS, total_epoch=1, drop_rate=0.0, mask=True, use_cer=True,
+                           dtype=dtype, device=str(dev), warmup_steps=2)
+    init = {"params": model.encoder.native.params.clone(), "buffers": model.encoder.native.buffers.clone()}
+    seen = []
+
+    def hook(db):
+        seen.append({"pcm": db.pcm.clone(), "lens": db.lens.clone(), "targets": db.targets.clone(), "sizes": db.sizes.clone(),
+                     "aug": None if db.aug is None else db.aug.clone()})
+    tr = Trainer(max_epochs=1, default_root_dir=str(tmp_path / "run"), device=str(dev), check_val_every_n_epoch=1, log_every_n_steps=2)
+    tr._fused_on_batch = hook
+    hist = tr.fit(model, dm)
+    assert tr.fused is not None and tr.fused.source_kind == "NativeSource"            # the fused step over the native ingest ran
+    assert tr.global_step == steps and len(seen) == steps
+    assert np.isfinite(hist[-1]["train_loss"]) and hist[-1]["train_wer"] >= 0 and "val_wer_total" in hist[-1]
+    if graph:
+        assert tr.fused.graph_steps > 0, "fixed-shape batches must reach the captured graph"
+    else:
+        assert tr.fused.graph_steps == 0
+    # the same batches through a hand-driven TrainStep (the bench path): same seed for the in-kernel dither
+    m2 = NativeModel("plain", 28, mask=True, act="relu", dtype=act, device=dev)
+    m2.params.copy_(init["params"]); m2.buffers.copy_(init["buffers"])
+    sched = CosineAnnealingWarmupRestarts(None, first_cycle_steps=1 * steps, cycle_mult=2, max_lr=1e-2, min_lr=1e-4, warmup_steps=2, gamma=0.5)
+    ts = TrainStep(m2, 1e-2, 1e-3, schedule=sched)
+    dd = ops.DeviceDither(tr.fused.dither.seed, dev)
+    for i, b in enumerate(seen):
+        nxt = seen[i + 1] if i + 1 < len(seen) else None
+        ts.step(b["pcm"], b["targets"], b["sizes"], sample_lens=b["lens"], dither=dd, aug=b["aug"],
+                prefetch_wave=None if nxt is None else nxt["pcm"], prefetch_lens=None if nxt is None else nxt["lens"],
+                prefetch_dither=None if nxt is None else dd, prefetch_aug=None if nxt is None else nxt["aug"], want_logp=False)
+    torch.cuda.synchronize()
+    # (validation ran at the end of the epoch and does not touch the parameters; BN running statistics are training-only)
+    assert torch.equal(model.encoder.native.params, m2.params), float((model.encoder.native.params - m2.params).abs().max())
+    assert torch.equal(model.encoder.native.buffers, m2.buffers)
+    return tr
+
+
+def test_trainer_fit_equals_trainstep_bit_identical_eager_f32(dev, tmp_path, monkeypatch):
+    _fit_and_replay(dev, tmp_path, "f32", 4, True, monkeypatch, graph=False)
+
+
+def test_trainer_fit_equals_trainstep_bit_identical_graph_bf16(dev, tmp_path, monkeypatch):
+    """fixed-length clips, no crop: from the third sighting of the batch shape the steps replay a captured hipGraph"""
+    tr = _fit_and_replay(dev, tmp_path, "bf16", 8, False, monkeypatch, graph=True)
+    assert tr.fused.eager_steps >= 2
+
+
+def test_trainer_uses_the_lean_head_for_a_large_vocabulary(dev, tmp_path):
+    """C = 4334 (AISHELL) in bf16: Trainer.fit must not materialise (B, T', C) f32 log-probs (BASELINE cfg5 through train.py)"""
+    vocab = os.path.join(ROOT, "data", "aishell1-vocab.txt")
+    data = _corpus(tmp_path, n_train=8, seconds=3.0, ragged=True, labels=vocab)
+    from lightning_asr_amd.train import main
+    out = tmp_path / "run"
+    tr = main(["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
+               "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % vocab, "train.train_batch_size=4",
+               "train.dev_batch_size=4", "train.total_epoch=1", "train.precision=16", "train.warmup_steps=0",
+               "data.bucket_by_length=true", "data.bucket_batches=2", "output_dir=%s" % out])
+    assert tr.fused is not None and tr.global_step == 2
+    native = tr.fused.native
+    assert native.lean_head and native._last_logp is None          # the step ran on bf16 logits + row statistics
+    rec = tr.history[-1]
+    assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0 and np.isfinite(rec["val_loss"])
+
+
+def test_bucketed_fit_keeps_padding_under_ten_percent(dev, tmp_path):
+    """BASELINE cfg5 'bucketed padding': data.bucket_by_length from the config, ragged 2-8 s manifest"""
+    data = _corpus(tmp_path, n_train=96, seconds=8.0, ragged=True)
+    from lightning_asr_amd.train import main
+    common = ["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
+              "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % os.path.join(ROOT, "data", "labels.txt"),
+              "train.train_batch_size=8", "train.dev_batch_size=4", "train.total_epoch=1", "train.precision=16", "train.warmup_steps=0",
+              "train.check_val_every_n_epoch=5"]
+    tr = main(common + ["data.bucket_by_length=true", "data.bucket_batches=12", "output_dir=%s" % (tmp_path / "b")])
+    f = tr.fused
+    pad_b = 1.0 - f.samples_real / f.samples_padded
+    tr2 = main(common + ["output_dir=%s" % (tmp_path / "u")])
+    f2 = tr2.fused
+    pad_u = 1.0 - f2.samples_real / f2.samples_padded
+    assert tr.global_step == 12 and pad_b <= 0.10 < pad_u, (pad_b, pad_u)
+
+
+def test_wer_host_fallback_for_multichar_labels(dev):
+    """CER over a vocabulary with a multi-character entry: the device token units are not the reference's characters
+    (utils/asr_metrics.py:215-216), so the metric takes the host path; both paths agree when labels are single characters"""
+    from lightning_asr_amd.utils.asr_metrics import WER
+    labels = ["a", "b", "<unk>", "c"]
+    w = WER(labels, use_cer=True)
+    assert not w.device_ok
+    ids = torch.tensor([[0, 4, 2, 2, 4, 3]], dtype=torch.int32, device=dev)        # "a<unk>c"
+    tg = torch.tensor([[0, 1, 3]])                                                   # "abc"
+    val = float(w(ids, tg, torch.tensor([3]), torch.tensor([6], dtype=torch.int32, device=dev)))
+    assert val == pytest.approx(5 / 3)               # characters: "a<unk>c" vs "abc" = 5 edits over 3 reference characters
+    w2 = WER(["a", "b", "d", "c"], use_cer=True)
+    assert w2.device_ok
+    val2 = float(w2(ids, tg, torch.tensor([3]), torch.tensor([6], dtype=torch.int32, device=dev)))
+    assert val2 == pytest.approx(1 / 3)
+    assert float(w2.compute_total()) == pytest.approx(1 / 3)

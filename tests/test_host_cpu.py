@@ -167,3 +167,96 @@ def test_bucket_batch_sampler_padding_and_sharding():
     b = BucketBatchSampler(dur, 32, bucket_batches=10, seed=1, rank=1, world=2)
     la, lb = list(a), list(b)
     assert len(la) == len(lb) == 15 and not ({i for x in la for i in x} & {i for x in lb for i in x})
+
+
+def _write_wav(path, pcm, channels=1):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+
+
+def test_native_wav_batch_reader_matches_python_wave(tmp_path):
+    """lasr_wav_read_batch (host threads, no device work) == the python `wave` decode of data_module.load_wav, including the
+    reference's bug-compatible random sub-sequence (data_module.py:138-148) taken as a slice of the file"""
+    import numpy as np
+    import torch
+    from lightning_asr_amd import ingest
+    from lightning_asr_amd.data_module import load_wav
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(9):
+        n = 16000 + 321 * i
+        ch = 2 if i == 4 else 1
+        p = tmp_path / ("%d.wav" % i)
+        _write_wav(p, rng.integers(-30000, 30000, size=(n, ch), dtype=np.int16), ch)
+        paths.append(str(p))
+    assert ingest.wav_info(paths[4]) == (16000 + 321 * 4, 2, 16000, 16)
+    out = torch.empty(9 * 20000, dtype=torch.int16)
+    lens = torch.empty(9, dtype=torch.int32)
+    ld = ingest.read_wav_batch(paths, out, lens, n_threads=3)
+    assert ld % 8 == 0 and ld >= 16000 + 321 * 8
+    for i, p in enumerate(paths):
+        ref = (load_wav(p)[0] * 32768).to(torch.int16)
+        assert int(lens[i]) == ref.numel() and torch.equal(out[i * ld:i * ld + ref.numel()], ref)
+        assert not out[i * ld + ref.numel():(i + 1) * ld].any()
+    u = rng.uniform(size=(9, 2))
+    ld2 = ingest.read_wav_batch(paths, out, lens, crop_u=u, crop_weight=0.98, n_threads=2)
+    for i, p in enumerate(paths):
+        x = load_wav(p)
+        L = x.shape[1]
+        tl = int(L * (0.98 + 0.02 * u[i, 0]))
+        loc = int(u[i, 1] * (L - tl))
+        ref = (x[:, loc:tl][0] * 32768).to(torch.int16)
+        assert int(lens[i]) == ref.numel() and torch.equal(out[i * ld2:i * ld2 + ref.numel()], ref)
+    with pytest.raises(Exception, match="do not fit"):
+        ingest.read_wav_batch(paths, out[:1000], lens)
+    bad = tmp_path / "bad.wav"
+    bad.write_bytes(b"not a wav file at all")
+    with pytest.raises(Exception, match="RIFF"):
+        ingest.read_wav_batch([str(bad)], out, lens)
+
+
+def test_batch_producer_fills_ring_slots(tmp_path):
+    """manifest -> BatchProducer -> HostBatch: PCM rows, lens, padded targets, SpecAugment rectangles, metadata layout"""
+    import json
+    import numpy as np
+    import torch
+    from lightning_asr_amd import ingest
+    from lightning_asr_amd.data_module import AudioParser, MyAudioDataset
+    rng = np.random.default_rng(1)
+    labels = list("abcdefg")
+    man = tmp_path / "m.json"
+    with open(man, "w") as f:
+        for i in range(6):
+            n = 8000 + 1000 * i
+            p = tmp_path / ("c%d.wav" % i)
+            _write_wav(p, rng.integers(-1000, 1000, size=(n, 1), dtype=np.int16))
+            f.write(json.dumps({"audio_filepath": str(p), "duration": n / 16000.0, "text": "abc"[: 1 + i % 3] + "g"}) + "\n")
+    ds = MyAudioDataset([str(man)], labels, mask=True)
+    assert ingest.fast_ingest_ok(ds)
+    ring = ingest.PinnedRing(2, 3 * 14000, 64, pin=False)
+    ap = AudioParser.__new__(AudioParser)
+    import random
+    ap.rand = random.Random(0)
+    prod = ingest.BatchProducer(ds, [[0, 1, 2], [3, 4, 5]], ring, mask=True, audio_parser=ap, n_threads=2, crop=False)
+    prod.start()
+    got = []
+    while True:
+        hb = prod.out.get(timeout=30)
+        if hb is None:
+            break
+        assert not isinstance(hb, BaseException), hb
+        got.append(hb)
+    assert len(got) == 2 and [hb.slot for hb in got] == [0, 1]
+    hb = got[1]
+    assert hb.B == 3 and hb.lens.tolist() == [11000, 12000, 13000] and hb.ld == 13000 and hb.S == 4
+    assert hb.sizes.tolist() == [2, 3, 4] and hb.targets[2].tolist() == [0, 1, 2, 6] and hb.targets[0].tolist() == [0, 6, 0, 0]
+    assert hb.aug.shape == (3, 4) and (hb.aug[:, 1] < 27).all() and abs(hb.seconds - 36000 / 16000.0) < 1e-9
+    pcm = ring.pcm[hb.slot][:3 * hb.ld].view(3, hb.ld)
+    from lightning_asr_amd.data_module import load_wav
+    ref = (load_wav(ds.datasets[4]["audio_filepath"])[0] * 32768).to(torch.int16)
+    assert torch.equal(pcm[1, :12000], ref) and not pcm[1, 12000:].any()
+    # the packed metadata block holds the same values at the documented offsets
+    o_lens, o_sizes, o_aug, o_tg, words = ingest._meta_layout(3, 4, True)
+    assert hb.meta[o_lens:o_lens + 3].tolist() == [11000, 12000, 13000] and words == hb.meta_words
+    assert hb.meta[o_tg:o_tg + 24].view(torch.int64).view(3, 4)[2].tolist() == [0, 1, 2, 6]
