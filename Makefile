@@ -5,6 +5,12 @@ SRC := $(wildcard lightning_asr_amd/csrc/*.hip)
 OBJ := $(patsubst lightning_asr_amd/csrc/%.hip,build/%.o,$(SRC))
 CXXFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Wall -Wno-unused-function
 
+all: lightning_asr_amd/liblasr.so tests/stub_rccl/libstubrccl.so
+
+# test infrastructure: a stand-in librccl for several ranks sharing one GPU (tests/test_gpu_dp.py, via LASR_RCCL_PATH)
+tests/stub_rccl/libstubrccl.so: tests/stub_rccl/stub_rccl.hip
+	$(HIPCC) -O2 --offload-arch=$(ARCH) -fPIC -shared -std=c++17 -o $@ $< -lrt
+
 lightning_asr_amd/liblasr.so: $(OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
@@ -16,4 +22,6 @@ build/%.o: lightning_asr_amd/csrc/%.hip
 -include $(OBJ:.o=.d)
 
 clean:
-	rm -rf build lightning_asr_amd/liblasr.so
+	rm -rf build lightning_asr_amd/liblasr.so tests/stub_rccl/libstubrccl.so
+
+.PHONY: all clean

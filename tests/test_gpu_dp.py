@@ -318,3 +318,95 @@ def test_graphed_step_bound_inputs_ping_pong(dev):
     torch.cuda.synchronize()
     assert l0 == l1
     assert torch.equal(m0.params, m1.params)
+
+
+# ---- the library's own communicator with world == 2 -----------------------------------------------------------------------------
+# Real RCCL refuses two ranks on one device and the test box has one GPU, so LASR_RCCL_PATH points lasr_comm_* at
+# tests/stub_rccl/libstubrccl.so: the eight nccl* entry points comm.hip binds, implemented over hipIpc staging buffers +
+# stream-ordered barriers for processes sharing a GPU.  Everything above the nccl* calls is the product path: unique-id bootstrap,
+# lasr_comm_init, the side stream and its events, bucket ranges of the staged backward, broadcast, wait, 1/world in NovoGrad.
+STUB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "libstubrccl.so")
+
+
+def _stub_worker(rank, world, port, q, variant, n_buckets):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LASR_RCCL_PATH=STUB,
+                      LASR_DP_BUCKETS=str(n_buckets))
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # carries the 128-byte unique id, nothing else
+    try:
+        from lightning_asr_amd.comm import Communicator
+        from lightning_asr_amd.engine import NativeModel
+        from lightning_asr_amd.step import TrainStep
+        dev = torch.device("cuda", 0)
+        comm = Communicator.from_torch_distributed(dev)
+        assert comm.world == 2 and comm.rank == rank
+        # collectives by themselves: SUM over ranks, grouped ranges, broadcast from a non-zero root
+        x = torch.arange(1000, dtype=torch.float32, device=dev) * (rank + 1)
+        comm.all_reduce(x)
+        y = torch.full((4096,), float(rank + 1), device=dev)
+        comm.all_reduce_ranges(y, [(0, 100), (2000, 4096)])
+        z = torch.full((777,), float(10 + rank), device=dev)
+        comm.broadcast(z, 1)
+        comm.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(x, torch.arange(1000, dtype=torch.float32, device=dev) * 3)
+        assert (y[:100] == 3).all() and (y[100:2000] == rank + 1).all() and (y[2000:] == 3).all() and (z == 11).all()
+        m = NativeModel(variant, 28, mask=True, act="relu", dtype=torch.float32, device=dev)
+        m.init_parameters(seed=rank)                 # ranks start apart: the wrap-time broadcast must align them
+        ts = TrainStep(m, 1e-2, 1e-3, comm=comm)
+        assert ts.world == 2 and ts.overlap and ts.comm is comm
+        ts.broadcast_parameters()
+        losses = []
+        for s in range(STEPS):
+            wave, tg, tl = _batch(rank, s)
+            loss, *_ = ts.step(wave.to(dev), tg.to(dev), tl.to(dev))
+            losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        q.put((rank, m.params.cpu().numpy(), losses))
+        dist.barrier()
+        comm.close()
+    except Exception:
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant,n_buckets", [("plain", 2), ("context", 4)])
+def test_library_communicator_two_ranks_over_stub_rccl(dev, variant, n_buckets):
+    import torch.multiprocessing as mp
+    from lightning_asr_amd.engine import NativeModel
+    from lightning_asr_amd.step import TrainStep
+    assert os.path.exists(STUB), "build tests/stub_rccl/libstubrccl.so (make)"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stub_worker, args=(r, 2, port, q, variant, n_buckets)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] is not None, r[2]
+    res = [(r[0], torch.from_numpy(r[1]), r[2]) for r in res]
+    assert torch.equal(res[0][1], res[1][1])                      # replicas stay bit-identical
+    m = NativeModel(variant, 28, mask=True, act="relu", dtype=torch.float32, device=dev)
+    m.init_parameters(seed=0)
+    ts = TrainStep(m, 1e-2, 1e-3)
+    for s in range(STEPS):
+        g = []
+        for r in range(2):
+            wave, tg, tl = _batch(r, s)
+            feats, pct = ts.features(wave.to(dev))
+            loss, *_ = m.loss_backward(feats, pct, tg.to(dev), tl.to(dev))
+            g.append(m.grads.clone())
+            assert res[r][2][s] == pytest.approx(float(loss.item()), rel=1e-5)
+        m.grads.copy_((g[0] + g[1]) * 0.5)
+        ts.optimizer_step()
+    got, ref = res[0][1].double(), m.params.cpu().double()
+    assert torch.isfinite(got).all()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-6
