@@ -397,7 +397,8 @@ def main():
             batches.append((w, None, t_, l_, B * cfg["clip_s"], 0.0))
     step_no = [0]
     audio_s = [0.0]
-    use_graph = args.graph and world == 1           # (RCCL inside a captured graph is opt-in: LASR_GRAPH_DP=1)
+    from lightning_asr_amd.step import graph_dp_enabled
+    use_graph = args.graph and (world == 1 or graph_dp_enabled())   # N > 1: the staged step with its RCCL all-reduces is captured too (LASR_GRAPH_DP=0: eager)
     graphs = {}
     if use_graph:
         # hipGraph replay: the ~200 launches of a step become one graph launch (host-enqueue time no longer bounds the step).  The
@@ -427,6 +428,12 @@ def main():
             sys.stderr.write("graph capture failed (%s): falling back to eager launches\n" % (e,))
             use_graph, graphs = False, {}
             torch.cuda.synchronize()
+        if dist is not None:                             # every rank replays, or none does (a lone eager rank would issue its collectives differently)
+            okf = torch.tensor([1 if use_graph else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0 and use_graph:
+                sys.stderr.write("another rank could not capture: eager launches on all ranks\n")
+                use_graph, graphs = False, {}
 
     def one_step(eager=False):
         i = step_no[0]
@@ -536,6 +543,9 @@ def main():
                    "audio_seconds_per_step_per_gpu": timed_audio_s / args.steps,
                    "padding_frac": sum(b[5] for b in batches) / len(batches),
                    "n_class": V + 1, "parallelism": "dp%d" % world, "feature_prefetch": bool(args.prefetch), "hip_graph": bool(use_graph),
+                   "grad_exchange": None if world == 1 else ("lasr_comm (librccl on the library's side stream, %d buckets overlapped with backward)"
+                                                             % int(os.environ.get("LASR_DP_BUCKETS", "2")) if ts.comm is not None
+                                                             else "torch.distributed all_reduce"),
                    "excluded": "H2D of the PCM (waves resident in HBM); the reference's per-step greedy decode + WER logging (train.py:80)"},
         "final_loss": final_loss,
         "roofline": roofline,

@@ -48,13 +48,43 @@ class TrainStep:
             self.world = comm.world
         elif self.world > 1 and os.environ.get("LASR_COMM", "rccl") == "rccl" and \
                 torch.distributed.get_backend(process_group) == "nccl":
-            self.comm = Communicator.from_torch_distributed(dev, process_group)
+            self.comm = self._checked_communicator(dev, process_group)
         # exercise the staged + async all-reduce path on a 1-rank group too (validation on one GPU)
         self.force_staged = bool(int(os.environ.get("LASR_FORCE_OVERLAP", "0"))) and \
             (self.comm is not None or torch.distributed.is_initialized())
         self._prefetched = None    # (key, feats, pct) of the batch announced by the previous step(prefetch_wave=...)
         self._lr_state = None      # device image of the schedule (use_device_schedule)
         self._lr_epoch = None      # host schedule position the device image corresponds to
+
+    @staticmethod
+    def _checked_communicator(dev, process_group) -> Optional[Communicator]:
+        """The library's RCCL communicator, proven on THIS machine before it carries gradients: every rank all-reduces
+        (rank + 1, 1) through it on the side stream and must read (world (world + 1) / 2, world); the ranks then agree (one
+        torch.distributed MIN) on whether all of them passed.  Any failure - librccl missing, init error, a wrong sum - sends the
+        whole group back to torch.distributed's all-reduce (what LASR_COMM=torch selects), loudly."""
+        import sys
+        import torch.distributed as dist
+        comm, ok, why = None, 1, ""
+        try:
+            comm = Communicator.from_torch_distributed(dev, process_group)
+            probe = torch.tensor([float(comm.rank + 1), 1.0], dtype=torch.float32, device=dev)
+            comm.all_reduce(probe)
+            comm.wait()
+            w = comm.world
+            got = probe.cpu().tolist()
+            if got != [w * (w + 1) / 2.0, float(w)]:
+                ok, why = 0, "all-reduce self-check read %s" % (got,)
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+        if int(flag.item()) == 1:
+            return comm
+        sys.stderr.write("lasr_comm self-check failed on rank %d (%s): gradient exchange falls back to torch.distributed\n"
+                         % (dist.get_rank(process_group), why or "another rank failed"))
+        if comm is not None:
+            comm.close()
+        return None
 
     @classmethod
     def from_optimizer(cls, model: NativeModel, optimizer, schedule=None, process_group=None, comm: Optional[Communicator] = None):
@@ -274,7 +304,9 @@ class GraphedTrainStep:
             cur.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):            # records the launches; nothing executes
+            # thread_local: the ingest threads (pinned allocations, H2D copies on their own stream) and RCCL's own bookkeeping may
+            # call the runtime while this thread records
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):            # records the launches; nothing executes
                 self.out = self._body()
             self.graph = graph
         finally:

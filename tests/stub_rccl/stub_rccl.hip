@@ -33,29 +33,26 @@ struct StubComm {
   char name[64];
   Shared* sh = nullptr;
   float* stage[kMaxRanks] = {};                // [rank] = my own allocation, peers through hipIpcOpenMemHandle
-  long long barriers = 0;                      // barriers issued so far by this rank (host-side counter)
+  long long executed = 0;                      // barriers EXECUTED so far by this rank (counted inside the callback, so a barrier
+                                               // replayed from a captured hipGraph gets a fresh number each time it runs)
 };
 
-struct BarrierArg { StubComm* c; long long target; };
-
 void barrier_cb(void* p) {
-  BarrierArg* a = static_cast<BarrierArg*>(p);
-  StubComm* c = a->c;
-  c->sh->arrive[c->rank].store(a->target, std::memory_order_release);
+  StubComm* c = static_cast<StubComm*>(p);
+  const long long target = ++c->executed;      // callbacks of one stream run in order: the k-th barrier of every rank pairs up
+  c->sh->arrive[c->rank].store(target, std::memory_order_release);
   const time_t t0 = time(nullptr);
   for (int r = 0; r < c->world; ++r) {
-    while (c->sh->arrive[r].load(std::memory_order_acquire) < a->target) {
-      if (time(nullptr) - t0 > 120) { fprintf(stderr, "stub_rccl: rank %d timed out waiting for rank %d at barrier %lld\n", c->rank, r, a->target); abort(); }
+    while (c->sh->arrive[r].load(std::memory_order_acquire) < target) {
+      if (time(nullptr) - t0 > 120) { fprintf(stderr, "stub_rccl: rank %d timed out waiting for rank %d at barrier %lld\n", c->rank, r, target); abort(); }
       usleep(20);
     }
   }
-  delete a;
 }
 
 hipError_t stream_barrier(StubComm* c, hipStream_t st) {
   if (c->world == 1) return hipSuccess;
-  c->barriers += 1;
-  return hipLaunchHostFunc(st, barrier_cb, new BarrierArg{c, c->barriers});
+  return hipLaunchHostFunc(st, barrier_cb, c);
 }
 
 struct Ptrs { const float* p[kMaxRanks]; };

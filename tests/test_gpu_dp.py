@@ -410,3 +410,69 @@ def test_library_communicator_two_ranks_over_stub_rccl(dev, variant, n_buckets):
     got, ref = res[0][1].double(), m.params.cpu().double()
     assert torch.isfinite(got).all()
     assert ((got - ref).norm() / ref.norm()).item() < 1e-6
+
+
+def _stub_graph_worker(rank, world, port, q):
+    """eager staged data-parallel steps vs the same steps replayed from a captured hipGraph (collectives on the library's side
+    stream INSIDE the capture), two ranks over the stub"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LASR_RCCL_PATH=STUB,
+                      LASR_DP_BUCKETS="2", LASR_GRAPH_DP="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lightning_asr_amd.comm import Communicator
+        from lightning_asr_amd.engine import NativeModel
+        from lightning_asr_amd.step import GraphedTrainStep, TrainStep
+        dev = torch.device("cuda", 0)
+        comm = Communicator.from_torch_distributed(dev)
+        batches = [tuple(t.to(dev) for t in _batch(rank, s)) for s in range(3)]
+        out = []
+        for mode in ("eager", "graph"):
+            m = NativeModel("plain", 28, mask=True, act="relu", dtype=torch.bfloat16, device=dev)
+            m.init_parameters(seed=5)
+            ts = TrainStep(m, 1e-2, 1e-3, comm=comm)
+            if mode == "eager":
+                for wave, tg, tl in batches:
+                    ts.step(wave, tg, tl)
+            else:
+                g = GraphedTrainStep(ts, B, L, S, prefetch=False)
+                g.capture(first_wave=batches[0][0])
+                for wave, tg, tl in batches:
+                    g.step(wave, tg, tl)
+            torch.cuda.synchronize()
+            dist.barrier()
+            out.append(m.params.cpu().numpy())
+        q.put((rank, out, None))
+        dist.barrier()
+        comm.close()
+    except Exception:
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_replays_from_a_graph_two_ranks(dev):
+    """bench.py captures the N > 1 step by default: event fork to the side stream, the bucket collectives, the join before NovoGrad
+    all inside the hipGraph.  Replayed, it must land bit for bit where the eager staged step lands, on both ranks."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    assert os.path.exists(STUB), "build tests/stub_rccl/libstubrccl.so (make)"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stub_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] is not None, r[2]
+    for r in res:
+        assert np.array_equal(r[1][0], r[1][1]), "graph replay differs from eager on rank %d" % r[0]
+    assert np.array_equal(res[0][1][0], res[1][1][0])            # and the replicas agree
+    assert np.isfinite(res[0][1][0]).all()
