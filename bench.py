@@ -371,7 +371,11 @@ def main():
     model.init_parameters(seed=0)                               # pl.seed_everything(0), train.py:203
     sched = CosineAnnealingWarmupRestarts(None, first_cycle_steps=100 * 1000, cycle_mult=2, max_lr=1e-2, min_lr=1e-4,
                                           warmup_steps=1000, gamma=0.5)
-    ts = TrainStep(model, 1e-2, 1e-3, schedule=sched)
+    comm1 = None
+    if world == 1 and os.environ.get("LASR_FORCE_OVERLAP") == "1":     # measure the staged (N > 1) form of the step on one GPU: 1-rank RCCL communicator
+        from lightning_asr_amd.comm import Communicator
+        comm1 = Communicator.single(dev)
+    ts = TrainStep(model, 1e-2, 1e-3, schedule=sched, comm=comm1)
     ts.broadcast_parameters()
     B = args.batch
 
@@ -543,6 +547,7 @@ def main():
                    "audio_seconds_per_step_per_gpu": timed_audio_s / args.steps,
                    "padding_frac": sum(b[5] for b in batches) / len(batches),
                    "n_class": V + 1, "parallelism": "dp%d" % world, "feature_prefetch": bool(args.prefetch), "hip_graph": bool(use_graph),
+                   "staged_backward": bool(ts.overlap and (ts.world > 1 or ts.force_staged)),
                    "grad_exchange": None if world == 1 else ("lasr_comm (librccl on the library's side stream, %d buckets overlapped with backward)"
                                                              % int(os.environ.get("LASR_DP_BUCKETS", "2")) if ts.comm is not None
                                                              else "torch.distributed all_reduce"),

@@ -47,7 +47,7 @@ class TrainStep:
         if comm is not None:
             self.world = comm.world
         elif self.world > 1 and os.environ.get("LASR_COMM", "rccl") == "rccl" and \
-                torch.distributed.get_backend(process_group) == "nccl":
+                (torch.distributed.get_backend(process_group) == "nccl" or os.environ.get("LASR_RCCL_PATH")):   # (gloo + LASR_RCCL_PATH: rehearsal over the test stub)
             self.comm = self._checked_communicator(dev, process_group)
         # exercise the staged + async all-reduce path on a 1-rank group too (validation on one GPU)
         self.force_staged = bool(int(os.environ.get("LASR_FORCE_OVERLAP", "0"))) and \

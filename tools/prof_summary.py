@@ -1,9 +1,16 @@
 """Print the per-kernel summary of a rocprofv3 (rocpd sqlite) run: python tools/prof_summary.py results.db [steps] [out.csv]"""
 import csv, sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 cols = [r[1] for r in c.execute("pragma table_info(top_kernels)")]
 rows = list(c.execute("select * from top_kernels"))
+arg = sys.argv[2] if len(sys.argv) > 2 else "1"
+if arg.startswith("auto:"):        # steps = calls of a kernel that runs exactly once per step (counts graph-capture warm-ups too)
+    hit = [r for r in rows if arg[5:] in r[0]]
+    if not hit:
+        sys.exit("no kernel matching %r in the trace" % arg[5:])
+    steps = float(hit[0][1])
+else:
+    steps = float(arg)
 if len(sys.argv) > 3:
     with open(sys.argv[3], "w", newline="") as f:
         w = csv.writer(f); w.writerow(cols); w.writerows(rows)
