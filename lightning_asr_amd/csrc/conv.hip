@@ -979,6 +979,281 @@ __global__ __launch_bounds__(512, 1) void dwconv_bwd_s1_mfma_kernel(DwBwd a) {
   }
 }
 
+
+// ---- the two consumers of d(depthwise output) from ONE staging of it ---------------------------------------------------------
+// dwconv_bwd_s1_mfma_kernel above runs the weight gradient (x, dy) and the data gradient (dy, flipped taps, + addend) as two
+// kinds of workgroup: dy is fetched and pushed through the transposing LDS round trip twice, and 2 x (C/64) x B workgroups of
+// 144 KB take two rounds on the chip.  Here ONE workgroup does both for its channels over 256-frame time tiles:
+//   images (frame-contiguous, t = tA - P + tau, tau in [0, 384)):  D = dy,  X = x
+//   weight gradient   dW'[16 n + m] += sum_u dY[u - m] X[u + 16 n - P],  u in [tA, tA + 256)  (+32 on the last tile: u runs to T + 15)
+//                     A = Toeplitz fragments of D (funnel shift for odd starts), B = strided windows of X, accumulators live across tiles
+//   data gradient     dx[tA + 16 blk + m] = sum_kap W'[kap - m - sh] D[16 blk + kap]          (A from the tap tables, B from D)
+// so dy crosses HBM and the staging once, the tap tables are built once per workgroup, and (C/CB) x B x gz workgroups make one round.
+// NW = waves per workgroup = channel octets: 8 (64 channels, whole 128-byte rows, one workgroup per CU) or 4 (32 channels,
+// two workgroups per CU).  The next tile's global loads are issued before the MFMA phases of the current one.
+namespace dwu {
+static constexpr int TT = 256;            // frames per tile
+static constexpr int FR = 384;            // staged frames per image and tile
+static constexpr int LDI = 784;           // bytes per channel row: 196 dwords = 4 mod 32 (conflict-free 8-byte transposition writes), multiple of 16
+static constexpr int RS = 128;            // frames per staging round
+template <int NKS, int NW>
+struct Cfg {
+  static constexpr int CB = 8 * NW, NT = 64 * NW;
+  static constexpr int LDST = NW == 8 ? 160 : 96;          // staging row pitch: 40 / 24 dwords (conflict-free tr reads and 16-byte writes)
+  static constexpr int WROW = 2 * (16 * NKS + 16);          // dwords per channel of the tap tables: TE | TO, each 16 NKS + 16
+  static constexpr int D_OFF = 0, X_OFF = CB * LDI, ST_OFF = 2 * CB * LDI, W_OFF = ST_OFF + RS * LDST;
+  static constexpr int SMEM = W_OFF + CB * WROW * 4;
+  static constexpr int LDO = CB * 2 + 16, LDOF = CB * 4 + 16;   // output image row pitch: bf16 / f32
+  static_assert(TT * LDOF <= ST_OFF, "output image fits the two input images");
+};
+}
+
+struct DwUni {
+  const bf16_t* x; const bf16_t* dy; const float* w; const bf16_t* addend; bf16_t* dx; float* partials;
+  int Tlen, C, k, gx, B, gz, total;
+};
+
+template <int NKS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kernel(DwUni a) {
+  using K = dwu::Cfg<NKS, NW>;
+  using namespace dwu;
+  constexpr int CB = K::CB, NT = K::NT, LDST = K::LDST, WROW = K::WROW, HALF = WROW / 2, CG = CB / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // workgroup id -> (channel group, utterance, time lane).  Blocks b and b + 8 share an XCD (round-robin placement, speed only):
+  // the two 32-channel halves of a 128-byte row are dealt to one XCD, next to each other in its queue.
+  int L;
+  {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    L = NW == 8 ? id : (((slot >> 1) * 8 + xcd) * 2 + (slot & 1));
+  }
+  if (L >= a.total) return;                              // workgroup-uniform (padded grid)
+  const int bx = L % a.gx, by = (L / a.gx) % a.B, bz = L / (a.gx * a.B), gz = a.gz;
+  char* dimg = smem_raw + K::D_OFF;
+  char* ximg = smem_raw + K::X_OFF;
+  char* stage = smem_raw + K::ST_OFF;
+  uint32_t* wsm = reinterpret_cast<uint32_t*>(smem_raw + K::W_OFF);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int Tlen = a.Tlen, C = a.C, k = a.k;
+  const int b = by, c0 = bx * CB;
+  const int pad = k / 2, P = (pad + 7) & ~7, sh = P - pad;
+  const int n16 = lane & 15, g4 = lane >> 4;
+  const bf16_t* xb = a.x + (size_t)b * Tlen * C;
+  const bf16_t* db = a.dy + (size_t)b * Tlen * C;
+  const bf16_t* addend = a.addend;
+  typedef __attribute__((address_space(3))) dw_s16x4 lds_s4;
+
+  // the workgroup's taps, reversed (data gradient), as packed bf16 pair tables: W[i] = w'[i - 24], TE[i] = (W[2i], W[2i+1]),
+  // TO[i] = (W[2i+1], W[2i+2]); loads unconditional (clamped index, masked value), all issued before the first conversion
+  {
+    constexpr int kIt = CB * WROW / NT;
+    float f0[kIt], f1[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int i = tid + NT * it;
+      const int ch = i / WROW, idx = i - ch * WROW;
+      const int i0 = idx < HALF ? 2 * idx : 2 * (idx - HALF) + 1;
+      const int j0 = i0 - 24, j1 = i0 - 23;
+      const float* wc = a.w + (size_t)min(c0 + ch, C - 1) * k;
+      const bool cok = c0 + ch < C;
+      const int q0 = min(max(j0, 0), k - 1), q1 = min(max(j1, 0), k - 1);
+      const float a0 = wc[k - 1 - q0], a1 = wc[k - 1 - q1];
+      f0[it] = (cok && j0 >= 0 && j0 < k) ? a0 : 0.f;
+      f1[it] = (cok && j1 >= 0 && j1 < k) ? a1 : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) wsm[tid + NT * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
+  }
+
+  dw_f32x4 accw[8];
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) accw[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int n_tiles = (Tlen + TT - 1) / TT;
+  constexpr int kRounds = FR / RS;                       // 3 per image
+  uint4 vd[kRounds][2], vx[kRounds][2], ra[4];
+  // a tile's global loads: D and X chunks (frame ch / NW, octet ch % NW of each round) and the addend of its 256 output frames
+  auto issue_loads = [&](int q) {
+    const int tA = q * TT;
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ch = tid + NT * h;
+        const int tau = r * RS + ch / NW;
+        const int t = tA - P + tau;
+        const int cc = c0 + (ch % NW) * 8;
+        const bool ok = t >= 0 && t < Tlen && cc < C;
+        const size_t off = (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8);
+        const uint4 l0 = *reinterpret_cast<const uint4*>(db + off);
+        const uint4 l1 = *reinterpret_cast<const uint4*>(xb + off);
+        const uint32_t mk = ok ? 0xffffffffu : 0u;
+        vd[r][h] = make_uint4(l0.x & mk, l0.y & mk, l0.z & mk, l0.w & mk);
+        vx[r][h] = make_uint4(l1.x & mk, l1.y & mk, l1.z & mk, l1.w & mk);
+      }
+    }
+    if (addend) {                                        // workgroup-uniform
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int ci = tid + NT * it;
+        const int t = tA + ci / NW, cc = c0 + (ci % NW) * 8;
+        ra[it] = Vec<bf16_t>::raw(addend + ((size_t)b * Tlen + min(t, Tlen - 1)) * C + min(cc, C - 8));
+      }
+    }
+  };
+
+  DW_STAMP(0);
+  issue_loads(bz);
+  for (int q = bz; q < n_tiles; q += gz) {
+    const int tA = q * TT;
+    const bool last = q == n_tiles - 1;
+    // ---- phase 1: registers -> staging ([frame][channel]) -> transposed images ([channel][frame]), D then X -------------
+#pragma unroll
+    for (int r2 = 0; r2 < 2 * kRounds; ++r2) {
+      const bool isx = r2 >= kRounds;
+      const int r = isx ? r2 - kRounds : r2;
+      __syncthreads();                                   // the previous round's readers (or the previous tile's output pass) are done
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int ch = tid + NT * h;
+        *reinterpret_cast<uint4*>(stage + (ch / NW) * LDST + ((ch % NW) << 4)) = isx ? vx[r][h] : vd[r][h];
+      }
+      __syncthreads();
+      char* img = isx ? ximg : dimg;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int blk = wid * 4 + it;                    // 8 frame groups x CG channel groups of 16 x 16 per round
+        const int fb = (blk / CG) * 16 + g4 * 4, cg = blk % CG;
+        const int qq = n16 >> 2, pp = n16 & 3;
+        const dw_s16x4 d = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(stage + (fb + qq) * LDST + (cg * 16 + pp * 4) * 2));
+        *reinterpret_cast<dw_s16x4*>(img + (cg * 16 + n16) * LDI + (r * RS + fb) * 2) = d;
+      }
+    }
+    __syncthreads();
+    const uint4 ra0 = ra[0], ra1 = ra[1], ra2 = ra[2], ra3 = ra[3];   // this tile's addend; the registers go to the next tile's loads
+    if (q == bz) DW_STAMP(1);
+    if (q + gz < n_tiles) issue_loads(q + gz);
+    if (q == bz) DW_STAMP(2);
+
+    // ---- phase 2a: weight gradient, 8 (9 on the last tile) K steps of 32 u values per channel ---------------------------
+    const int nku = last ? 9 : 8;
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const int cl = wid * 8 + ch;
+      // A[m][u] = dY[u - m]: elements e .. e+7 of the D image, e = P + 32 ks + 8 g4 - m (m = n16): five dwords from floor(e/2)
+      // and a funnel shift by 16 bits for the odd lanes
+      const int e0 = P + 8 * g4 - n16;
+      const uint32_t shft = (e0 & 1) * 16;
+      const uint32_t* arow = reinterpret_cast<const uint32_t*>(dimg + cl * LDI) + (e0 >> 1);
+      const char* brow = ximg + cl * LDI + (16 * n16 + 8 * g4) * 2;
+#pragma unroll
+      for (int kb = 0; kb < 9; kb += 3) {
+        uint32_t wa[3][5];
+        uint4 bb[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) wa[j][i] = arow[16 * (kb + j) + i];
+          bb[j] = *reinterpret_cast<const uint4*>(brow + 64 * (kb + j));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (kb + j < nku) {                            // workgroup-uniform
+            union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[j][i + 1], wa[j][i], shft);
+            bf.u[0] = bb[j].x; bf.u[1] = bb[j].y; bf.u[2] = bb[j].z; bf.u[3] = bb[j].w;
+            accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (q == bz) DW_STAMP(3);
+    // ---- phase 2b: data gradient of the tile's 256 frames, NKS K steps per channel ----------------------------------------
+    dw_f32x4 accd[8];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch) {
+      const int cl = wid * 8 + ch;
+      accd[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* row = dimg + cl * LDI;
+      const int s0 = 8 * g4 - n16 - sh + 24;
+      const uint32_t* wrow = wsm + cl * WROW + ((s0 & 1) ? HALF + ((s0 - 1) >> 1) : (s0 >> 1));
+      uint32_t wa[NKS][4];
+      uint4 b0[NKS];
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[ks][i] = wrow[16 * ks + i];
+        b0[ks] = *reinterpret_cast<const uint4*>(row + (16 * n16 + 32 * ks + 8 * g4) * 2);
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        union { uint32_t u[4]; dw_bf16x8 v; } af, bf0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af.u[i] = wa[ks][i];
+        bf0.u[0] = b0[ks].x; bf0.u[1] = b0[ks].y; bf0.u[2] = b0[ks].z; bf0.u[3] = b0[ks].w;
+        accd[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf0.v, accd[ch], 0, 0, 0);
+      }
+    }
+    // ---- phase 3: lane = (block n16, frames 4 g4 .. +3) holds its wave's 8 channels per frame: 16 bytes (bf16) or 32 (f32, when
+    //      an addend is summed in and rounded once) per frame into an LDS image [frame][CB] with rows permuted for conflict-free
+    //      writes, then the tile leaves as whole rows of 16-byte pieces
+    if (q == bz) DW_STAMP(4);
+    __syncthreads();                                     // every wave is done with the input images
+    char* oimg = smem_raw;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fl = n16 * 16 + g4 * 4 + r;
+      const int prow = (fl & 15) * 16 + (fl >> 4);
+      float o[8];
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) o[ch] = accd[ch][r];
+      if (!addend) {
+        Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(oimg + prow * K::LDO) + wid * 8, o);
+      } else {
+        *reinterpret_cast<float4*>(oimg + prow * K::LDOF + wid * 32) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(oimg + prow * K::LDOF + wid * 32 + 16) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+    __syncthreads();
+    const uint4 rav[4] = {ra0, ra1, ra2, ra3};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ci = tid + NT * it;
+      const int fl = ci / NW, oc = ci % NW;
+      const int t = tA + fl, cc = c0 + oc * 8;
+      const bool ok = t < Tlen && cc < C;
+      const size_t off = ((size_t)b * Tlen + min(t, Tlen - 1)) * C + min(cc, C - 8);
+      const int prow = (fl & 15) * 16 + (fl >> 4);
+      if (!addend) {
+        if (ok) *reinterpret_cast<uint4*>(a.dx + off) = *reinterpret_cast<const uint4*>(oimg + prow * K::LDO + oc * 16);
+      } else {
+        const float4 lo = *reinterpret_cast<const float4*>(oimg + prow * K::LDOF + oc * 32);
+        const float4 hi = *reinterpret_cast<const float4*>(oimg + prow * K::LDOF + oc * 32 + 16);
+        float a8[8];
+        Vec<bf16_t>::unpack(rav[it], a8);
+        float o[8] = {lo.x + a8[0], lo.y + a8[1], lo.z + a8[2], lo.w + a8[3], hi.x + a8[4], hi.y + a8[5], hi.z + a8[6], hi.w + a8[7]};
+        if (ok) Vec<bf16_t>::store(a.dx + off, o);
+      }
+    }
+    if (q == bz) DW_STAMP(5);
+  }
+#ifdef LASR_DW_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  DW_STAMP(6);
+  // ---- D[m][n] = dW'[16 n + m]: lane (n = n16, rows 4 g4 + r) -> tap j = 16 n + 4 g4 + r - sh
+  float* out = a.partials + ((size_t)b * gz + bz) * C * k;
+#pragma unroll
+  for (int ch = 0; ch < 8; ++ch) {
+    const int c = c0 + wid * 8 + ch;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * n16 + 4 * g4 + r - sh;
+      if (c < C && j >= 0 && j < k) out[(size_t)c * k + j] = accw[ch][r];
+    }
+  }
+}
+
 }  // namespace lasr
 
 using namespace lasr;
@@ -1159,6 +1434,43 @@ extern "C" int lasr_dwconv_bwd_fused(const void* x, const void* dy, const float*
     LASR_TRY(lasr_dwconv_wgrad_partials(x, dy, dtype, B, T, C, k, 1, workspace, workspace_bytes, n_partials, stream));
     return lasr_dwconv_fwd(dy, w, addend, dx, dtype, B, T, C, k, 1, 1, stream);
   }
+  const int nks = (15 + k + shk + 31) / 32;
+  {
+    // one workgroup for both consumers of dy (dwconv_bwd_uni_kernel): LASR_DW_UNI = 32 (default: 32-channel workgroups, two per CU;
+    // k > 75 takes the 64-channel form), 64 (64-channel workgroups, one per CU), 0 (the two-kind grid below, for A/B runs).
+    // Measured in the cfg2 step (rocprofv3, profiles/r03c_*): 36.9 / 38.1 / 37.8 us per 512-channel unit - see DESIGN.md
+    static const int uni = getenv("LASR_DW_UNI") ? atoi(getenv("LASR_DW_UNI")) : 32;
+    const bool u32 = uni == 32 && nks <= 3;
+    if (uni == 64 || uni == 32) {
+      DwUni u;
+      u.x = (const bf16_t*)x; u.dy = (const bf16_t*)dy; u.w = w; u.addend = (const bf16_t*)addend; u.dx = (bf16_t*)dx;
+      u.partials = reinterpret_cast<float*>(workspace);
+      u.Tlen = (int)T; u.C = (int)C; u.k = k; u.B = (int)B;
+      const int cb = u32 ? 32 : 64;
+      u.gx = (int)cdiv(C, cb);
+      const int n_tiles = (int)cdiv(T, (int64_t)dwu::TT);
+      const int want = u32 ? 400 : 200;                  // workgroups that fill the chip (two / one per CU)
+      int gz = 1;
+      while (gz * 2 <= n_tiles && (int64_t)u.gx * B * gz < want) gz *= 2;
+      u.gz = gz;
+      u.total = (int)(u.gx * B * gz);
+      const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 4.0 * (double)B * T * C * k, (double)B * T * C * (addend ? 4 : 3) * 2);
+#define LASR_DWU(N_, W_)                                                                                                          \
+  do {                                                                                                                            \
+    using Kc = dwu::Cfg<N_, W_>;                                                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_bwd_uni_kernel<N_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    const unsigned grid = (unsigned)((u.total + 15) / 16 * 16);                                                                     \
+    hipLaunchKernelGGL((dwconv_bwd_uni_kernel<N_, W_>), dim3(grid), dim3(64 * W_), Kc::SMEM, as_stream(stream), u);                  \
+  } while (0)
+      if (u32) { if (nks == 1) LASR_DWU(1, 4); else if (nks == 2) LASR_DWU(2, 4); else LASR_DWU(3, 4); }
+      else { if (nks == 1) LASR_DWU(1, 8); else if (nks == 2) LASR_DWU(2, 8); else if (nks == 3) LASR_DWU(3, 8); else LASR_DWU(4, 8); }
+#undef LASR_DWU
+      prof_end(tok, as_stream(stream));
+      LASR_LAUNCH_CHECK("dwconv_bwd_uni_kernel");
+      *n_partials = (int)B * gz;
+      return 0;
+    }
+  }
   DwBwd a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.w = w; a.addend = (const bf16_t*)addend; a.dx = (bf16_t*)dx;
   a.partials = reinterpret_cast<float*>(workspace);
@@ -1174,7 +1486,6 @@ extern "C" int lasr_dwconv_bwd_fused(const void* x, const void* dy, const float*
   const bool half = !no_half && T > 256 && cdiv(C, kCB) * B * cdiv(T, (int64_t)512) < 200;
   a.gz_d = half ? (int)std::min<int64_t>(cdiv(T, (int64_t)256), 8) : 1;
   const unsigned total = (unsigned)(a.n_w + a.gx * a.B * a.gz_d);
-  const int nks = (15 + k + shk + 31) / 32;
   constexpr int kSmem = dwm::SMEM > dwg::SMEM ? dwm::SMEM : dwg::SMEM;
   const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 4.0 * (double)B * T * C * k, (double)B * T * C * (addend ? 5 : 4) * 2);
 #define LASR_DWB2(N_, S_)                                                                                                      \
