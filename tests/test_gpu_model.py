@@ -10,10 +10,9 @@ from oracle.make_golden import golden_inputs, checksum
 pytestmark = pytest.mark.gpu
 
 
-# End-to-end f32 gradient gates (worst relative L2 over the parameter tensors, GPU f32 path vs the f64 oracle) = 2x the measured
-# worst, recorded in profiles/r03_e2e_measured.json by conftest.record_measured.  The GPU result is bit-reproducible and the f64
-# oracle does not move with the host's thread count, so these are stable; the tight bounds (2e-5 per unit) are test_gpu_units.py.
-GATE = {"plain_golden": 1e-2, "context_golden": 1e-2, "context_se_golden": 1e-2, "edge": 2e-2}
+# End-to-end f32 gradient gates (worst relative L2 over the parameter tensors, GPU f32 path vs the f64 oracle): conftest.e2e_gate =
+# 2 x the worst measured on the MI355X (profiles/r03_e2e_measured.json), floored at the one-ReLU-flip level (6e-3).  The GPU result is
+# bit-reproducible and the f64 oracle does not move with the host's thread count; the tight bounds (2e-5 per unit) are test_gpu_units.py.
 
 def rel_l2(a, b):
     a, b = a.double().cpu(), b.double().cpu()
@@ -76,9 +75,9 @@ def test_plain_loss_backward_matches_golden_f32(dev):
     rels = {t.name: rel_l2(m.view(t, m.grads), g) for t, g in zip(m.param_infos(), grads)}
     worst = max(rels.values())
     print("worst grad rel-L2 vs f64 oracle %.3e" % worst)
-    from conftest import record_measured
+    from conftest import e2e_gate, record_measured
     record_measured("plain_golden_f32_grad_rel_l2_vs_f64_oracle", worst)
-    assert worst < GATE["plain_golden"], sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    assert worst < e2e_gate("plain_golden_f32_grad_rel_l2_vs_f64_oracle"), sorted(rels.items(), key=lambda kv: -kv[1])[:5]
     # running statistics after one training forward
     for t in m.tensors:
         if t.kind == 1:
@@ -161,9 +160,9 @@ def test_context_variants_match_golden_f32(dev, variant):
     _, _, _, grads = E.loss_and_grads(o, x.double(), tg, pct, tsz)
     rels = {t.name: rel_l2(m2.view(t, m2.grads), g) for t, g in zip(m2.param_infos(), grads)}
     worst = max(rels.values())
-    from conftest import record_measured
+    from conftest import e2e_gate, record_measured
     record_measured("%s_golden_f32_grad_rel_l2_vs_f64_oracle" % variant, worst)
-    assert worst < GATE["%s_golden" % variant], sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    assert worst < e2e_gate("%s_golden_f32_grad_rel_l2_vs_f64_oracle" % variant), sorted(rels.items(), key=lambda kv: -kv[1])[:5]
 
 
 @pytest.mark.parametrize("variant", ["context", "context_se"])
@@ -272,9 +271,9 @@ def test_small_and_ragged_shapes_match_oracle(dev, variant, B, T_in, pcts, S):
     assert abs(loss.item() - loss_ref) / abs(loss_ref) < 1e-4
     rels = {t.name: rel_l2(m.view(t, m.grads), gr) for t, gr in zip(m.param_infos(), grads)}
     worst = max(rels.values())
-    from conftest import record_measured
+    from conftest import e2e_gate, record_measured
     record_measured("edge_%s_B%d_T%d_f32_grad_rel_l2_vs_f64_oracle" % (variant, B, T_in), worst)
-    assert worst < GATE["edge"], sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+    assert worst < e2e_gate("edge_%s_B%d_T%d_f32_grad_rel_l2_vs_f64_oracle" % (variant, B, T_in)), sorted(rels.items(), key=lambda kv: -kv[1])[:5]
     mb = _native(variant, 28, dev, dtype=torch.bfloat16)
     lossb, _, lpb, _ = mb.loss_backward(feats.to(torch.bfloat16), pct.to(dev), tg.to(dev), tsz.to(dev))
     assert torch.isfinite(lpb).all() and torch.isfinite(mb.grads).all()
