@@ -408,7 +408,22 @@ def main():
         # hipGraph replay: the ~200 launches of a step become one graph launch (host-enqueue time no longer bounds the step).  The
         # graphs read the resident synthetic batches IN PLACE: nothing is copied per step.
         try:
-            if cfg["ragged"]:                            # one graph per bucket, features + step of the same batch
+            if cfg["ragged"] and args.prefetch:
+                # one graph per bucket; graph i trains on bucket i's features (computed by the previous replay) and computes bucket
+                # i+1's inside its loss launch, into that bucket's own feature buffer: nothing is copied between replays
+                nb_ = len(batches)
+                FP = []
+                for bk in batches:
+                    f_, p_ = ts.features(bk[0], bk[1])
+                    FP.append((f_.clone(), p_.clone()))
+                for i, bk in enumerate(batches):
+                    nx = batches[(i + 1) % nb_]
+                    graphs[i] = GraphedTrainStep(ts, B, nx[0].shape[1], bk[2].shape[1], ragged=True, prefetch=True,
+                                                 inputs=(nx[0], nx[1], bk[2], bk[3]), feats_in=FP[i], feats_out=FP[(i + 1) % nb_])
+                    graphs[i].capture()
+                f_, p_ = ts.features(batches[0][0], batches[0][1])     # (the captures' warm-up passes ran through the buffers)
+                FP[0][0].copy_(f_); FP[0][1].copy_(p_)
+            elif cfg["ragged"]:                          # --no-prefetch: features + step of the same bucket in one replay
                 for i, bk in enumerate(batches):
                     graphs[i] = GraphedTrainStep(ts, B, bk[0].shape[1], bk[2].shape[1], ragged=True, prefetch=False,
                                                  inputs=(bk[0], bk[1], bk[2], bk[3]))

@@ -11,6 +11,7 @@
 // decoder gradient GEMMs read), against 444 + 888 + 888 + 666 + 444 MB for logits / log_softmax / CTC gradient / cast / colsum.
 // The statistics are taken from the logits AS STORED (bf16), so exp(logit - lse) sums to one over the stored row.
 #include "ctc_lattice.h"
+#include "mel.h"
 
 namespace lasr {
 
@@ -261,6 +262,16 @@ extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* 
                                   const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T, int64_t C,
                                   int64_t S_max, int blank, float* nll, int32_t* argmax, void* grad, float* bias_grad,
                                   const float* gscale, void* workspace, size_t workspace_bytes, void* stream) {
+  return ctc_loss_lean_job(logits, ldc, row_stat, row_arg, n_col_tiles, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, argmax, grad,
+                           bias_grad, gscale, workspace, workspace_bytes, nullptr, stream);
+}
+
+// job != null: the log-mel features of ANOTHER batch (the prefetch of the next step) are computed in the grid of the lattice kernel
+// when its emissions fit one workgroup's LDS next to the labels, behind the gradient kernel otherwise
+int lasr::ctc_loss_lean_job(const void* logits, int64_t ldc, const float* row_stat, const int32_t* row_arg, int n_col_tiles,
+                            const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T, int64_t C,
+                            int64_t S_max, int blank, float* nll, int32_t* argmax, void* grad, float* bias_grad, const float* gscale,
+                            void* workspace, size_t workspace_bytes, const MelJob* job, void* stream) {
   LASR_CHECK_ARG(logits && row_stat && row_arg && targets && in_lens && tgt_lens && nll && grad && bias_grad && workspace,
                  "lasr_ctc_loss_lean: null pointer");
   LASR_CHECK_SHAPE(B > 0 && T > 0 && C > 1 && S_max >= 0 && blank >= 0 && blank < C && ldc == ((C + 7) & ~(int64_t)7) && ldc <= 9216 &&
@@ -302,9 +313,15 @@ extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* 
                          tgt_lens, T, (int64_t)CE, sm, (int)sm, alpha, beta, next_same, nll);                                  \
     }                                                                                                                          \
   } while (0)
-  if (ns == 4) LASR_CTC_AB(4); else if (ns == 8) LASR_CTC_AB(8); else LASR_CTC_AB(16);
+  bool job_done = false;
+  if (job && em_lds && compact_lattice_mel_fits(T, CE)) {
+    LASR_TRY(launch_compact_lattice_mel(E, targets, in_lens, tgt_lens, B, T, CE, sm, (int)sm, alpha, beta, next_same, nll, ns, *job, stream));
+    job_done = true;
+  } else {
+    if (ns == 4) LASR_CTC_AB(4); else if (ns == 8) LASR_CTC_AB(8); else LASR_CTC_AB(16);
+    LASR_LAUNCH_CHECK("ctc_alpha_beta_compact_kernel");
+  }
 #undef LASR_CTC_AB
-  LASR_LAUNCH_CHECK("ctc_alpha_beta_compact_kernel");
   const int cpad = (int)((C + 7) & ~(int64_t)7);
   const size_t shmem = 4 * ((size_t)cpad + 4 * (size_t)sm) * sizeof(float);
   LASR_CHECK_SHAPE(shmem <= 160 * 1024 && ldc / 8 <= 64 * 18, "lasr_ctc_loss_lean: C=%lld too large for the LDS row buffers", (long long)C);
@@ -322,5 +339,9 @@ extern "C" int lasr_ctc_loss_lean(const void* logits, int64_t ldc, const float* 
 #undef LASR_CTC_G
 #undef LASR_CTC_G2
   LASR_LAUNCH_CHECK("ctc_grad_lean_kernel");
-  return launch_reduce_partials(bias_partials, nwg, C, bias_grad, C, nullptr, st);   // f64, fixed order
+  LASR_TRY(launch_reduce_partials(bias_partials, nwg, C, bias_grad, C, nullptr, st));   // f64, fixed order
+  if (job && !job_done)
+    return mel_fwd_src(job->src, job->sample_lens, job->aug, job->B, job->L, job->normalize, nullptr, job->out_btf, job->dtype, job->frames_out,
+                       job->pct_out, job->ws, job->ws_bytes, stream);
+  return 0;
 }

@@ -384,14 +384,15 @@ struct MelCtcArgs {
   WaveSrc src; const int32_t* sample_lens; const int32_t* aug;
   int64_t L, Tm; float* db_out; double* partials; int32_t* frames_out; float* pct_out; int nbx;
 };
-template <int NS>
+// COMPACT: the lattice of the large-vocabulary head (ctc_lean.hip): `logp` is the gathered emission matrix E [N][C = S_max + 1 ...]
+template <int NS, bool COMPACT = false>
 __global__ __launch_bounds__(256) void mel_ctc_kernel(MelCtcArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if ((int)blockIdx.x < a.n_ctc) {                       // workgroup-uniform
     int32_t* s_tg = reinterpret_cast<int32_t*>(smem_raw);
     float* s_lp = reinterpret_cast<float*>(smem_raw + kCtcMaxS * sizeof(int32_t));
-    ctc_alpha_beta_body<NS, true, 256>(a.logp, a.targets, a.in_lens, a.tgt_lens, a.T, a.C, a.S_max, a.blank, a.alpha, a.beta, a.next_same,
-                                       a.nll, (int)blockIdx.x, s_tg, s_lp);
+    ctc_alpha_beta_body<NS, true, 256, COMPACT>(a.logp, a.targets, a.in_lens, a.tgt_lens, a.T, a.C, a.S_max, a.blank, a.alpha, a.beta, a.next_same,
+                                                a.nll, (int)blockIdx.x, s_tg, s_lp);
   } else {
     const int id = (int)blockIdx.x - a.n_ctc;
     mel_db_body(a.src, a.sample_lens, a.aug, a.L, a.Tm, a.db_out, a.partials, a.frames_out, a.pct_out, id % a.nbx, id / a.nbx,
@@ -548,6 +549,46 @@ int ctc_loss_mel_src(const float* logp, const int64_t* targets, const int32_t* i
   if (grad) LASR_TRY(launch_ctc_grad(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, stream));
   dim3 grid(nblk, (unsigned)Bm);
   launch_norm(dtype, grid, as_stream(stream), a.db_out, a.partials, frames_out, Tm, nblk, normalize, out_bft, out_btf, src);
+  LASR_LAUNCH_CHECK("mel_norm_kernel");
+  return 0;
+}
+
+bool compact_lattice_mel_fits(int64_t T, int64_t CE) {
+  static const bool off = getenv("LASR_NO_MEL_CTC") != nullptr || getenv("LASR_CTC_NO_LDS") != nullptr;
+  return !off && kCtcMaxS * sizeof(int32_t) + (size_t)(T + 2) * CE * sizeof(float) <= 158 * 1024;
+}
+
+int launch_compact_lattice_mel(const float* E, const int64_t* targets, const int32_t* in_lens, const int32_t* tgt_lens, int64_t B, int64_t T,
+                               int64_t CE, int64_t S_max, int blank_col, float* alpha, float* beta, int32_t* next_same, float* nll, int ns,
+                               const MelJob& job, void* stream) {
+  LASR_CHECK_ARG(E && job.src.wave && job.out_btf && job.frames_out && job.pct_out && job.ws, "lasr_ctc_loss_lean (+features): null pointer");
+  LASR_CHECK_ARG(job.dtype == LASR_F32 || job.dtype == LASR_BF16, "lasr_ctc_loss_lean (+features): bad dtype");
+  LASR_CHECK_SHAPE(job.B > 0 && job.B < 65536 && job.L >= 2 && job.L < (1ll << 30), "lasr_ctc_loss_lean (+features): B=%lld L=%lld", (long long)job.B,
+                   (long long)job.L);
+  const int64_t Tm = lasr_mel_num_frames(job.L);
+  if (job.ws_bytes < lasr_mel_workspace_bytes(job.B, Tm)) return fail(LASR_E_WORKSPACE, "lasr_ctc_loss_lean (+features): workspace");
+  LASR_TRY(init_tables());
+  MelCtcArgs a;
+  a.logp = E; a.targets = targets; a.in_lens = in_lens; a.tgt_lens = tgt_lens; a.T = T; a.C = CE; a.S_max = S_max; a.blank = blank_col;
+  a.alpha = alpha; a.beta = beta; a.next_same = next_same; a.nll = nll; a.n_ctc = (int)B;
+  a.src = job.src; a.sample_lens = job.sample_lens; a.aug = job.aug; a.L = job.L; a.Tm = Tm;
+  a.db_out = reinterpret_cast<float*>(job.ws);
+  a.partials = reinterpret_cast<double*>(reinterpret_cast<char*>(job.ws) + align_up((size_t)job.B * Tm * kMel * sizeof(float), 256));
+  a.frames_out = job.frames_out; a.pct_out = job.pct_out;
+  const int nblk = (int)cdiv(Tm, kFramesPerBlock);
+  a.nbx = nblk;
+  const size_t lds = std::max(sizeof(MelSmem), kCtcMaxS * sizeof(int32_t) + (size_t)(T + 2) * CE * sizeof(float));
+  const dim3 grid((unsigned)(B + (int64_t)nblk * job.B));
+#define LASR_MCK(NS_)                                                                                                              \
+  do {                                                                                                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mel_ctc_kernel<NS_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((mel_ctc_kernel<NS_, true>), grid, dim3(256), lds, as_stream(stream), a);                                     \
+  } while (0)
+  if (ns == 4) LASR_MCK(4); else if (ns == 8) LASR_MCK(8); else LASR_MCK(16);
+#undef LASR_MCK
+  LASR_LAUNCH_CHECK("mel_ctc_kernel (compact)");
+  launch_norm(job.dtype, dim3(nblk, (unsigned)job.B), as_stream(stream), a.db_out, a.partials, job.frames_out, Tm, nblk, job.normalize, nullptr,
+              job.out_btf, job.src);
   LASR_LAUNCH_CHECK("mel_norm_kernel");
   return 0;
 }

@@ -853,11 +853,12 @@ static int forward_and_loss(lasr_model_t* m, const float* params, float* buffers
     const int64_t N = B * p.T;
     const float* rs = atf(ws, p.o_rowstat);
     const int32_t* ra = reinterpret_cast<const int32_t*>(rs + (size_t)N * cdiv(C, 256) * 2);
-    LASR_TRY(lasr_ctc_loss_lean(at(ws, p.o_logits), lean_ldc(m), rs, ra, m->lean_tiles, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1,
-                                nll_out, argmax_out, at(ws, p.o_d1), grads + m->b_dec, nullptr, at(ws, p.o_lean), p.lean_bytes, stream));
-    if (pf.armed)   // (the lattice of a large vocabulary does not share a grid with the feature transform)
-      LASR_TRY(mel_fwd_src(pf.src, pf.sample_lens, pf.aug, pf.B, pf.L, pf.normalize, nullptr, pf.out_btf, pf.dtype, pf.frames_out,
-                           pf.pct_out, pf.ws, pf.ws_bytes, stream));
+    MelJob job;
+    if (pf.armed) job = MelJob{pf.src, pf.sample_lens, pf.aug, pf.B, pf.L, pf.normalize, pf.out_btf, pf.dtype, pf.frames_out, pf.pct_out, pf.ws, pf.ws_bytes};
+    // (the next step's features ride in the grid of the compact lattice when its emissions fit one workgroup's LDS)
+    LASR_TRY(ctc_loss_lean_job(at(ws, p.o_logits), lean_ldc(m), rs, ra, m->lean_tiles, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1,
+                               nll_out, argmax_out, at(ws, p.o_d1), grads + m->b_dec, nullptr, at(ws, p.o_lean), p.lean_bytes,
+                               pf.armed ? &job : nullptr, stream));
   } else if (pf.armed) {   // this step's loss and the next step's features in one grid
     LASR_TRY(ctc_loss_mel_src(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
                               at(ws, p.o_ctc), p.ctc_bytes, pf.src, pf.sample_lens, pf.aug, pf.B, pf.L, pf.normalize, nullptr,

@@ -176,3 +176,35 @@ def test_wer_host_fallback_for_multichar_labels(dev):
     val2 = float(w2(ids, tg, torch.tensor([3]), torch.tensor([6], dtype=torch.int32, device=dev)))
     assert val2 == pytest.approx(1 / 3)
     assert float(w2.compute_total()) == pytest.approx(1 / 3)
+
+
+def test_lean_head_computes_the_prefetched_features_inside_its_lattice_launch(dev):
+    """large-vocabulary head (bf16, C >= 256): the next batch's log-mel features ride in the grid of the compact lattice kernel;
+    same features and the same loss / gradients, bit for bit, as the separate launches"""
+    from lightning_asr_amd import ops
+    from lightning_asr_amd.engine import NativeModel
+    g = torch.Generator().manual_seed(11)
+    B, L, S, C = 3, 24000, 9, 300
+    wave = (0.1 * torch.randn(B, L, generator=g)).to(dev)
+    nxt = (0.1 * torch.randn(B, 31000, generator=g)).to(dev)
+    nlens = torch.tensor([31000, 20000, 9000], dtype=torch.int32, device=dev)
+    tg = torch.randint(0, C - 1, (B, S), generator=g).to(dev)
+    tl = torch.tensor([9, 5, 1], dtype=torch.int32, device=dev)
+    res = []
+    for fused in (False, True):
+        m = NativeModel("plain", C, mask=True, dtype=torch.bfloat16, device=dev)
+        m.init_parameters(4)
+        assert m.lean_head
+        _, feats, _, pct = ops.mel(wave, None, None, None, True, torch.bfloat16, want_bft=False)
+        nf = None
+        if fused:
+            nf, npct = m.arm_prefetch(nxt, nlens)
+        loss, nll, logp, am = m.loss_backward(feats, pct, tg, tl, want_logp=False)
+        assert logp is None
+        if not fused:
+            _, nf, _, npct = ops.mel(nxt, nlens, None, None, True, torch.bfloat16, want_bft=False)
+        torch.cuda.synchronize()
+        res.append((loss.clone(), nll.clone(), m.grads.clone(), nf.clone(), npct.clone(), am.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][2]).all()
