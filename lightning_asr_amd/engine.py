@@ -223,7 +223,8 @@ class NativeModel:
 
     def _logp_buffer(self, B: int, T: int, want_logp: bool):
         if not want_logp and self.lean_head:
-            return None                      # the library then runs the lean head: no (B, T', C) f32 tensor exists anywhere
+            return None                      # the library then runs the lean head: no (B, T', C) f32 tensor is written or read
+                                             # (the workspace still reserves the dense head's f32 logits for eval forwards / want_logp=True)
         return torch.empty(B, T, self.n_class, dtype=torch.float32, device=self.device)
 
     def out_frames(self, T_in: int) -> int:

@@ -208,3 +208,43 @@ def test_lean_head_computes_the_prefetched_features_inside_its_lattice_launch(de
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
     assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][2]).all()
+
+
+def test_custom_dataset_and_overridden_step_keep_working(dev, tmp_path):
+    """(1) a dataset that overrides __getitem__ cannot use the native wav reader: the fused step then takes its batches from the
+    DataLoader (HostWaveSource); (2) a module that overrides training_step keeps the autograd route of Trainer.fit"""
+    from lightning_asr_amd.data_module import LibriDataModule, MyAudioDataset
+    from lightning_asr_amd.lightning_compat import Trainer, seed_everything
+    from lightning_asr_amd.train import LightingModule
+    data = _corpus(tmp_path, n_train=8, seconds=2.0)
+
+    class MyDS(MyAudioDataset):
+        def __getitem__(self, index):
+            w, ids, path = super().__getitem__(index)
+            return w * 0.5, ids, path
+
+    class MyDM(LibriDataModule):
+        def setup(self, stage=None):
+            super().setup(stage)
+            self.train_datasets = MyDS(self.train_manifest, self.labels, mask=True, max_duration=self.train_max_duration)
+
+    def run(module_cls, dm_cls, root):
+        seed_everything(0)
+        dm = dm_cls([str(data / "train.json")], str(data / "dev.json"), str(data / "dev.json"), LABELS, train_bs=4, dev_bs=4, num_worker=0,
+                    device=str(dev), act_dtype=torch.bfloat16)
+        model = module_cls(learning_rate=1e-2, weight_decay=1e-3, labels=LABELS, total_epoch=1, mask=True, use_cer=True, dtype="bf16",
+                           device=str(dev), warmup_steps=0)
+        tr = Trainer(max_epochs=1, default_root_dir=str(tmp_path / root), device=str(dev))
+        hist = tr.fit(model, dm)
+        assert tr.global_step == 2 and np.isfinite(hist[-1]["train_loss"]) and hist[-1]["train_wer"] >= 0
+        return tr
+
+    tr = run(LightingModule, MyDM, "a")
+    assert tr.fused is not None and tr.fused.source_kind == "HostWaveSource"
+
+    class MyModule(LightingModule):
+        def training_step(self, batch, batch_idx):
+            return super().training_step(batch, batch_idx) * 1.0
+
+    tr = run(MyModule, LibriDataModule, "b")
+    assert tr.fused is None                                  # training_step -> loss.backward() -> Novograd.step
