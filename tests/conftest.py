@@ -47,3 +47,10 @@ def e2e_gate(name: str, floor: float = 6e-3, default: float = 2e-2) -> float:
     except Exception:
         return default
     return max(2.0 * m[name], floor) if name in m else default
+
+
+# ONE tolerance for the log-mel front-end (north_star: "mel features within 1e-4 relative"): the HIP kernel against the oracle
+# evaluated in f64, relative to the feature scale.  Measured worst on the MI355X: 2.9e-5 (profiles/r03_e2e_measured.json, mel_*).
+# Against the oracle's f32 evaluation (what the reference's torch.stft computes in) the distance is the f32 oracle's OWN round-off in
+# the weak bins of high-dynamic-range frames (up to 5e-4 on a pure tone), so that comparison is allowed MEL_TOL + that spread.
+MEL_TOL = 1e-4

@@ -49,9 +49,12 @@ def test_mel_matches_oracle(dev, kind):
         # normalisation).  A pure tone has ~70 dB of dynamic range, where two f32 FFTs differ in the
         # weak bins by their own round-off: price that with the f64 evaluation of the same oracle.
         ref64 = R.parse_wave(wave[b:b + 1, :Lb].double(), dither[b:b + 1, :Lb].double())
-        tol = max(1e-4, 2.0 * max_rel(ref[0], ref64[0]))
-        assert max_rel(got, ref[0]) < tol, (kind, b, max_rel(got, ref[0]), tol)
-        assert max_rel(got, ref64[0]) < tol, (kind, b, max_rel(got, ref64[0]), tol)
+        from conftest import MEL_TOL, record_measured
+        assert max_rel(got, ref64[0]) < MEL_TOL, (kind, b, max_rel(got, ref64[0]))
+        assert max_rel(got, ref[0]) < MEL_TOL + max_rel(ref[0], ref64[0]), (kind, b, max_rel(got, ref[0]), max_rel(ref[0], ref64[0]))
+        record_measured("mel_%s_%d_vs_f64_oracle" % (kind, b), max_rel(got, ref64[0]))
+        record_measured("mel_%s_%d_vs_f32_oracle" % (kind, b), max_rel(got, ref[0]))
+        record_measured("mel_%s_%d_f32_oracle_vs_f64_oracle" % (kind, b), max_rel(ref[0], ref64[0]))
         assert torch.all(bft[b, :, Tb:] == 0)
         assert torch.equal(btf[b].t().contiguous().cpu(), bft[b].cpu())
 
