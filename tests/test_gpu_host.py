@@ -51,10 +51,11 @@ def test_training_step_matches_oracle_f32(dev):
     x_gpu, pct_gpu = ap.features(waves, mask=False, dither=False)
     assert x_gpu.shape == inputs.shape
     from conftest import MEL_TOL
-    feats64 = [R.parse_wave(w.unsqueeze(0).double()) for w in waves]          # the same oracle evaluated in f64
-    inputs64, _, _, _ = R.collate([f.float() for f in feats64], [tg[i].tolist() for i in range(B)])
-    scale = inputs64.abs().max()
-    assert (x_gpu.cpu().double() - torch.cat([torch.nn.functional.pad(f, (0, inputs.shape[3] - f.shape[2])) for f in feats64]).unsqueeze(1)).abs().max() < MEL_TOL * scale
+    ref64 = torch.zeros(inputs.shape, dtype=torch.float64)                      # the same oracle evaluated in f64, collated
+    for i, w in enumerate(waves):
+        f64 = R.parse_wave(w.unsqueeze(0).double())
+        ref64[i, 0, :, :f64.shape[2]] = f64[0]
+    assert (x_gpu.cpu().double() - ref64).abs().max() < MEL_TOL * ref64.abs().max()
     assert torch.allclose(pct_gpu.cpu(), pct, atol=1e-7)
     m = _module(dev)
     m.train()
