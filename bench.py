@@ -304,6 +304,8 @@ def trainer_path(args, cfg):
                    "audio_seconds_per_step_per_gpu": audio / K, "padding_frac": 1.0 - f.samples_real / max(f.samples_padded, 1),
                    "ingest": f.source_kind, "ingest_threads": args.ingest_threads, "train_crop": crop,
                    "hip_graph_steps": f.graph_steps, "eager_steps": f.eager_steps, "lean_head": bool(f.native.lean_head),
+                   "host_ms_per_step": {"waiting_for_ingest": 1e3 * f.ingest_wait_s / max(tr.global_step, 1),
+                                        "enqueuing_the_step": 1e3 * f.host_step_s / max(tr.global_step, 1)},
                    "included": "wav decode on host threads, int16 H2D, random sub-sequence crop + SpecAugment draws, in-kernel dither, "
                                "per-step greedy decode + edit distance + loss/WER accumulation (train.py:79-81), all of TrainStep",
                    "excluded": "validation, checkpoint writes (epoch-end work; the timed steps sit inside one epoch)"},

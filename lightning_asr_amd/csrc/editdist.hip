@@ -52,7 +52,10 @@ __device__ __forceinline__ int wave_prefix_min_excl_carry(int v, int lane) {   /
 }
 
 // grid = B, block = 64.  hyp [B][ld_h] i32 with hyp_lens; ref [B][ld_r] i64 with ref_lens (i32).
+// NJ = DP cells per lane: 64 * NJ >= the longest reference of the batch (a row costs NJ cell updates per lane whatever the
+// reference's length, so the 100-label references of a 10 s clip run with NJ = 2: 76 -> ~8 us per batch of 32)
 // dist[b] = Levenshtein(hyp units, ref units), ref_units[b] = number of reference units.
+template <int NJ>
 __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __restrict__ hyp, const int32_t* __restrict__ hyp_lens, int64_t ld_h,
                                                            const int64_t* __restrict__ ref, const int32_t* __restrict__ ref_lens, int64_t ld_r,
                                                            int space_id, int32_t* __restrict__ dist, int32_t* __restrict__ ref_units) {
@@ -71,24 +74,24 @@ __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __rest
   __syncthreads();
   const int na = s_n[0], nb = s_n[1];
   // lane owns reference positions j = lane*NJ + q + 1 (q < NJ): contiguous per lane, so the in-lane part of the scan is serial
-  unsigned long long bj[kEdNJ];
-  int prev[kEdNJ];                // prev[q] = D[i-1][j]
+  unsigned long long bj[NJ];
+  int prev[NJ];                // prev[q] = D[i-1][j]
 #pragma unroll
-  for (int q = 0; q < kEdNJ; ++q) {
-    const int j = lane * kEdNJ + q + 1;
+  for (int q = 0; q < NJ; ++q) {
+    const int j = lane * NJ + q + 1;
     bj[q] = j <= nb ? s_b[j - 1] : 0ull;
     prev[q] = j;                  // D[0][j] = j
   }
   for (int i = 1; i <= na; ++i) {
     const unsigned long long ai = s_a[i - 1];
     // D[i-1][j-1] for this lane's first cell comes from the previous lane's last cell (lane 0: D[i-1][0] = i-1)
-    int left_prev = __shfl_up(prev[kEdNJ - 1], 1, 64);
+    int left_prev = __shfl_up(prev[NJ - 1], 1, 64);
     if (lane == 0) left_prev = i - 1;
-    int t[kEdNJ];
+    int t[NJ];
     int run = 0x3fffffff;         // min over this lane's cells of t[k] - k
 #pragma unroll
-    for (int q = 0; q < kEdNJ; ++q) {
-      const int j = lane * kEdNJ + q + 1;
+    for (int q = 0; q < NJ; ++q) {
+      const int j = lane * NJ + q + 1;
       const int diag = q == 0 ? left_prev : prev[q - 1];
       const int v = min(prev[q] + 1, diag + (ai != bj[q] ? 1 : 0));
       run = min(run, v - j);
@@ -100,19 +103,19 @@ __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __rest
     if (lane == 0) before = 0x3fffffff;
     before = min(before, i);      // cur[0] = i contributes (i - 0) to every j
 #pragma unroll
-    for (int q = 0; q < kEdNJ; ++q) {
-      const int j = lane * kEdNJ + q + 1;
+    for (int q = 0; q < NJ; ++q) {
+      const int j = lane * NJ + q + 1;
       prev[q] = j + min(t[q], before);
     }
   }
   // D[na][nb]: nb = 0 -> na
   int res = na;
 #pragma unroll
-  for (int q = 0; q < kEdNJ; ++q) {
-    const int j = lane * kEdNJ + q + 1;
+  for (int q = 0; q < NJ; ++q) {
+    const int j = lane * NJ + q + 1;
     if (j == nb) res = prev[q];
   }
-  const int owner = nb > 0 ? (nb - 1) / kEdNJ : 0;
+  const int owner = nb > 0 ? (nb - 1) / NJ : 0;
   res = __shfl(res, owner, 64);
   if (lane == 0) { dist[b] = res; ref_units[b] = nb; }
 }
@@ -160,8 +163,15 @@ extern "C" int lasr_edit_distance_batch(const int32_t* hyp_tokens, const int32_t
   LASR_CHECK_SHAPE(ld_hyp <= kEdMaxUnits && ld_ref <= kEdMaxUnits, "lasr_edit_distance_batch: more than %d tokens per utterance",
                    kEdMaxUnits);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(edit_distance_kernel, dim3((unsigned)B), dim3(64), 0, st, hyp_tokens, hyp_lens, ld_hyp, ref_tokens, ref_lens, ld_ref,
-                     space_id, dist, ref_units);
+  if (ld_ref <= 128)
+    hipLaunchKernelGGL(edit_distance_kernel<2>, dim3((unsigned)B), dim3(64), 0, st, hyp_tokens, hyp_lens, ld_hyp, ref_tokens, ref_lens, ld_ref,
+                       space_id, dist, ref_units);
+  else if (ld_ref <= 512)
+    hipLaunchKernelGGL(edit_distance_kernel<8>, dim3((unsigned)B), dim3(64), 0, st, hyp_tokens, hyp_lens, ld_hyp, ref_tokens, ref_lens, ld_ref,
+                       space_id, dist, ref_units);
+  else
+    hipLaunchKernelGGL(edit_distance_kernel<kEdNJ>, dim3((unsigned)B), dim3(64), 0, st, hyp_tokens, hyp_lens, ld_hyp, ref_tokens, ref_lens, ld_ref,
+                       space_id, dist, ref_units);
   LASR_LAUNCH_CHECK("edit_distance_kernel");
   if (totals) {
     hipLaunchKernelGGL(edit_totals_kernel, dim3(1), dim3(64), 0, st, dist, ref_units, B, reinterpret_cast<long long*>(totals));

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import logging
 import os
+import time
 from collections import deque
 from typing import Dict, Optional
 
@@ -69,7 +70,7 @@ class HostWaveSource:
             db.aug = None
             db.paths, db.B, db.ld, db.S, db.seconds = paths, B, L, targets.shape[1], float(lens.sum()) / SR
             db.ready, db.dslot, db.index, db.key = None, -1, k, (B, L, targets.shape[1], False)
-            db.mask = mask
+            db.mask, db.waited = mask, True
             yield db
 
     def release(self, db) -> None:
@@ -88,7 +89,8 @@ class NativeSource:
         cap = int(batch_size * (int(max_seconds * SR) + 64))
         self.ring = PinnedRing(4, cap, 8 * batch_size + 2 * batch_size * 256)
         self.feeder = DeviceFeeder(self.ring, device, n_slots=4)
-        self.producer = BatchProducer(dataset, index_batches, self.ring, mask, audio_parser, n_threads=n_threads, crop=crop)
+        self.producer = BatchProducer(dataset, index_batches, self.ring, mask, audio_parser, n_threads=n_threads, crop=crop,
+                                      feeder=self.feeder)
         self.mask = mask
         self.n = len(index_batches)
 
@@ -96,13 +98,11 @@ class NativeSource:
         self.producer.start()
         try:
             while True:
-                hb = self.producer.out.get()
-                if hb is None:
+                db = self.producer.out.get()          # uploaded by the producer thread; `ready` orders the consumer behind the copies
+                if db is None:
                     return
-                if isinstance(hb, BaseException):
-                    raise hb
-                db = self.feeder.upload(hb)
-                db.mask = self.mask
+                if isinstance(db, BaseException):
+                    raise db
                 yield db
         finally:
             self.producer.stop()
@@ -142,6 +142,8 @@ class FusedLoop:
         self.graph_steps = self.eager_steps = 0
         self.audio_seconds = 0.0
         self.samples_real = self.samples_padded = 0      # padding bookkeeping: sum of valid samples / of B * row pitch
+        self.ingest_wait_s = 0.0                         # host time spent waiting for the next batch from the ingest (0 = never starved)
+        self.host_step_s = 0.0                           # host time spent enqueuing steps
         self.on_host_batch = getattr(trainer, "_fused_on_batch", None)  # test hook: called with every DevBatch before it is trained on
 
     # ---- one step ------------------------------------------------------------------------------------------------------
@@ -178,9 +180,11 @@ class FusedLoop:
     def step(self, cur: DevBatch, nxt: Optional[DevBatch], batch_idx: int):
         ts, native = self.ts, self.native
         stream = torch.cuda.current_stream()
-        for b in (cur, nxt):
-            if b is not None and b.ready is not None:
-                stream.wait_event(b.ready)
+        for b in (cur, nxt):          # once per batch, and not at all when its copies have already completed (issued two steps ahead)
+            if b is not None and not b.waited:
+                b.waited = True
+                if b.ready is not None and not b.ready.query():
+                    stream.wait_event(b.ready)
         if self.on_host_batch is not None:
             self.on_host_batch(cur)
         feats, pct = self._feats_for(cur)
@@ -203,6 +207,8 @@ class FusedLoop:
         # train.py:79-81: self.log('train_loss'), self.log('train_wer') - decode, distance and accumulation stay on the device
         wer = self.model.wer
         t_lens = native.tap("lens")
+        if os.environ.get("LASR_EXP_NO_METRICS"):      # experiment switch: price the per-step decode + WER logging
+            return loss
         if wer.device_path(am, cur.targets):
             dist, units = wer.device_distances(am, cur.targets, cur.sizes, t_lens)
             ops.step_metrics(loss, dist, units, self.acc)
@@ -246,10 +252,14 @@ class FusedLoop:
                     break
                 cur = window.popleft()
                 nxt = window[0] if window else None
+                t0 = time.perf_counter()
                 b = next(it, None)
+                t1 = time.perf_counter()
                 if b is not None:
                     window.append(b)
                 self.step(cur, nxt, batch_idx)
+                self.ingest_wait_s += t1 - t0
+                self.host_step_s += time.perf_counter() - t1
                 src.release(cur)
                 tr.global_step += 1
                 batch_idx += 1

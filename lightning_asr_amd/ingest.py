@@ -95,8 +95,9 @@ class BatchProducer(threading.Thread):
     from the consumer once its H2D copies are done."""
 
     def __init__(self, dataset, index_batches: Iterable[List[int]], ring: PinnedRing, mask: bool, audio_parser, n_threads: int = 8,
-                 crop_weight: float = 0.98, depth: int = 2, crop: Optional[bool] = None):
+                 crop_weight: float = 0.98, depth: int = 2, crop: Optional[bool] = None, feeder: Optional["DeviceFeeder"] = None):
         super().__init__(daemon=True)
+        self.feeder = feeder         # given: this thread also issues the H2D copies and hands over DevBatch objects
         self.ds, self.batches, self.ring, self.mask, self.ap = dataset, index_batches, ring, mask, audio_parser
         self.n_threads, self.crop_weight = max(1, int(n_threads)), crop_weight
         self.crop = mask if crop is None else crop
@@ -127,22 +128,37 @@ class BatchProducer(threading.Thread):
                 slot = self.ring.free.get()
                 if slot < 0 or self._halt.is_set():
                     return
-                if not self._put(self.make(list(idx), slot, k)):
+                item = self.make(list(idx), slot, k)
+                if self.feeder is not None:
+                    item = self.feeder.upload(item)
+                    item.mask = self.mask
+                if not self._put(item):
                     return
             self._put(None)
         except BaseException as e:  # noqa: BLE001 - handed to the consumer, which re-raises
             self._put(e)
 
+    def _ids(self, i: int) -> np.ndarray:
+        """token ids of manifest entry i (text -> ids once per entry, then cached)"""
+        cache = self.ds.__dict__.setdefault("_lasr_ids_cache", {})
+        a = cache.get(i)
+        if a is None:
+            c2i = self.ds.char2index
+            a = cache[i] = np.fromiter((c2i[ch] for ch in self.ds.datasets[i]["text"]), dtype=np.int64)
+        return a
+
     def make(self, idx: List[int], slot: int, index: int = 0) -> HostBatch:
+        """one batch into ring slot `slot`; everything but the wav decode is a handful of numpy writes into the slot's metadata block
+        (this thread shares the GIL with the thread that enqueues the training step)"""
         ds, ring = self.ds, self.ring
-        items = [ds.datasets[i] for i in idx]
-        B = len(items)
-        paths = [d["audio_filepath"] for d in items]
-        ids = [[ds.char2index[ch] for ch in d["text"]] for d in items]
-        S = max(1, max(len(t) for t in ids))
+        B = len(idx)
+        paths = [ds.datasets[i]["audio_filepath"] for i in idx]
+        ids = [self._ids(i) for i in idx]
+        S = max(1, max(a.size for a in ids))
         o_lens, o_sizes, o_aug, o_tg, words = _meta_layout(B, S, self.mask)
         ring.grow(slot, meta_words=words)
         meta = ring.meta[slot]
+        mnp = meta.numpy()                                   # shares the (pinned) memory
         crop_u = np.random.uniform(0.0, 1.0, size=(B, 2)) if self.crop else None      # the two draws of sub_secquence per clip
         lens = meta[o_lens:o_lens + B]
         while True:
@@ -153,29 +169,29 @@ class BatchProducer(threading.Thread):
                 if "do not fit the buffer" not in str(e):
                     raise
                 ring.grow(slot, capacity=int(ring.pcm[slot].numel() * 1.5) + 8 * B)    # a file longer than its manifest duration
-        sizes = meta[o_sizes:o_sizes + B]
-        tg = meta[o_tg:o_tg + 2 * B * S].view(torch.int64).view(B, S)
-        tg.zero_()
-        for i, t in enumerate(ids):
-            sizes[i] = len(t)
-            if t:
-                tg[i, :len(t)] = torch.tensor(t, dtype=torch.int64)
+        lens_np = mnp[o_lens:o_lens + B]
+        mnp[o_sizes:o_sizes + B] = [a.size for a in ids]
+        tg_np = mnp[o_tg:o_tg + 2 * B * S].view(np.int64).reshape(B, S)
+        tg_np[:] = 0
+        for i, a in enumerate(ids):
+            tg_np[i, :a.size] = a
         aug = None
         if self.mask:       # spec_augment(27, 0.07) rectangles, drawn per clip in the reference's order (data_module.py:97-122,165)
+            draw = self.ap.draw_spec_augment
+            mnp[o_aug:o_aug + 4 * B] = np.asarray([draw(1 + (int(l) + 64) // 160) for l in lens_np], dtype=np.int32).reshape(-1)
             aug = meta[o_aug:o_aug + 4 * B].view(B, 4)
-            for i in range(B):
-                n_time = 1 + (int(lens[i]) + 64) // 160
-                aug[i] = torch.tensor(self.ap.draw_spec_augment(n_time), dtype=torch.int32)
         hb = HostBatch()
-        hb.slot, hb.B, hb.ld, hb.S, hb.lens, hb.sizes, hb.aug, hb.targets = slot, B, ld, S, lens, sizes, aug, tg
+        hb.slot, hb.B, hb.ld, hb.S, hb.lens, hb.aug = slot, B, ld, S, lens, aug
+        hb.sizes = meta[o_sizes:o_sizes + B]
+        hb.targets = meta[o_tg:o_tg + 2 * B * S].view(torch.int64).view(B, S)
         hb.meta, hb.meta_words, hb.paths, hb.mask, hb.index = meta, words, paths, self.mask, index
-        hb.seconds = float(lens.sum()) / SR
+        hb.seconds = float(lens_np.sum()) / SR
         return hb
 
 
 class DevBatch:
     """one batch resident in HBM (views of a device ring slot), valid for the compute stream once ``ready`` has been waited on"""
-    __slots__ = ("pcm", "lens", "sizes", "aug", "targets", "paths", "B", "ld", "S", "seconds", "ready", "dslot", "index", "key", "mask")
+    __slots__ = ("pcm", "lens", "sizes", "aug", "targets", "paths", "B", "ld", "S", "seconds", "ready", "dslot", "index", "key", "mask", "waited")
 
 
 class DeviceFeeder:
@@ -189,8 +205,11 @@ class DeviceFeeder:
         self.pcm = [torch.empty(ring.capacity, dtype=torch.int16, device=self.device) for _ in range(n_slots)]
         self.meta = [torch.empty(ring.meta_words, dtype=torch.int32, device=self.device) for _ in range(n_slots)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.released: List[Optional[torch.cuda.Event]] = [None] * n_slots
-        self._next = 0
+        # device slots are handed back explicitly: (slot, event recorded on the compute stream after the last kernel that reads it).
+        # The uploader (producer thread) BLOCKS here when every slot is in flight - it may run several batches ahead of the step.
+        self.free_dev: "queue.Queue" = queue.Queue()
+        for k in range(n_slots):
+            self.free_dev.put((k, None))
         self._done_q: "queue.Queue" = queue.Queue()
         self._recycler = threading.Thread(target=self._recycle, daemon=True)
         self._recycler.start()
@@ -206,18 +225,24 @@ class DeviceFeeder:
 
     def close(self) -> None:
         self._done_q.put(None)
+        self.free_dev.put((-1, None))          # unblock an uploader waiting for a device slot
 
     def upload(self, hb: HostBatch) -> DevBatch:
-        k = self._next
-        self._next = (k + 1) % self.n_slots
+        """(called from the producer thread: HIP calls of a copy are ordinary stream operations, the compute thread only ever
+        reads ``released`` / writes it in ``release``)"""
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        k, released = self.free_dev.get()
+        if k < 0:
+            raise RuntimeError("device feeder closed")
         n = hb.B * hb.ld
         if n > self.pcm[k].numel():
             self.pcm[k] = torch.empty(n, dtype=torch.int16, device=self.device)
         if hb.meta_words > self.meta[k].numel():
             self.meta[k] = torch.empty(hb.meta_words, dtype=torch.int32, device=self.device)
         cs = self.copy_stream
-        if self.released[k] is not None:
-            cs.wait_event(self.released[k])     # the step that read this device slot has finished with it
+        if released is not None:
+            cs.wait_event(released)             # the step that read this device slot has finished with it
         with torch.cuda.stream(cs):
             self.pcm[k][:n].copy_(self.ring.pcm[hb.slot][:n], non_blocking=True)
             self.meta[k][:hb.meta_words].copy_(hb.meta[:hb.meta_words], non_blocking=True)
@@ -234,13 +259,14 @@ class DeviceFeeder:
         db.targets = m[o_tg:o_tg + 2 * B * S].view(torch.int64).view(B, S)
         db.paths, db.B, db.ld, db.S, db.seconds, db.ready, db.dslot, db.index = hb.paths, B, hb.ld, S, hb.seconds, ev, k, hb.index
         db.key = (B, hb.ld, S, hb.aug is not None)
+        db.waited = False
         return db
 
     def release(self, db: DevBatch) -> None:
         """call after the last kernel that reads ``db`` has been enqueued on the current stream"""
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self.released[db.dslot] = ev
+        self.free_dev.put((db.dslot, ev))
 
 
 def fast_ingest_ok(dataset) -> bool:

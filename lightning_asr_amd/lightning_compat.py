@@ -211,7 +211,7 @@ class Trainer:
             src = make_source(dm, loader, self.device, False, n, getattr(dm, "dev_max_duration", 40) or 40, getattr(dm, "dev_bs", 16))
             try:
                 for db in src:
-                    if db.ready is not None:
+                    if db.ready is not None and not db.ready.query():
                         torch.cuda.current_stream().wait_event(db.ready)
                     inputs, pct = dm.audio_parser.features_device(db.pcm, db.lens, None)
                     yield inputs, db.targets, pct, db.sizes, db.paths
