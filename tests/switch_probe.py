@@ -1,0 +1,39 @@
+"""Helper of tests/test_gpu_switches.py: one bf16 training step (and one eval forward) of the plan under whatever LASR_* switches the
+environment carries; prints a JSON line with the loss, the gradient norms per parameter group and an eval checksum."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from lightning_asr_amd.engine import NativeModel  # noqa: E402
+from lightning_asr_amd.step import TrainStep  # noqa: E402
+
+
+def main():
+    variant, n_class = sys.argv[1], int(sys.argv[2])
+    dev = torch.device("cuda:0")
+    B, L, S = 24, 64000, 20                      # 24 x 201 = 4824 rows: past the 4096-row threshold of the sliced BN backward
+    wave, tg, tl = bench.synth_batch(B, L, S, 77, dev, n_class - 1)
+    nxt, _, _ = bench.synth_batch(B, L, S, 78, dev, n_class - 1)
+    m = NativeModel(variant, n_class, mask=True, act="relu", dtype=torch.bfloat16, device=dev)
+    m.init_parameters(seed=1)
+    ts = TrainStep(m, 1e-2, 1e-3)
+    loss, nll, logp, am = ts.step(wave, tg, tl, prefetch_wave=nxt, want_logp=False)
+    torch.cuda.synchronize()
+    g = m.grads.double()
+    groups = {}
+    for t in m.param_infos():
+        key = t.name.split(".")[1] if t.name.startswith("encoder.") else t.name.split(".")[0]
+        groups[key] = groups.get(key, 0.0) + float((g[t.offset:t.offset + t.numel] ** 2).sum())
+    feats, pct = ts.features(wave)
+    lp, _ = m.forward(feats, pct, training=False)
+    print(json.dumps({"loss": float(loss), "grad_norm": {k: v ** 0.5 for k, v in groups.items()}, "eval_checksum": float(lp.double().abs().mean()),
+                      "params_after": float(m.params.double().abs().sum())}))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""GPU tier: the A/B switches that select alternative kernels inside liblasr (DESIGN.md §4 "Switches") are branches of the shipped
+library; the default suite only walks the defaults.  Each switch here runs the same bf16 training step + eval forward in a
+subprocess (the switches are read once per process) and must agree with the default build of the step: same loss, same gradient
+norms per layer group, same eval log-probs - to bf16-path tolerances (different kernels round differently)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWITCHES = [
+    {},                                             # defaults (the yardstick)
+    {"LASR_DW_UNI": "0"}, {"LASR_DW_UNI": "64"},   # depthwise backward: two-kind grid / 64-channel unified form
+    {"LASR_DWCONV_FMA": "1"}, {"LASR_DWCONV_DOT2": "1"}, {"LASR_DWWGRAD_VALU": "1"},   # VALU forms of the depthwise kernels
+    {"LASR_DW_NO_FUSED_BWD": "1"},
+    {"LASR_NO_FUSE": "1"}, {"LASR_NO_DEFER": "1"},  # unfused BN statistics / inline weight-gradient reductions
+    {"LASR_BN_SLICED": "0"},                        # row-major BN backward pair
+    {"LASR_WGRAD_SMALL_TILE": "1"}, {"LASR_NO_GEMM_BATCH": "1"}, {"LASR_GEMM_BIG_MIN_TILES": "100000"},   # 128 x 128 GEMM forms
+    {"LASR_NO_MEL_CTC": "1"}, {"LASR_CTC_NO_LDS": "1"},   # separate lattice / feature launches; emissions through the register ring
+    {"LASR_NO_EVAL_FOLD": "1"},
+]
+
+
+def _run(env_extra, variant="plain", n_class=28):
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("LASR_") and k not in ("LASR_LIB_PATH",):
+            del env[k]
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_probe.py"), variant, str(n_class)], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, (env_extra, out.stderr[-2000:])
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def _close(a, b, env):
+    assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(b["loss"]), (env, a["loss"], b["loss"])
+    for k, v in b["grad_norm"].items():
+        assert abs(a["grad_norm"][k] - v) <= 5e-2 * v + 1e-6, (env, k, a["grad_norm"][k], v)
+    assert abs(a["eval_checksum"] - b["eval_checksum"]) <= 5e-3 * abs(b["eval_checksum"]), (env, a["eval_checksum"], b["eval_checksum"])
+
+
+def test_kernel_switches_agree_with_the_default_paths(dev):
+    base = _run({})
+    assert base["loss"] > 0 and all(v > 0 for v in base["grad_norm"].values())
+    for env in SWITCHES[1:]:
+        _close(_run(env), base, env)
+
+
+def test_large_vocabulary_head_switch(dev):
+    """dense head (LASR_NO_LEAN_HEAD=1) against the lean head at C = 300"""
+    base = _run({}, n_class=300)
+    _close(_run({"LASR_NO_LEAN_HEAD": "1"}, n_class=300), base, "LASR_NO_LEAN_HEAD")
+
+
+def test_context_se_switches(dev):
+    base = _run({}, variant="context_se")
+    for env in ({"LASR_SE_UNFUSED_BWD": "1"}, {"LASR_NO_FUSE": "1"}):
+        _close(_run(env, variant="context_se"), base, env)
