@@ -260,3 +260,40 @@ def test_batch_producer_fills_ring_slots(tmp_path):
     o_lens, o_sizes, o_aug, o_tg, words = ingest._meta_layout(3, 4, True)
     assert hb.meta[o_lens:o_lens + 3].tolist() == [11000, 12000, 13000] and words == hb.meta_words
     assert hb.meta[o_tg:o_tg + 24].view(torch.int64).view(3, 4)[2].tolist() == [0, 1, 2, 6]
+
+
+def test_batch_producer_hands_errors_to_the_consumer_and_grows_a_short_slot(tmp_path):
+    """a missing wav file surfaces as an exception object on the producer's queue (the trainer re-raises it); a clip longer than the
+    ring slot was sized for (manifest duration too small) makes the producer grow the slot instead of failing"""
+    import json
+    import random
+    import numpy as np
+    from lightning_asr_amd import ingest
+    from lightning_asr_amd.data_module import AudioParser, MyAudioDataset
+    rng = np.random.default_rng(2)
+    man = tmp_path / "m.json"
+    with open(man, "w") as f:
+        for i in range(3):
+            p = tmp_path / ("d%d.wav" % i)
+            if i != 1:
+                _write_wav(p, rng.integers(-1000, 1000, size=(20000, 1), dtype=np.int16))
+            f.write(json.dumps({"audio_filepath": str(p), "duration": 0.1, "text": "ab"}) + "\n")      # duration understated
+    ds = MyAudioDataset([str(man)], list("ab"), mask=False)
+    ap = AudioParser.__new__(AudioParser)
+    ap.rand = random.Random(0)
+
+    def drain(batches, cap):
+        ring = ingest.PinnedRing(2, cap, 64, pin=False)
+        prod = ingest.BatchProducer(ds, batches, ring, mask=False, audio_parser=ap, n_threads=2)
+        prod.start()
+        out = []
+        while True:
+            it = prod.out.get(timeout=30)
+            out.append(it)
+            if it is None or isinstance(it, BaseException):
+                return out, ring
+    out, ring = drain([[0, 2]], 2 * 1600 + 64)               # sized for 0.1 s clips, the files hold 1.25 s
+    assert isinstance(out[0], ingest.HostBatch) and out[0].lens.tolist() == [20000, 20000] and out[1] is None
+    assert ring.pcm[out[0].slot].numel() >= 2 * 20000
+    out, _ = drain([[0, 1]], 2 * 20000 + 64)
+    assert isinstance(out[-1], BaseException) and "cannot open" in str(out[-1])
