@@ -207,8 +207,6 @@ class FusedLoop:
         # train.py:79-81: self.log('train_loss'), self.log('train_wer') - decode, distance and accumulation stay on the device
         wer = self.model.wer
         t_lens = native.tap("lens")
-        if os.environ.get("LASR_EXP_NO_METRICS"):      # experiment switch: price the per-step decode + WER logging
-            return loss
         if wer.device_path(am, cur.targets):
             dist, units = wer.device_distances(am, cur.targets, cur.sizes, t_lens)
             ops.step_metrics(loss, dist, units, self.acc)
