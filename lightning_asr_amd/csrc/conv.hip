@@ -12,19 +12,21 @@ static constexpr int kTT = 128;   // output frames per workgroup (16 lanes x 8 o
 static constexpr int kR = 8;      // outputs per thread
 static constexpr int kMaxK = 128;
 
-// grid: (ceil(Tout/kTT), ceil(C/kCB), B), block 256, dynamic LDS: x tile + taps
-template <typename T>
+// grid: (ceil(Tout/(16 R)), ceil(C/kCB), B), block 256, dynamic LDS: x tile + taps.  R = outputs per thread: 8 (128-frame tiles) or
+// 4 (64-frame tiles: twice the workgroups for the one stride-2 layer, whose 64 channels x 32 utterances x 4 tiles left half the chip idle)
+template <typename T, int R = kR>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const T* __restrict__ addend, T* __restrict__ y, int64_t Tin,
                                                          int64_t Tout, int64_t C, int k, int stride, int flip) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int pad = k / 2;
-  const int in_rows = (kTT - 1) * stride + k;
+  constexpr int TT = 16 * R;
+  const int in_rows = (TT - 1) * stride + k;
   float* s_x = smem;                         // [in_rows][kCB]
   float* s_w = smem + (size_t)in_rows * kCB;  // [k][kCB]
   const int b = blockIdx.z;
   const int64_t c0 = (int64_t)blockIdx.y * kCB;
-  const int64_t t0 = (int64_t)blockIdx.x * kTT;
+  const int64_t t0 = (int64_t)blockIdx.x * TT;
   const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;
   const int64_t c = c0 + cl * 4;
   const bool c_ok = c < C;  // C % 4 == 0
@@ -59,15 +61,15 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   }
   __syncthreads();
 
-  float acc[kR][4];
+  float acc[R][4];
 #pragma unroll
-  for (int r = 0; r < kR; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
-  const float* xs = s_x + (size_t)(tl * kR * stride) * kCB + cl * 4;
+  for (int r = 0; r < R; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f;
+  const float* xs = s_x + (size_t)(tl * R * stride) * kCB + cl * 4;
   const float* ws = s_w + cl * 4;
   for (int j = 0; j < k; ++j) {
     const float4 wv = *reinterpret_cast<const float4*>(ws + j * kCB);
 #pragma unroll
-    for (int r = 0; r < kR; ++r) {
+    for (int r = 0; r < R; ++r) {
       const float4 xv = *reinterpret_cast<const float4*>(xs + (size_t)(r * stride + j) * kCB);
       acc[r][0] = fmaf(wv.x, xv.x, acc[r][0]);
       acc[r][1] = fmaf(wv.y, xv.y, acc[r][1]);
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   }
   if (!c_ok) return;
 #pragma unroll
-  for (int r = 0; r < kR; ++r) {
-    const int64_t t = t0 + tl * kR + r;
+  for (int r = 0; r < R; ++r) {
+    const int64_t t = t0 + tl * R + r;
     if (t < Tout) {
       const int64_t off = ((int64_t)b * Tout + t) * C + c;
       if (addend) {
@@ -1314,14 +1316,19 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
                            (bf16_t*)y, Tin, C, k, flip);
       }
     }
-  } else if (dtype == LASR_F32) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(dwconv_fwd_kernel<float>, grid, dim3(256), shmem, as_stream(stream), (const float*)x, w,
-                       (const float*)addend, (float*)y, Tin, Tout, C, k, stride, flip);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, grid, dim3(256), shmem, as_stream(stream), (const bf16_t*)x, w,
-                       (const bf16_t*)addend, (bf16_t*)y, Tin, Tout, C, k, stride, flip);
+    // 64-frame tiles when 128-frame tiles would not fill the chip (first_cnn: 64 channels, stride 2)
+    const bool small = (int64_t)grid.x * grid.y * grid.z < 200;
+    const dim3 g2 = small ? dim3((unsigned)cdiv(Tout, 64), grid.y, grid.z) : grid;
+#define LASR_DWF(T_, R_)                                                                                                          \
+  do {                                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_fwd_kernel<T_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((dwconv_fwd_kernel<T_, R_>), g2, dim3(256), shmem, as_stream(stream), (const T_*)x, w, (const T_*)addend, (T_*)y, Tin,  \
+                       Tout, C, k, stride, flip);                                                                                 \
+  } while (0)
+    if (dtype == LASR_F32) { if (small) LASR_DWF(float, 4); else LASR_DWF(float, 8); }
+    else { if (small) LASR_DWF(bf16_t, 4); else LASR_DWF(bf16_t, 8); }
+#undef LASR_DWF
   }
   prof_end(tok, as_stream(stream));
   LASR_LAUNCH_CHECK("dwconv_fwd_kernel");
