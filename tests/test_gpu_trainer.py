@@ -66,7 +66,7 @@ def test_mel_pcm16_device_dither_is_bit_identical_to_f32_with_noise_tensor(dev):
     assert torch.equal(nf, want)
 
 
-def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph):
+def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph, drop_rate=0.0):
     from lightning_asr_amd import ops
     from lightning_asr_amd.data_module import LibriDataModule
     from lightning_asr_amd.engine import NativeModel
@@ -80,7 +80,7 @@ def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph):
     act = torch.float32 if dtype == "f32" else torch.bfloat16
     dm = LibriDataModule([str(data / "train.json")], str(data / "dev.json"), str(data / "dev.json"), LABELS, train_bs=4, dev_bs=4,
                          num_worker=2, device=str(dev), act_dtype=act, train_crop=crop)
-    model = LightingModule(learning_rate=1e-2, weight_decay=1e-3, labels=LABELS, total_epoch=1, drop_rate=0.0, mask=True, use_cer=True,
+    model = LightingModule(learning_rate=1e-2, weight_decay=1e-3, labels=LABELS, total_epoch=1, drop_rate=drop_rate, mask=True, use_cer=True,
                            dtype=dtype, device=str(dev), warmup_steps=2)
     init = {"params": model.encoder.native.params.clone(), "buffers": model.encoder.native.buffers.clone()}
     seen = []
@@ -101,6 +101,8 @@ def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph):
     # the same batches through a hand-driven TrainStep (the bench path): same seed for the in-kernel dither
     m2 = NativeModel("plain", 28, mask=True, act="relu", dtype=act, device=dev)
     m2.params.copy_(init["params"]); m2.buffers.copy_(init["buffers"])
+    if drop_rate:      # nn.Dropout(p=drop_rate): the same counter-based masks (seed from pl.seed_everything, step counter on the device)
+        m2.set_dropout(drop_rate, model.encoder.native.drop_seed)
     sched = CosineAnnealingWarmupRestarts(None, first_cycle_steps=1 * steps, cycle_mult=2, max_lr=1e-2, min_lr=1e-4, warmup_steps=2, gamma=0.5)
     ts = TrainStep(m2, 1e-2, 1e-3, schedule=sched)
     dd = ops.DeviceDither(tr.fused.dither.seed, dev)
@@ -124,6 +126,12 @@ def test_trainer_fit_equals_trainstep_bit_identical_graph_bf16(dev, tmp_path, mo
     """fixed-length clips, no crop: from the third sighting of the batch shape the steps replay a captured hipGraph"""
     tr = _fit_and_replay(dev, tmp_path, "bf16", 8, False, monkeypatch, graph=True)
     assert tr.fused.eager_steps >= 2
+
+
+def test_trainer_fit_with_dropout_replays_fresh_masks_from_the_graph(dev, tmp_path, monkeypatch):
+    """model.drop_rate > 0 through Trainer.fit: the masks are regenerated from (seed, device step counter), so the graph-replayed steps
+    draw the masks the eager hand-driven steps draw - same parameters bit for bit - and validation (eval mode) runs without dropout"""
+    _fit_and_replay(dev, tmp_path, "bf16", 6, False, monkeypatch, graph=True, drop_rate=0.1)
 
 
 def test_trainer_uses_the_lean_head_for_a_large_vocabulary(dev, tmp_path):
