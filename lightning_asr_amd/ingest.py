@@ -33,10 +33,11 @@ def wav_info(path: str):
 
 
 def read_wav_batch(paths: Sequence[str], out: torch.Tensor, lens_out: torch.Tensor, crop_u: Optional[np.ndarray] = None,
-                   crop_weight: float = 0.98, n_threads: int = 8, expect_rate: int = SR) -> int:
+                   crop_weight: float = 0.98, n_threads: int = 8, expect_rate: int = 0) -> int:
     """Decode ``paths`` into ``out`` (1-D int16 host tensor, normally pinned) as rows of pitch ``ld`` (returned);
     ``lens_out`` (>= len(paths) int32 host tensor) receives the valid samples per row.  crop_u: (n, 2) float64 uniforms for the
-    training-time sub-sequence (data_module.py:138-148), or None."""
+    training-time sub-sequence (data_module.py:138-148), or None.  expect_rate > 0 refuses files of another sample rate; the
+    default takes any rate as it is, like the reference (data_module.py:153 drops the rate torchaudio.load returns)."""
     n = len(paths)
     if out.dtype != torch.int16 or out.is_cuda or not out.is_contiguous():
         raise TypeError("read_wav_batch writes a contiguous int16 host tensor")
