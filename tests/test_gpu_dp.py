@@ -240,9 +240,11 @@ def test_graphed_step_equals_eager(dev, variant, prefetch):
     assert int(sd["encoder.first_cnn.bn.num_batches_tracked"]) == 4
 
 
-def _fit_worker(rank, world, port, data, out, q):
+def _fit_worker(rank, world, port, data, out, q, stub=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       LASR_DIST_BACKEND="gloo")
+    if stub:       # the library's own communicator (lasr_comm_*) over the test stand-in for librccl; gloo only carries the unique id
+        os.environ["LASR_RCCL_PATH"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "libstubrccl.so")
     try:
         from lightning_asr_amd.train import main
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -252,17 +254,25 @@ def _fit_worker(rank, world, port, data, out, q):
               "train.warmup_steps=2", "output_dir=%s" % os.path.join(out, "rank%d" % rank)]
         tr = main(ov)
         import torch.distributed as dist
-        q.put((rank, tr.global_step, tr.history[-1]["train_loss"], str(tr.device)))
+        native = tr.fused.native
+        used_comm = tr.fused.ts.comm is not None
+        q.put((rank, tr.global_step, tr.history[-1]["train_loss"], str(tr.device), float(native.params.double().sum()), used_comm,
+               tr.history[-1].get("val_wer"), tr.history[-1].get("val_wer_total")))
+        dist.barrier()
+        if used_comm:
+            tr.fused.ts.comm.close()
         dist.destroy_process_group()
     except Exception:
         import traceback
-        q.put((rank, None, traceback.format_exc(), ""))
+        q.put((rank, None, traceback.format_exc(), "", 0.0, False, None, None))
 
 
-def test_trainer_fit_two_ranks(dev, tmp_path):
+@pytest.mark.parametrize("stub", [False, True])
+def test_trainer_fit_two_ranks(dev, tmp_path, stub):
     """python -m lightning_asr_amd.train with WORLD_SIZE=2 (train.py:233-252, `accelerator: ddp`): both ranks select their device
     BEFORE allocating, shard the corpus (DistributedSampler), all-reduce the flat gradient and stay in lock-step.  Two ranks
-    share the test box's one GPU, so the group is gloo (LASR_DIST_BACKEND)."""
+    share the test box's one GPU, so the group is gloo (LASR_DIST_BACKEND).  stub=True: the gradient exchange, the wrap-time broadcast
+    and the validation metric sums go through the library's communicator (over tests/stub_rccl), as they do over RCCL on real ranks."""
     import subprocess
     import sys
     import torch.multiprocessing as mp
@@ -275,7 +285,7 @@ def test_trainer_fit_two_ranks(dev, tmp_path):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, data, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, data, str(tmp_path), q, stub)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
@@ -286,6 +296,9 @@ def test_trainer_fit_two_ranks(dev, tmp_path):
     assert res[0][1] == res[1][1] == 2            # 8 utterances / (2 ranks x batch 2) = 2 steps each
     assert res[0][3] == res[1][3] == "cuda:0"
     assert all(r[2] == r[2] for r in res)         # finite losses (not NaN)
+    assert res[0][4] == res[1][4]                 # the replicas hold the same parameters
+    assert res[0][5] == res[1][5] == stub         # lasr_comm_* carried the exchange exactly when the stub stood in for librccl
+    assert res[0][6] == res[1][6] and res[0][7] == res[1][7]     # val_wer / val_wer_total agree across the ranks
 
 
 def test_graphed_step_bound_inputs_ping_pong(dev):
