@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LASR_VERSION 100
+#define LASR_VERSION 101   /* 101: lasr_mel_fwd_src / lasr_wav_read_batch / lasr_step_metrics / lasr_model_set_prefetch_src */
 
 enum { LASR_F32 = 0, LASR_BF16 = 1 };
 enum { LASR_ACT_NONE = 0, LASR_ACT_RELU = 1, LASR_ACT_SWISH = 2 };

@@ -278,8 +278,11 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
     scratch = std::max(scratch, lasr_gemm_workspace_bytes(160, 256, 16, 0));
     scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, 160));
   }
+  // f32 logits (dense head) or bf16 logits with rows padded to 8 classes (large-vocabulary head) - and, in the SAME bytes, the dense
+  // head's d(loss)/d(logits): log_softmax has consumed the logits before the CTC gradient kernel writes, and backward reads only the
+  // gradient (444 MB less at C = 4334, bs = 32; tap "logits" of a dense TRAINING step therefore shows the gradient)
   p.o_logits = take(cur, (size_t)N * C * sizeof(float));
-  p.o_glogits = take(cur, (size_t)N * C * sizeof(float));
+  p.o_glogits = p.o_logits;
   p.o_nll = take(cur, (size_t)(B + 1) * sizeof(float));
   for (Unit& u : m->units) {   // eval-mode folded weights
     if (u.has_res) {
