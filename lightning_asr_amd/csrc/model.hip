@@ -97,7 +97,6 @@ struct Plan {
   size_t o_lens = 0, o_logits = 0, o_glogits = 0, o_nll = 0, o_scratch = 0, o_g[2] = {0, 0}, o_d1 = 0, o_d2 = 0, o_du = 0, o_dxr = 0;
   size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0;
   size_t o_cat = 0, o_gx[2] = {0, 0}, o_lstm_saved = 0, o_dg[2] = {0, 0};   // context: [N][336] | [N][160] f32 x2 | saved | [N][160] f32 x2
-  size_t o_dgb[2] = {0, 0}, o_lstm_wgp[2] = {0, 0};   // bf16 copies of the gate gradients and the split-K slabs of dW_ih: they live until the stage's batched weight-gradient launch
   size_t scratch_bytes = 0, ctc_bytes = 0;
   size_t o_rowstat = 0, o_lean = 0, lean_bytes = 0;   // large-vocabulary head: softmax row statistics, lasr_ctc_loss_lean workspace
 };
@@ -275,10 +274,6 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
     p.o_cat = take(cur, (size_t)N * 336 * es);
     for (int d = 0; d < 2; ++d) { p.o_gx[d] = take(cur, (size_t)N * 160 * sizeof(float)); p.o_dg[d] = take(cur, (size_t)N * 160 * sizeof(float)); }
     p.o_lstm_saved = take(cur, lasr_bilstm_saved_bytes(B, p.T));
-    for (int d = 0; d < 2; ++d) {
-      p.o_dgb[d] = take(cur, (size_t)N * 160 * sizeof(bf16_t));
-      p.o_lstm_wgp[d] = take(cur, lasr_gemm_workspace_bytes(160, 256, wgrad_split(), 0));
-    }
     scratch = std::max(scratch, lasr_bilstm_bwd_workspace_bytes(B));
     scratch = std::max(scratch, lasr_gemm_workspace_bytes(160, 256, 16, 0));
     scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, 160));
@@ -739,9 +734,9 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       if (u.has_res) pr[1] = {dy2, x_in, grads + u.w_res, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
       if (defer_w) {
         float* slab = atf(ws, u.o_wgp);
+        if (wprobs.size() + (u.has_res ? 2 : 1) > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));   // (the launch takes 32 problems)
         wprobs.push_back(pr[0]); wslabs.push_back(slab);
         if (u.has_res) { wprobs.push_back(pr[1]); wslabs.push_back(slab + u.wgp_bytes / (2 * sizeof(float))); }
-        if (wprobs.size() + 2 > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
       }
@@ -797,20 +792,16 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       for (int d = 0; d < 2; ++d) {
         const void* dg_ab = atf(ws, p.o_dg[d]);
         if (dt == LASR_BF16) {
-          LASR_TRY(lasr_cast_f32_to_bf16(atf(ws, p.o_dg[d]), at(ws, p.o_dgb[d]), N * 160, stream));
-          dg_ab = at(ws, p.o_dgb[d]);
+          LASR_TRY(lasr_cast_f32_to_bf16(atf(ws, p.o_dg[d]), at(ws, p.o_d1), N * 160, stream));
+          dg_ab = at(ws, p.o_d1);
         }
         LASR_TRY(lasr_colsum_f32(atf(ws, p.o_dg[d]), grads + m->lstm.b_ih[d], N, 160, scratch, sb, stream));
         // both biases enter the gates as b_ih + b_hh: one gradient, stored twice
         LASR_TRY(lasr_copy_cols(grads + m->lstm.b_ih[d], LASR_F32, 160, 0, grads + m->lstm.b_hh[d], LASR_F32, 160, 0, 1, 160, 0, stream));
-        if (defer && dt == LASR_BF16) {   // dW_ih = dG^T x23 joins the stage's batched weight-gradient launch (was: its own split-K launch + reduction)
-          wprobs.push_back({dg_ab, x23, grads + m->lstm.w_ih[d], 160, 256, N, nullptr, nullptr, 0, nullptr});
-          wslabs.push_back(atf(ws, p.o_lstm_wgp[d]));
-          if (wprobs.size() + 2 > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
-        } else {
-          LASR_TRY(lasr_gemm(dg_ab, x23, grads + m->lstm.w_ih[d], dt, LASR_F32, 160, 256, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16,
-                             scratch, sb, stream));
-        }
+        // (dW_ih = dG^T x23 stays its own split-K launch: as problems 86 and 87 of the stage's batched launch the two one-tile problems
+        //  push it from 3 slices x 85 tiles = 255 workgroups to 2 x 87 = 174, +47 us - exactly what the two small launches cost)
+        LASR_TRY(lasr_gemm(dg_ab, x23, grads + m->lstm.w_ih[d], dt, LASR_F32, 160, 256, N, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, 16,
+                           scratch, sb, stream));
         LASR_TRY(lasr_gemm(dg_ab, wptr(m, params, ws, m->lstm.w_ih[d]), at(ws, p.o_g[cur ^ 1]), dt, dt, N, 256, 160, 0, 1, nullptr,
                            at(ws, p.o_g[cur ^ 1]), nullptr, 0, nullptr, 1, scratch, sb, stream));
       }
