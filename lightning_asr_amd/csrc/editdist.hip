@@ -13,6 +13,7 @@
 // a prefix-min, so a row is: elementwise t, one wave prefix-min scan (6 DPP/shuffle steps), add j.  The reference row
 // lives in registers (NJ cells per lane), `prev` never leaves the wave.
 #include "common.h"
+#include <algorithm>
 
 namespace lasr {
 
@@ -52,8 +53,8 @@ __device__ __forceinline__ int wave_prefix_min_excl_carry(int v, int lane) {   /
 }
 
 // grid = B, block = 64.  hyp [B][ld_h] i32 with hyp_lens; ref [B][ld_r] i64 with ref_lens (i32).
-// NJ = DP cells per lane: 64 * NJ >= the longest reference of the batch (a row costs NJ cell updates per lane whatever the
-// reference's length, so the 100-label references of a 10 s clip run with NJ = 2: 76 -> ~8 us per batch of 32)
+// NJ = DP cells per lane: 64 * NJ >= the longer of (hypothesis, reference) pitch of the batch (a row costs NJ cell updates per lane
+// whatever the actual length: 2048 cells per row for every batch cost 77 us at cfg2)
 // dist[b] = Levenshtein(hyp units, ref units), ref_units[b] = number of reference units.
 template <int NJ>
 __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __restrict__ hyp, const int32_t* __restrict__ hyp_lens, int64_t ld_h,
@@ -72,18 +73,24 @@ __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __rest
     s_n[1] = ed_units(nullptr, ref + (int64_t)b * ld_r, nr, space_id, s_b);
   }
   __syncthreads();
-  const int na = s_n[0], nb = s_n[1];
-  // lane owns reference positions j = lane*NJ + q + 1 (q < NJ): contiguous per lane, so the in-lane part of the scan is serial
+  // The distance is symmetric: the LONGER sequence goes onto the lanes (the row cost does not depend on it), the loop runs over the
+  // SHORTER one - an untrained model's greedy output is ~T' tokens against a 100-label reference: 501 dependent rows became 100.
+  const int n_ref = s_n[1];
+  const bool swap = s_n[0] > s_n[1];                       // wave-uniform
+  const unsigned long long* s_rows = swap ? s_b : s_a;
+  const unsigned long long* s_cols = swap ? s_a : s_b;
+  const int na = swap ? s_n[1] : s_n[0], nb = swap ? s_n[0] : s_n[1];
+  // lane owns column positions j = lane*NJ + q + 1 (q < NJ): contiguous per lane, so the in-lane part of the scan is serial
   unsigned long long bj[NJ];
   int prev[NJ];                // prev[q] = D[i-1][j]
 #pragma unroll
   for (int q = 0; q < NJ; ++q) {
     const int j = lane * NJ + q + 1;
-    bj[q] = j <= nb ? s_b[j - 1] : 0ull;
+    bj[q] = j <= nb ? s_cols[j - 1] : 0ull;
     prev[q] = j;                  // D[0][j] = j
   }
   for (int i = 1; i <= na; ++i) {
-    const unsigned long long ai = s_a[i - 1];
+    const unsigned long long ai = s_rows[i - 1];
     // D[i-1][j-1] for this lane's first cell comes from the previous lane's last cell (lane 0: D[i-1][0] = i-1)
     int left_prev = __shfl_up(prev[NJ - 1], 1, 64);
     if (lane == 0) left_prev = i - 1;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __rest
   }
   const int owner = nb > 0 ? (nb - 1) / NJ : 0;
   res = __shfl(res, owner, 64);
-  if (lane == 0) { dist[b] = res; ref_units[b] = nb; }
+  if (lane == 0) { dist[b] = res; ref_units[b] = n_ref; }
 }
 
 // totals[0] += sum dist, totals[1] += sum ref_units  (the Metric's `scores` / `words` states, utils/asr_metrics.py:114-115)
@@ -163,10 +170,11 @@ extern "C" int lasr_edit_distance_batch(const int32_t* hyp_tokens, const int32_t
   LASR_CHECK_SHAPE(ld_hyp <= kEdMaxUnits && ld_ref <= kEdMaxUnits, "lasr_edit_distance_batch: more than %d tokens per utterance",
                    kEdMaxUnits);
   hipStream_t st = as_stream(stream);
-  if (ld_ref <= 128)
+  const int64_t ld_cols = std::max(ld_hyp, ld_ref);        // either side may end up on the lanes
+  if (ld_cols <= 128)
     hipLaunchKernelGGL(edit_distance_kernel<2>, dim3((unsigned)B), dim3(64), 0, st, hyp_tokens, hyp_lens, ld_hyp, ref_tokens, ref_lens, ld_ref,
                        space_id, dist, ref_units);
-  else if (ld_ref <= 512)
+  else if (ld_cols <= 512)
     hipLaunchKernelGGL(edit_distance_kernel<8>, dim3((unsigned)B), dim3(64), 0, st, hyp_tokens, hyp_lens, ld_hyp, ref_tokens, ref_lens, ld_ref,
                        space_id, dist, ref_units);
   else
