@@ -489,3 +489,33 @@ def test_data_parallel_step_replays_from_a_graph_two_ranks(dev):
         assert np.array_equal(r[1][0], r[1][1]), "graph replay differs from eager on rank %d" % r[0]
     assert np.array_equal(res[0][1][0], res[1][1][0])            # and the replicas agree
     assert np.isfinite(res[0][1][0]).all()
+
+
+def test_staged_step_with_real_rccl_replays_from_a_graph_one_rank(dev, monkeypatch):
+    """the library's communicator over the REAL librccl (one rank) inside the capture: event fork to the side stream, ncclAllReduce
+    (grouped ranges), join before NovoGrad - replayed, the staged step lands bit for bit where the eager staged step lands"""
+    from lightning_asr_amd.comm import Communicator
+    from lightning_asr_amd.engine import NativeModel
+    from lightning_asr_amd.step import GraphedTrainStep, TrainStep
+    monkeypatch.setenv("LASR_FORCE_OVERLAP", "1")
+    monkeypatch.setenv("LASR_DP_BUCKETS", "4")
+    comm = Communicator.single(dev)
+    batches = [tuple(t.to(dev) for t in _batch(0, s)) for s in range(3)]
+    out = []
+    for mode in ("eager", "graph"):
+        m = NativeModel("plain", 28, mask=True, act="relu", dtype=torch.bfloat16, device=dev)
+        m.init_parameters(seed=6)
+        ts = TrainStep(m, 1e-2, 1e-3, comm=comm)
+        assert ts.force_staged and ts.comm is comm
+        if mode == "eager":
+            for wave, tg, tl in batches:
+                ts.step(wave, tg, tl)
+        else:
+            g = GraphedTrainStep(ts, B, L, S, prefetch=False)
+            g.capture(first_wave=batches[0][0])
+            for wave, tg, tl in batches:
+                g.step(wave, tg, tl)
+        torch.cuda.synchronize()
+        out.append(m.params.clone())
+    assert torch.equal(out[0], out[1])
+    comm.close()
