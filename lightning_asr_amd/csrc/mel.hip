@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) void mel_norm_kernel(const float* __restrict__
       double var = (q - n * mu * mu) / (n - 1.0);  // unbiased, torch.std_mean default
       if (var < 0) var = 0;
       s_mu = normalize ? (float)mu : 0.f;
-      s_rstd = normalize ? (float)(1.0 / sqrt(var)) : 1.f;
+      // (a constant spectrogram - an empty clip, which the reference's reflect pad refuses - normalises to zeros, not to 0/0)
+      s_rstd = normalize ? (var > 0 ? (float)(1.0 / sqrt(var)) : 0.f) : 1.f;
     }
   }
   __syncthreads();

@@ -59,6 +59,33 @@ def test_mel_matches_oracle(dev, kind):
         assert torch.equal(btf[b].t().contiguous().cpu(), bft[b].cpu())
 
 
+def test_mel_shortest_clips(dev):
+    """The shortest clips the reference can featurise: MelSpectrogram(pad=32, center=True, n_fft=512) reflect-pads 256 samples of a
+    (L + 64)-sample signal, which torch refuses below L = 193 (data_module.py:68-71,160).  From 193 samples on the kernel matches
+    the oracle; below (the reference raises) it still writes finite features for its 1 + (L + 64) // 160 frames and zeros behind
+    them, so that a stray empty file cannot poison a batch's BatchNorm statistics."""
+    from conftest import MEL_TOL
+    from lightning_asr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    lens_l = [193, 257, 520, 192, 1, 0]
+    L = 520
+    wave = 0.1 * torch.randn(len(lens_l), L, generator=g)
+    dither = torch.randn(len(lens_l), L, generator=g)
+    lens = torch.tensor(lens_l, dtype=torch.int32)
+    bft, btf, frames, pct = ops.mel(wave.to(dev), lens.to(dev), dither.to(dev), None, True)
+    T = ops.mel_num_frames(L)
+    for b, Lb in enumerate(lens_l):
+        Tb = R.num_frames(Lb)
+        assert int(frames[b]) == Tb and abs(float(pct[b]) - Tb / T) < 1e-7
+        assert torch.isfinite(bft[b]).all() and torch.all(bft[b, :, Tb:] == 0), Lb
+        if Lb >= 193:
+            ref64 = R.parse_wave(wave[b:b + 1, :Lb].double(), dither[b:b + 1, :Lb].double())
+            assert ref64.shape[2] == Tb
+            assert max_rel(bft[b, :, :Tb], ref64[0]) < MEL_TOL, (Lb, max_rel(bft[b, :, :Tb], ref64[0]))
+    with pytest.raises(RuntimeError):
+        R.parse_wave(wave[3:4, :192], dither[3:4, :192])
+
+
 def test_mel_db_and_specaugment(dev):
     from lightning_asr_amd import ops
     g = torch.Generator().manual_seed(5)

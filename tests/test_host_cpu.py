@@ -216,6 +216,72 @@ def test_native_wav_batch_reader_matches_python_wave(tmp_path):
         ingest.read_wav_batch([str(bad)], out, lens)
 
 
+def _riff(chunks):
+    """a RIFF/WAVE file from (tag, payload) chunks (odd payloads get the pad byte the format asks for)"""
+    import struct
+    body = b"WAVE"
+    for tag, payload in chunks:
+        body += tag + struct.pack("<I", len(payload)) + payload + (b"\0" if len(payload) & 1 else b"")
+    return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def test_native_wav_reader_header_variants(tmp_path):
+    """the header walk of lasr_wav_read_batch on the layouts real corpora contain: WAVE_FORMAT_EXTENSIBLE, chunks (odd-sized ones
+    too) between "fmt " and "data", a streamed file whose data size field overshoots the file, an empty clip; what it must refuse
+    (8-bit, float, another sample rate when one is demanded, a header cut short) it refuses with the file named"""
+    import struct
+    import numpy as np
+    import torch
+    from lightning_asr_amd import ingest
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-20000, 20000, size=3001, dtype=np.int16)
+    fmt_pcm = struct.pack("<HHIIHH", 1, 1, 16000, 32000, 2, 16)
+    guid_pcm = struct.pack("<H", 1) + bytes.fromhex("000000001000800000aa00389b71")
+    fmt_ext = struct.pack("<HHIIHHHHI", 0xFFFE, 1, 16000, 32000, 2, 16, 22, 16, 4) + guid_pcm
+    cases = {
+        "plain": _riff([(b"fmt ", fmt_pcm), (b"data", pcm.tobytes())]),
+        "extensible": _riff([(b"fmt ", fmt_ext), (b"data", pcm.tobytes())]),
+        "list_odd": _riff([(b"fmt ", fmt_pcm), (b"LIST", b"INFOabc"), (b"fact", struct.pack("<I", 3001)), (b"data", pcm.tobytes())]),
+    }
+    streamed = bytearray(cases["plain"])
+    streamed[40:44] = struct.pack("<I", 0xFFFFFFFF)                 # data size written before the length was known
+    cases["streamed"] = bytes(streamed)
+    paths = []
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".wav")
+        p.write_bytes(blob)
+        paths.append(str(p))
+    empty = tmp_path / "empty.wav"
+    empty.write_bytes(_riff([(b"fmt ", fmt_pcm), (b"data", b"")]))
+    paths.append(str(empty))
+    out = torch.full((len(paths) * 3008,), 7, dtype=torch.int16)
+    lens = torch.empty(len(paths), dtype=torch.int32)
+    ld = ingest.read_wav_batch(paths, out, lens, n_threads=2, expect_rate=16000)
+    assert ld == 3008 and lens.tolist() == [3001] * 4 + [0]
+    ref = torch.from_numpy(pcm.copy())
+    for i in range(4):
+        assert torch.equal(out[i * ld:i * ld + 3001], ref) and not out[i * ld + 3001:(i + 1) * ld].any()
+    assert not out[4 * ld:5 * ld].any()
+    assert ingest.wav_info(paths[1]) == (3001, 1, 16000, 16)
+    refused = {
+        "8-bit": (_riff([(b"fmt ", struct.pack("<HHIIHH", 1, 1, 16000, 16000, 1, 8)), (b"data", b"\x80" * 100)]), "16-bit"),
+        "float": (_riff([(b"fmt ", struct.pack("<HHIIHH", 3, 1, 16000, 64000, 4, 32)), (b"data", b"\0" * 400)]), "integer PCM"),
+        "cut": (cases["plain"][:30], "fmt|data"),
+        "no_data": (_riff([(b"fmt ", fmt_pcm), (b"LIST", b"INFO")]), "no data chunk"),
+    }
+    for name, (blob, msg) in refused.items():
+        p = tmp_path / (name + ".wav")
+        p.write_bytes(blob)
+        with pytest.raises(Exception, match=msg) as ei:
+            ingest.read_wav_batch([str(p)], out, lens)
+        assert name + ".wav" in str(ei.value)
+    p8k = tmp_path / "8k.wav"
+    p8k.write_bytes(_riff([(b"fmt ", struct.pack("<HHIIHH", 1, 1, 8000, 16000, 2, 16)), (b"data", pcm.tobytes())]))
+    with pytest.raises(Exception, match="sample rate"):
+        ingest.read_wav_batch([str(p8k)], out, lens, expect_rate=16000)
+    assert ingest.read_wav_batch([str(p8k)], out, lens) == 3008        # the default takes any rate, like the reference (data_module.py:153)
+
+
 def test_batch_producer_fills_ring_slots(tmp_path):
     """manifest -> BatchProducer -> HostBatch: PCM rows, lens, padded targets, SpecAugment rectangles, metadata layout"""
     import json
