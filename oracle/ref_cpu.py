@@ -305,7 +305,7 @@ def mask_lengths(T: int, pct: torch.Tensor) -> torch.Tensor:
 
 def _time_mask(x: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
     T = x.size(2)
-    keep = (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)
+    keep = (torch.arange(T, device=x.device).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(1)
     return x * keep.to(x.dtype)
 
 
@@ -574,7 +574,7 @@ def novograd_step(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor],
     for i, (p, g) in enumerate(zip(params, grads)):
         if st.exp_avg[i] is None:
             st.exp_avg[i] = torch.zeros_like(p)
-            st.exp_avg_sq[i] = torch.zeros((), dtype=p.dtype)
+            st.exp_avg_sq[i] = torch.zeros((), dtype=p.dtype, device=p.device)
         norm = g.norm().pow(2)
         v = st.exp_avg_sq[i]
         if v == 0:
