@@ -114,14 +114,15 @@ struct Vec<bf16_t> {
     o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
   }
   __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) { unpack(raw(p), o); }
-  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+  __device__ static __forceinline__ uint4 pack(const float (&o)[8]) {
     uint4 v;
     v.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
     v.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
     v.z = (uint32_t)f32_to_bf16(o[4]) | ((uint32_t)f32_to_bf16(o[5]) << 16);
     v.w = (uint32_t)f32_to_bf16(o[6]) | ((uint32_t)f32_to_bf16(o[7]) << 16);
-    *reinterpret_cast<uint4*>(p) = v;
+    return v;
   }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) { *reinterpret_cast<uint4*>(p) = pack(o); }
 };
 
 // out[i] = sum_p partials[p][i] for i < ncols, in a fixed order; i < split goes to out0, the rest to

@@ -4,6 +4,7 @@
 // autograd backward.  VALU work (0.13 of 2.5 GMAC/utterance); time tiles are staged through LDS
 // with their k-1 halo, channels ride the lanes so every global access is a full coalesced row.
 #include "common.h"
+#include "fused.h"
 
 namespace lasr {
 
@@ -477,6 +478,13 @@ static constexpr int WSM_OFF = IMG_BYTES + STAGE_BYTES;
 static constexpr int SMEM = WSM_OFF + kCB * WROW * 4;  // 144 384
 static_assert(LDI >= TIN * 2 && LDI % 16 == 0, "image pitch");
 }
+// FUSE (forward only): the layer's input is not read from HBM but made here - x = act(y a + b [+ y2 a2 + b2]), the BatchNorm +
+// residual add + activation of the unit BELOW (bn_act_fwd_kernel's arithmetic, operation for operation) - from that unit's y / y2
+// and BN coefficients while the tile is staged; the tile's own rows are written to `out` on the way (the residual 1x1 conv and the
+// backward read them), halo rows are recomputed by the neighbouring tile.  One launch and one 16 MB read per unit less.
+struct DwBnIn {
+  const bf16_t* y; const bf16_t* y2; const float* coef; const float* coef2; bf16_t* out; int act;
+};
 typedef __bf16 dw_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
 typedef short dw_s16x4 __attribute__((ext_vector_type(4)));
@@ -490,11 +498,11 @@ __device__ unsigned long long* g_dw_stamps = nullptr;   // debug builds only (to
 // NSET: 256-frame MFMA sets per time tile (2: one workgroup per 64 channels x 512 frames; 1: half tiles, twice the
 // workgroups - for layers whose C/64 x B grid would leave CUs idle); gridDim.z workgroups share an utterance's tiles.
 // (bx, by, bz) of (gx, B, gz): channel group, utterance, time-tile lane - the kernel's own grid or a slice of a fused grid
-template <int NKS, int NSET>
+template <int NKS, int NSET, bool FUSE = false>
 __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                     const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
                                                     int Tlen, int C, int k, int flip, int bx, int by, int bz, int gz,
-                                                    char* smem_raw) {
+                                                    char* smem_raw, const DwBnIn bn = DwBnIn{}) {
   using namespace dwm;
   char* img = smem_raw;                               // [64 channels][LDI]: frame tau at byte 2*tau
   char* stage = smem_raw + IMG_BYTES;                 // [RS frames][LDST]
@@ -525,8 +533,19 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
   }
   const int pad = k / 2, P = (pad + 7) & ~7, sh = P - pad;
   constexpr int KW = 32 * NKS;                        // = round-up-32(15 + k + sh) (host dispatch)
-  const bf16_t* xb = x + (size_t)b * Tlen * C;
+  const bf16_t* xb = FUSE ? nullptr : x + (size_t)b * Tlen * C;
   const int n16 = lane & 15, g4 = lane >> 4;          // MFMA lane coordinates
+  // FUSE: the BN coefficients of the thread's channel octet (tid & 7: the same in every chunk it stages)
+  float ca[8], cb[8], ca2[8], cb2[8];
+  if (FUSE) {
+    const int ccl = min(c0 + ((tid & 7) << 3), C - 8);
+    auto ld8 = [](const float* p, float (&o)[8]) {
+      const float4 u = *reinterpret_cast<const float4*>(p), q = *reinterpret_cast<const float4*>(p + 4);
+      o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = q.x; o[5] = q.y; o[6] = q.z; o[7] = q.w;
+    };
+    ld8(bn.coef + ccl, ca); ld8(bn.coef + C + ccl, cb);
+    if (bn.y2) { ld8(bn.coef2 + ccl, ca2); ld8(bn.coef2 + C + ccl, cb2); }
+  }
 
   DW_STAMP(0);
   constexpr int TTS = 256 * NSET;                     // output frames per time tile
@@ -536,18 +555,61 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
     // all global loads of the tile first (two 16-byte chunks per thread and round), then round by round
     constexpr int kRounds = (TTS - 16 + KWMAX + RS - 1) / RS;      // 5 (3 for half tiles)
     uint4 v[kRounds][2];
+    if (!FUSE) {
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
+      for (int r = 0; r < kRounds; ++r) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ch = tid + 512 * h;                 // chunk of the round: frame ch>>3, channel octet ch&7
-        const int tau = r * RS + (ch >> 3);
-        const int t = tA - P + tau;
-        const int cc = c0 + ((ch & 7) << 3);
-        const bool ok = tau < tin && t >= 0 && t < Tlen && cc < C;
-        const uint4 ld = *reinterpret_cast<const uint4*>(xb + (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8));
-        const uint32_t mk = ok ? 0xffffffffu : 0u;
-        v[r][h] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
+        for (int h = 0; h < 2; ++h) {
+          const int ch = tid + 512 * h;                 // chunk of the round: frame ch>>3, channel octet ch&7
+          const int tau = r * RS + (ch >> 3);
+          const int t = tA - P + tau;
+          const int cc = c0 + ((ch & 7) << 3);
+          const bool ok = tau < tin && t >= 0 && t < Tlen && cc < C;
+          const uint4 ld = *reinterpret_cast<const uint4*>(xb + (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8));
+          const uint32_t mk = ok ? 0xffffffffu : 0u;
+          v[r][h] = make_uint4(ld.x & mk, ld.y & mk, ld.z & mk, ld.w & mk);
+        }
+      }
+    } else {
+      // the same chunks of y (and y2) of the unit below; x is made from them in issue order, the tile's own frames leave for `out`
+      uint4 ly[kRounds][2], lr[kRounds][2];
+      const size_t ub = (size_t)b * Tlen * C;
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ch = tid + 512 * h;
+          const int t = tA - P + r * RS + (ch >> 3);
+          const size_t off = ub + (size_t)min(max(t, 0), Tlen - 1) * C + min(c0 + ((ch & 7) << 3), C - 8);
+          ly[r][h] = Vec<bf16_t>::raw(bn.y + off);
+          if (bn.y2) lr[r][h] = Vec<bf16_t>::raw(bn.y2 + off);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRounds; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ch = tid + 512 * h;
+          const int tau = r * RS + (ch >> 3);
+          const int t = tA - P + tau;
+          const int cc = c0 + ((ch & 7) << 3);
+          const bool ok = tau < tin && t >= 0 && t < Tlen && cc < C;
+          float yv[8], rv[8], o[8];
+          Vec<bf16_t>::unpack(ly[r][h], yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = fmaf(yv[j], ca[j], cb[j]);
+          if (bn.y2) {                                  // workgroup-uniform
+            Vec<bf16_t>::unpack(lr[r][h], rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += fmaf(rv[j], ca2[j], cb2[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = act_fwd(o[j], bn.act);
+          const uint4 pk = Vec<bf16_t>::pack(o);
+          if (ok && t >= tA && t < tA + TTS) *reinterpret_cast<uint4*>(bn.out + ub + (size_t)t * C + cc) = pk;
+          const uint32_t mk = ok ? 0xffffffffu : 0u;
+          v[r][h] = make_uint4(pk.x & mk, pk.y & mk, pk.z & mk, pk.w & mk);
+        }
       }
     }
     // the addend of the data gradient (same [frame][channel] tile as the output) is requested now, behind the tile's own
@@ -691,6 +753,14 @@ __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __
                                                                 int Tlen, int C, int k, int flip) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   dwconv_s1_mfma_body<NKS, NSET>(x, w, addend, y, Tlen, C, k, flip, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw);
+}
+
+// forward with the BN + add + activation of the unit below made in the staging loop (DwBnIn)
+template <int NKS, int NSET>
+__global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_bn_kernel(DwBnIn bn, const float* __restrict__ w, bf16_t* __restrict__ y, int Tlen,
+                                                                   int C, int k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  dwconv_s1_mfma_body<NKS, NSET, true>(nullptr, w, nullptr, y, Tlen, C, k, 0, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw, bn);
 }
 
 // Weight gradient, stride 1.  Lane = 4 channels x 8 consecutive taps (group jg) x one time split;
@@ -1332,6 +1402,41 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
   }
   prof_end(tok, as_stream(stream));
   LASR_LAUNCH_CHECK("dwconv_fwd_kernel");
+  return 0;
+}
+
+int lasr::dwconv_fwd_bn(const void* y, const float* coef, const void* y2, const float* coef2, int act, const float* w, void* out, void* u,
+                        int64_t B, int64_t T, int64_t C, int k, void* stream) {
+  LASR_CHECK_ARG(y && coef && w && out && u && (!y2 || coef2), "dwconv_fwd_bn: null pointer");
+  static const bool off = getenv("LASR_DWCONV_FMA") || getenv("LASR_DWCONV_DOT2");
+  const int padk = k / 2, shk = ((padk + 7) & ~7) - padk;
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  if (off || k < 1 || k > kMaxK || !(k & 1) || C % 8 != 0 || C < 8 || 15 + k + shk > dwm::KWMAX || T <= 0 || T >= (1 << 30) || B <= 0 ||
+      B >= 65536 || !al16(y) || !al16(y2) || !al16(out) || !al16(u) || !al16(coef) || !al16(coef2))
+    return 1;
+  const int nks = (15 + k + shk + 31) / 32;
+  static const bool no_half = getenv("LASR_DWCONV_NO_HALF") != nullptr;
+  const bool half = !no_half && T > 256 && cdiv(C, kCB) * B * cdiv(T, (int64_t)512) < 200;     // (the grid of lasr_dwconv_fwd)
+  // Full 512-frame tiles are one workgroup per CU in ONE round, every workgroup in the same phase at the same time: the second
+  // input and the extra output are pure added HBM time there (measured at C = 512: 21.6 us against 13.7 + 7.6 for the two
+  // launches, and the GEMM behind it starts into twice the write-back).  Half tiles run two staggered rounds: 13.2 against 9.5 + 7.6.
+  static const bool full_too = getenv("LASR_BN_DW_FUSE") && atoi(getenv("LASR_BN_DW_FUSE")) == 2;
+  if (!half && !full_too) return 1;
+  const dim3 gridm((unsigned)cdiv(C, kCB), (unsigned)B, half ? (unsigned)std::min<int64_t>(cdiv(T, (int64_t)256), 8) : 1u);
+  DwBnIn bn;
+  bn.y = (const bf16_t*)y; bn.y2 = (const bf16_t*)y2; bn.coef = coef; bn.coef2 = coef2; bn.out = (bf16_t*)out; bn.act = act;
+  const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 2.0 * (double)B * T * C * k, (double)B * T * C * (y2 ? 4 : 3) * 2);
+#define LASR_DWMB2(N_, S_)                                                                                                  \
+  do {                                                                                                                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_mfma_bn_kernel<N_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((dwconv_s1_mfma_bn_kernel<N_, S_>), gridm, dim3(512), dwm::SMEM, as_stream(stream), bn, w, (bf16_t*)u, (int)T, (int)C, k); \
+  } while (0)
+#define LASR_DWMB(N_) do { if (half) LASR_DWMB2(N_, 1); else LASR_DWMB2(N_, 2); } while (0)
+  if (nks == 1) LASR_DWMB(1); else if (nks == 2) LASR_DWMB(2); else if (nks == 3) LASR_DWMB(3); else LASR_DWMB(4);
+#undef LASR_DWMB
+#undef LASR_DWMB2
+  prof_end(tok, as_stream(stream));
+  LASR_LAUNCH_CHECK("dwconv_s1_mfma_bn_kernel");
   return 0;
 }
 

@@ -4,6 +4,7 @@
 // the whole step can be captured into a hipGraph by the host.
 #include "common.h"
 #include "mel.h"
+#include "fused.h"
 #include <string>
 #include <vector>
 #include <math.h>
@@ -511,7 +512,23 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
   }
   const void* x = feats;
   int64_t Tx = T_in;
-  for (const Unit& u : m->units) {
+  // The BatchNorm + add + activation pass of a plain / residual unit is made by the depthwise launch of the unit above it (fused.h):
+  // `pend` is the unit whose pass is still owed.  LASR_BN_DW_FUSE=0: always its own launch (A/B runs; the results are bit-identical).
+  static const bool bn_dw_fuse = !(getenv("LASR_BN_DW_FUSE") && atoi(getenv("LASR_BN_DW_FUSE")) == 0);
+  const Unit* pend = nullptr;
+  auto bn_act_of = [&](const Unit& v) -> int {
+    ProfScope ps_bn(LASR_PROF_BN, stream, (double)N * v.co * dtype_size(dt) * (v.has_res ? 3 : 2));
+    const lasr_dropout drop = {m->drop_step, m->drop_seed, (uint32_t)(&v - m->units.data()), dropping ? m->drop_p : 0.f};
+    return lasr_bn_act_fwd_drop(at(ws, v.o_y), atf(ws, v.o_coef), v.has_res ? at(ws, v.o_y2) : nullptr,
+                                v.has_res ? atf(ws, v.o_coef2) : nullptr, v.has_se ? atf(ws, v.o_se_scale) : nullptr, at(ws, v.o_out), dt, B,
+                                T, v.co, v.act ? m->cfg.act : LASR_ACT_NONE, dropping ? &drop : nullptr, stream);
+  };
+  for (size_t ui = 0; ui < m->units.size(); ++ui) {
+    const Unit& u = m->units[ui];
+    if (pend && !(u.has_dw && u.stride == 1 && !u.ctx_before)) {   // (not reached: the hand-over is only arranged for such a unit)
+      LASR_TRY(bn_act_of(*pend));
+      pend = nullptr;
+    }
     if (u.ctx_before) {
       // context branch: gates' input projection as two GEMMs (f32 out), the recurrence, then cat(x, lstm) -> [N][336]
       for (int d = 0; d < 2; ++d)
@@ -525,7 +542,16 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
     }
     const void* gin = x;
     if (u.has_dw) {
-      LASR_TRY(lasr_dwconv_fwd(x, params + u.w_dw, nullptr, at(ws, u.o_u), dt, B, Tx, u.ci, u.k, u.stride, 0, stream));
+      int fused = 1;
+      if (pend) {
+        fused = dwconv_fwd_bn(at(ws, pend->o_y), atf(ws, pend->o_coef), pend->has_res ? at(ws, pend->o_y2) : nullptr,
+                              pend->has_res ? atf(ws, pend->o_coef2) : nullptr, pend->act ? m->cfg.act : LASR_ACT_NONE, params + u.w_dw,
+                              at(ws, pend->o_out), at(ws, u.o_u), B, T, u.ci, u.k, stream);
+        if (fused < 0) return fused;
+        if (fused == 1) LASR_TRY(bn_act_of(*pend));     // a shape without the fused kernel: the two launches
+        pend = nullptr;
+      }
+      if (fused == 1) LASR_TRY(lasr_dwconv_fwd(x, params + u.w_dw, nullptr, at(ws, u.o_u), dt, B, Tx, u.ci, u.k, u.stride, 0, stream));
       gin = at(ws, u.o_u);
     }
     if (!training && eval_fold(dt) && fold_unit(u)) {
@@ -569,19 +595,24 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
         }
       }
     }
-    ProfScope ps_bn(LASR_PROF_BN, stream, (double)N * u.co * dtype_size(dt) * (u.has_res ? 3 : 2) + (u.has_se ? (double)N * u.co * dtype_size(dt) : 0.0));
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
+      ProfScope ps_se(LASR_PROF_BN, stream, (double)N * u.co * dtype_size(dt));
       LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
       LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
                            atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), stream));
     }
-    const lasr_dropout drop = {m->drop_step, m->drop_seed, (uint32_t)(&u - m->units.data()), dropping ? m->drop_p : 0.f};
-    LASR_TRY(lasr_bn_act_fwd_drop(at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr,
-                                  u.has_res ? atf(ws, u.o_coef2) : nullptr, u.has_se ? atf(ws, u.o_se_scale) : nullptr, at(ws, u.o_out), dt, B,
-                                  T, u.co, u.act ? m->cfg.act : LASR_ACT_NONE, dropping ? &drop : nullptr, stream));
+    // BN + residual add + activation: by the next unit's depthwise launch when that is a stride-1 bf16 depthwise conv reading this
+    // unit's output directly (training; no SE scale, no dropout mask in between), otherwise here
+    const Unit* nx = ui + 1 < m->units.size() ? &m->units[ui + 1] : nullptr;
+    if (bn_dw_fuse && training && !no_fuse() && dt == LASR_BF16 && !u.has_se && !dropping && nx && nx->has_dw && nx->stride == 1 &&
+        !nx->ctx_before && nx->ci == u.co)
+      pend = &u;
+    else
+      LASR_TRY(bn_act_of(u));
     x = at(ws, u.o_out);
     Tx = T;
   }
+  if (pend) LASR_TRY(bn_act_of(*pend));   // (not reached: the last unit has no unit above it)
   // decoder 1x1 1024 -> C with bias (models/QuartNet.py:275), f32 logits, then log_softmax (+argmax)
   const int64_t C = m->cfg.n_class;
   // a narrow vocabulary leaves N/128 = 1 tile column: split K so that the 32 MB of activations are streamed by

@@ -22,6 +22,7 @@ SWITCHES = [
     {"LASR_WGRAD_SMALL_TILE": "1"}, {"LASR_NO_GEMM_BATCH": "1"}, {"LASR_GEMM_BIG_MIN_TILES": "100000"},   # 128 x 128 GEMM forms
     {"LASR_NO_MEL_CTC": "1"}, {"LASR_CTC_NO_LDS": "1"},   # separate lattice / feature launches; emissions through the register ring
     {"LASR_NO_EVAL_FOLD": "1"},
+    {"LASR_BN_DW_FUSE": "0"},                       # BN + add + activation as its own launch instead of inside the next depthwise forward
 ]
 
 
@@ -49,6 +50,12 @@ def test_kernel_switches_agree_with_the_default_paths(dev):
     assert base["loss"] > 0 and all(v > 0 for v in base["grad_norm"].values())
     for env in SWITCHES[1:]:
         _close(_run(env), base, env)
+
+
+def test_bn_inside_the_depthwise_forward_is_bit_identical(dev):
+    """the BatchNorm + residual add + ReLU of a unit made in the staging loop of the next unit's depthwise forward (csrc/fused.h)
+    performs bn_act_fwd_kernel's arithmetic operation for operation: loss, gradient norms and eval log-probs are the SAME numbers"""
+    assert _run({}) == _run({"LASR_BN_DW_FUSE": "0"})
 
 
 def test_large_vocabulary_head_switch(dev):
