@@ -636,8 +636,10 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
 
 // SE: the constants come folded from the excite backward (tab_in [10][C], se_bwd_pool_kernel); d1 = d*se + seg with the
 // utterance's scale and pooled-path gradient as register constants (a chunk is one utterance).
-template <bool HAS2, bool SE>
-__global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+// RB: rows in flight per thread; WPE: waves per SIMD the register allocation must leave room for (2 = one 512-thread workgroup per
+// CU, 4 = two).
+template <bool HAS2, bool SE, int RB = 2, int WPE = 2>
+__global__ __launch_bounds__(512, WPE) void bn_bwd_apply_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                   const bf16_t* __restrict__ y2, const float* __restrict__ partials,
                                                                   int nchunk, const float* __restrict__ tab_in, const float* __restrict__ se,
                                                                   const float* __restrict__ seg, const float* __restrict__ coef,
@@ -701,18 +703,18 @@ __global__ __launch_bounds__(512) void bn_bwd_apply_sliced_kernel(const bf16_t* 
   const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, rows);
   float sev[V], sgv[V];
   if (SE) { lds_vec8(se + (size_t)blockIdx.y * C + c, sev); lds_vec8(seg + (size_t)blockIdx.y * C + c, sgv); }
-  for (int rb = r0 + rl; rb < r1; rb += 2 * kSlLanes) {
-    uint4 rd[2], ry[2], rr2[2];
-    uint32_t off[2];
+  for (int rb = r0 + rl; rb < r1; rb += RB * kSlLanes) {
+    uint4 rd[RB], ry[RB], rr2[RB];
+    uint32_t off[RB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
       off[u] = (uint32_t)min(rb + u * kSlLanes, rows - 1) * (uint32_t)C + (uint32_t)c;
       rd[u] = Vec<bf16_t>::raw(dout + off[u]);
       ry[u] = Vec<bf16_t>::raw(y + off[u]);
       if (HAS2) rr2[u] = Vec<bf16_t>::raw(y2 + off[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < RB; ++u) {
       const int r = rb + u * kSlLanes;
       const bool live = r < r1;
       const int rc = min(r, rows - 1);
@@ -1021,15 +1023,28 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
   if (const int rpc = bn_sliced_rpc(dtype, rows, C, se_scale != nullptr, da.step != nullptr, 0, sums != nullptr)) {
     if (workspace_bytes < lasr_bn_bwd_workspace_bytes(B, T_, C)) return fail(LASR_E_WORKSPACE, "lasr_bn_act_bwd_apply: workspace");
     LASR_CHECK_ARG(dgamma && dbeta && (!y2 || (dgamma2 && dbeta2)), "lasr_bn_act_bwd_apply: parameter-gradient pointers");
-    const int nchunk = (int)cdiv(rows, rpc);
-    const dim3 grid((unsigned)(C / kSlCh), (unsigned)nchunk);
+    const int nchunk = (int)cdiv(rows, rpc);          // partial rows of the statistics pass
     const float* partials = reinterpret_cast<const float*>(workspace);
-    if (y2) hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<true, false>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
-                               partials, nchunk, nullptr, nullptr, nullptr, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
-                               dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, act, rpc);
-    else hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<false, false>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)y2,
-                            partials, nchunk, nullptr, nullptr, nullptr, coef, saved, gamma, coef2, saved2, gamma2, 1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2,
-                            dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, act, rpc);
+    // The apply pass takes row chunks HALF as long as the statistics pass (LASR_BN_APPLY_SPLIT = 2; 1: the same chunks): 512
+    // workgroups with one row in flight per thread in 121 registers, so two are resident per CU and their load, arithmetic and
+    // store phases interleave - against one round of 256 workgroups that are all in the same phase at the same time.  Measured in
+    // the cfg2 step, one call: split 1 / 2 / 3 / 4 = 2.228 / 2.191 / 2.220 / 2.235 ms.  (The statistics pass does not gain from the
+    // same treatment: 2.219 with both split against 2.198.)  The arithmetic per element is unchanged.
+    static const int asplit = getenv("LASR_BN_APPLY_SPLIT") ? atoi(getenv("LASR_BN_APPLY_SPLIT")) : 2;
+#define LASR_APPLY_SL(H2_, RB_, W_, RPC_, G_)                                                                                          \
+  hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<H2_, false, RB_, W_>), G_, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, \
+                     (const bf16_t*)y2, partials, nchunk, nullptr, nullptr, nullptr, coef, saved, gamma, coef2, saved2, gamma2,          \
+                     1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2, dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, \
+                     act, RPC_)
+    const int rpc2 = asplit > 1 ? (int)cdiv(rows, (int64_t)nchunk * asplit) : rpc;
+    if (asplit > 1 && rpc2 >= kSlLanes) {
+      const dim3 grid2((unsigned)(C / kSlCh), (unsigned)cdiv(rows, rpc2));
+      if (y2) LASR_APPLY_SL(true, 1, 4, rpc2, grid2); else LASR_APPLY_SL(false, 1, 4, rpc2, grid2);
+    } else {
+      const dim3 grid((unsigned)(C / kSlCh), (unsigned)nchunk);
+      if (y2) LASR_APPLY_SL(true, 2, 2, rpc, grid); else LASR_APPLY_SL(false, 2, 2, rpc, grid);
+    }
+#undef LASR_APPLY_SL
     LASR_LAUNCH_CHECK("bn_bwd_apply_sliced_kernel");
     return 0;
   }
@@ -1122,6 +1137,8 @@ extern "C" int lasr_bn_se_bwd(const void* dout, const void* y, const float* coef
     bn.coef = coef; bn.saved = saved; bn.coef2 = y2 ? coef2 : nullptr; bn.saved2 = saved2; bn.gamma2 = gamma2;
     bn.inv_n = 1.0f / (float)(B * T_); bn.tab = tab; bn.dgamma = dgamma; bn.dbeta = dbeta; bn.dgamma2 = dgamma2; bn.dbeta2 = dbeta2;
     LASR_TRY(launch_se_bwd(nullptr, &bn, se_scale, se_hidden, se_pooled, W1, W2, B, T_, C, seg_out, dW1, dW2, se_work, st));
+    // (the apply pass stays on whole-utterance chunks here: the half-utterance form of lasr_bn_act_bwd_apply_drop needs the SE
+    //  constants in 128 registers, spills 9 of them and measured 3.80 against 3.78 ms per cfg4 step)
     if (y2) hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<true, true>), grid, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y,
                                (const bf16_t*)y2, nullptr, 0, tab, se_scale, seg_out, coef, saved, gamma, coef2, saved2, gamma2, 0.f, row_lens,
                                (bf16_t*)dy, (bf16_t*)dy2, dgamma, dbeta, dgamma2, dbeta2, (int)(B * T_), (int)T_, (int)C, act, (int)T_);

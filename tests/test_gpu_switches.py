@@ -23,6 +23,8 @@ SWITCHES = [
     {"LASR_NO_MEL_CTC": "1"}, {"LASR_CTC_NO_LDS": "1"},   # separate lattice / feature launches; emissions through the register ring
     {"LASR_NO_EVAL_FOLD": "1"},
     {"LASR_BN_DW_FUSE": "0"},                       # BN + add + activation as its own launch instead of inside the next depthwise forward
+    {"LASR_BN_DW_FUSE": "2"},                       # ... inside every stride-1 depthwise forward, full tiles too
+    {"LASR_BN_APPLY_SPLIT": "1"},                   # BN backward apply pass on the statistics pass's chunks (one workgroup per CU)
 ]
 
 
