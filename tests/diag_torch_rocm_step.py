@@ -26,12 +26,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--variant", default="plain")
+    ap.add_argument("--n-vocab", type=int, default=27, help="labels (the blank is added): 27 = labels.txt, 4333 = the AISHELL vocabulary")
+    ap.add_argument("--clip-s", type=float, default=10.0)
     ap.add_argument("--no-tune", action="store_true", help="MIOpen immediate mode instead of its kernel search (minutes per dtype)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    B, clip_s, V = 32, 10.0, 27
+    B, clip_s, V = 32, a.clip_s, a.n_vocab
     torch.manual_seed(0)
-    wave, tg, tl = R.synth_batch(B, int(clip_s * 16000), 100, V, 1234)
+    wave, tg, tl = R.synth_batch(B, int(clip_s * 16000), int(10 * clip_s) if V == 27 else int(2.8 * clip_s), V, 1234)
     feats = torch.stack([R.parse_wave(wave[i:i + 1])[0] for i in range(B)]).unsqueeze(1).to(dev)
     pct, tg, tl = torch.ones(B, device=dev), tg.to(dev), tl.to(dev)
     state = {k: v.to(dev) for k, v in R.random_state(a.variant, V + 1, 0).items()}
@@ -72,7 +74,7 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / a.steps * 1e3
     print(json.dumps({"yardstick": "oracle (plain PyTorch restatement of the reference) on cuda through PyTorch-ROCm eager",
-                      "variant": a.variant, "autocast": a.dtype, "B": B, "clip_s": clip_s, "ms_per_step": round(ms, 3),
+                      "variant": a.variant, "n_class": V + 1, "autocast": a.dtype, "B": B, "clip_s": clip_s, "ms_per_step": round(ms, 3),
                       "audio_s_per_s": round(B * clip_s / (ms * 1e-3), 1), "loss": float(loss.detach()), "miopen_search": not a.no_tune, "torch": torch.__version__,
                       "device": torch.cuda.get_device_name(0)}))
 
