@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define LASR_VERSION 101   /* 101: lasr_mel_fwd_src / lasr_wav_read_batch / lasr_step_metrics / lasr_model_set_prefetch_src */
+#define LASR_VERSION 102   /* 101: lasr_mel_fwd_src / lasr_wav_read_batch / lasr_step_metrics / lasr_model_set_prefetch_src
+                              102: LASR_LEN_LEAD (crop after pre-emphasis), lasr_wav_read_batch(lead_in), lasr_train_tail, lasr_comm_* timing */
 
 enum { LASR_F32 = 0, LASR_BF16 = 1 };
 enum { LASR_ACT_NONE = 0, LASR_ACT_RELU = 1, LASR_ACT_SWISH = 2 };
@@ -68,6 +69,12 @@ int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dit
  *   both NULL: no dither.
  * lasr_dither_noise writes the noise a call with the same (seed, *step) uses: out (B, L) f32 (verification; the counter is
  * left untouched).                                                                                                   */
+/* Crop AFTER dither + pre-emphasis (data_module.py:155-159: `y += noise; y = cat(y[0], y[1:] - 0.97 y[:-1]); y = sub_secquence(y)`):
+ * the first sample of a crop that starts at file sample loc > 0 is y[loc] - 0.97 y[loc-1], not y[loc].  A caller that crops the RAW
+ * waveform hands the sample before the crop over as a lead-in: row b = [x[loc-1], x[loc], ..., x[loc+n-1]] and
+ * sample_lens[b] = n | LASR_LEN_LEAD.  The lead-in sample is dithered like every other sample (explicit noise: the row's first noise
+ * value; generated noise: the row's first counter) and produces no output sample of its own.  n + 1 <= L.                     */
+#define LASR_LEN_LEAD (1 << 30)
 enum { LASR_WAVE_F32 = 0, LASR_WAVE_PCM16 = 1 };
 typedef struct {
   const void* wave; int32_t wave_dtype; const float* dither; uint64_t dither_seed; uint64_t* dither_step;
@@ -525,8 +532,10 @@ int lasr_step_metrics(const float* loss, const int32_t* dist, const int32_t* ref
  * - the reference's sub_secquence, slice end included as it is there.  expect_rate > 0: fail on another sample rate.
  * No device work; returns LASR_E_WORKSPACE when n * ld exceeds out_capacity (elements).                                 */
 int lasr_wav_info(const char* path, int64_t* n_frames, int32_t* n_channels, int32_t* sample_rate, int32_t* bits);
+/* lead_in != 0: a crop that does not begin at the file's first sample is preceded in its row by the sample before it and its
+ *   lens_out entry carries LASR_LEN_LEAD (see above: the reference crops AFTER pre-emphasis); the pitch counts the lead-in. */
 int lasr_wav_read_batch(const char* const* paths, int64_t n, const double* crop_u, double crop_weight, int16_t* out,
-                        int64_t out_capacity, int64_t* ld_out, int32_t* lens_out, int32_t expect_rate, int n_threads);
+                        int64_t out_capacity, int64_t* ld_out, int32_t* lens_out, int32_t expect_rate, int n_threads, int lead_in);
 
 /* ---- data-parallel gradient exchange: RCCL over xGMI, called by the library itself ------------------------------
  * Replaces the NCCL all-reduce the reference gets from Lightning's DDP plugin (conf/conf.yaml:30-31 `accelerator: ddp`,

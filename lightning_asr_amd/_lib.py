@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("LASR_LIB_PATH", os.path.join(_HERE, "liblasr.so"))   
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+LEN_LEAD = 1 << 30          # LASR_LEN_LEAD: a row of samples that starts with one lead-in sample (crop after pre-emphasis)
 VARIANT = {"plain": 0, "context": 1, "context_se": 2}
 
 _p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
@@ -135,7 +136,7 @@ SIGNATURES = {
     "lasr_edit_distance_batch": (_i32, [_p, _p, _i64, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
     "lasr_step_metrics": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "lasr_wav_info": (_i32, [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "lasr_wav_read_batch": (_i32, [_p, _i64, _p, C.c_double, _p, _i64, C.POINTER(_i64), _p, C.c_int32, _i32]),
+    "lasr_wav_read_batch": (_i32, [_p, _i64, _p, C.c_double, _p, _i64, C.POINTER(_i64), _p, C.c_int32, _i32, _i32]),
     "lasr_comm_unique_id": (_i32, [_p, _sz]),
     "lasr_comm_init": (_i32, [C.POINTER(_p), _p, _sz, _i32, _i32, _i32]),
     "lasr_comm_destroy": (_i32, [_p]),

@@ -65,6 +65,7 @@ struct Job {
   int fd = -1;
   WavInfo w;
   int64_t first = 0, count = 0;    // slice of the file this batch takes
+  int lead = 0;                    // 1: the row starts with file sample first - 1 (LASR_LEN_LEAD)
   std::string err;
 };
 
@@ -108,7 +109,8 @@ extern "C" int lasr_wav_info(const char* path, int64_t* n_frames, int32_t* n_cha
 }
 
 extern "C" int lasr_wav_read_batch(const char* const* paths, int64_t n, const double* crop_u, double crop_weight, int16_t* out,
-                                   int64_t out_capacity, int64_t* ld_out, int32_t* lens_out, int32_t expect_rate, int n_threads) {
+                                   int64_t out_capacity, int64_t* ld_out, int32_t* lens_out, int32_t expect_rate, int n_threads,
+                                   int lead_in) {
   LASR_CHECK_ARG(paths && n > 0 && out && ld_out && lens_out && out_capacity > 0, "lasr_wav_read_batch: bad argument");
   std::vector<Job> jobs((size_t)n);
   // pass 1: headers -> the slice every file contributes
@@ -119,10 +121,12 @@ extern "C" int lasr_wav_read_batch(const char* const* paths, int64_t n, const do
     if (expect_rate > 0 && j.w.rate != expect_rate) { j.err = std::string("unexpected sample rate in ") + paths[i]; return; }
     j.first = 0; j.count = j.w.n_frames;
     if (crop_u) crop_slice(j.w.n_frames, crop_u + 2 * i, crop_weight, &j.first, &j.count);
+    j.lead = (lead_in && j.first > 0 && j.count > 0) ? 1 : 0;
+    if (j.count + j.lead >= LASR_LEN_LEAD) j.err = std::string("too long: ") + paths[i];
   });
   int64_t lmax = 0;
   const Job* bad = nullptr;
-  for (const Job& j : jobs) { if (!j.err.empty() && !bad) bad = &j; lmax = std::max(lmax, j.count); }
+  for (const Job& j : jobs) { if (!j.err.empty() && !bad) bad = &j; lmax = std::max(lmax, j.count + j.lead); }
   const int64_t ld = (std::max<int64_t>(lmax, 2) + 7) / 8 * 8;      // rows stay 16-byte aligned
   if (!bad && n * ld > out_capacity) {
     for (Job& j : jobs) if (j.fd >= 0) close(j.fd);
@@ -140,28 +144,29 @@ extern "C" int lasr_wav_read_batch(const char* const* paths, int64_t n, const do
     int16_t* row = out + i * ld;
     const int ch = j.w.channels;
     int64_t got = 0;
+    const int64_t first = j.first - j.lead, count = j.count + j.lead;    // the row: [lead-in sample] + the slice
     if (ch == 1) {
-      const int64_t want = j.count * 2;
+      const int64_t want = count * 2;
       int64_t done = 0;
       while (done < want) {
-        const ssize_t r = pread(j.fd, reinterpret_cast<char*>(row) + done, (size_t)(want - done), j.w.data_off + j.first * 2 + done);
+        const ssize_t r = pread(j.fd, reinterpret_cast<char*>(row) + done, (size_t)(want - done), j.w.data_off + first * 2 + done);
         if (r <= 0) break;
         done += r;
       }
       got = done / 2;
     } else {   // interleaved: keep channel 0 (the reference feeds row 0 of torchaudio.load's (channels, L) result)
       std::vector<int16_t> tmp((size_t)4096 * ch);
-      while (got < j.count) {
-        const int64_t fr = std::min<int64_t>(4096, j.count - got);
-        const ssize_t r = pread(j.fd, tmp.data(), (size_t)(fr * ch * 2), j.w.data_off + (j.first + got) * ch * 2);
+      while (got < count) {
+        const int64_t fr = std::min<int64_t>(4096, count - got);
+        const ssize_t r = pread(j.fd, tmp.data(), (size_t)(fr * ch * 2), j.w.data_off + (first + got) * ch * 2);
         if (r < (ssize_t)(fr * ch * 2)) break;
         for (int64_t t = 0; t < fr; ++t) row[got + t] = tmp[(size_t)(t * ch)];
         got += fr;
       }
     }
-    if (got < j.count) j.err = std::string("short read: ") + paths[i];
+    if (got < count) j.err = std::string("short read: ") + paths[i];
     memset(row + got, 0, (size_t)(ld - got) * sizeof(int16_t));
-    lens_out[i] = (int32_t)j.count;
+    lens_out[i] = (int32_t)j.count | (j.lead ? LASR_LEN_LEAD : 0);
     close(j.fd);
     j.fd = -1;
   });

@@ -159,7 +159,12 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
 
   const int b = by;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t Lb = sample_lens ? (int64_t)sample_lens[b] : L;
+  // sample_lens[b]: valid samples; bit LASR_LEN_LEAD set = the row starts with ONE lead-in sample x[-1] in front of them (a crop
+  // that does not begin at the file's first sample: the reference pre-emphasises BEFORE it crops, data_module.py:157-159, so the
+  // crop's first sample is y[loc] - 0.97 y[loc-1], dither of both included)
+  const int32_t lw = sample_lens ? sample_lens[b] : 0;
+  const int off = (lw >> 30) & 1;
+  const int64_t Lb = sample_lens ? (int64_t)(lw & (LASR_LEN_LEAD - 1)) : L;
   const int64_t Lp = Lb + 2 * kPad;
   const int64_t Tb = 1 + Lp / kHop;
   const float* y = reinterpret_cast<const float*>(src.wave) + (int64_t)b * L;
@@ -213,8 +218,8 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
       i = i >= Lp ? 2 * (Lp - 1) - i : i;
       const int64_t j = i - kPad;                           // index into the utterance
       const int64_t jmax = max(Lb - 1, (int64_t)0);
-      jcs[u] = min(max(j, (int64_t)0), jmax);
-      jps[u] = min(max(j - 1, (int64_t)0), jmax);
+      jcs[u] = min(max(j, (int64_t)0), jmax) + off;                 // row indices: the signal sits `off` samples into the row
+      jps[u] = min(max(j - 1 + off, (int64_t)0), jmax + off);
     }
     if (src.pcm16) {   // 16-bit PCM as stored in the wav file: /32768 is exact in f32 (what torchaudio.load's normalisation yields)
       int16_t c16[kSigIt], p16[kSigIt];
@@ -250,7 +255,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
       // f32 steps, as the reference computes them (data_module.py:155,157)
       float c = cur[u], p = prv[u];
       if (noisy) { c += 1e-5f * ncur[u]; p += 1e-5f * nprv[u]; }
-      const float v = j == 0 ? c : c - 0.97f * p;
+      const float v = (j == 0 && !off) ? c : c - 0.97f * p;
       s_sig[threadIdx.x + 256 * u] = (j < 0 || j >= Lb || i < 0) ? 0.f : v;
     }
   }

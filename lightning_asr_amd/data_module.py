@@ -19,18 +19,33 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader, Dataset
 
-from . import ops
+from . import _lib, ops
 from .lightning_compat import LightningDataModule
 
 
 def load_wav(path_or_file) -> torch.Tensor:
     """16-bit PCM wav -> (1, L) f32 in [-1, 1) (what torchaudio.load returns, data_module.py:153)."""
-    with _wave.open(path_or_file, "rb") as w:
-        if w.getsampwidth() != 2:
-            raise ValueError("only 16-bit PCM wav is supported")
-        n, ch = w.getnframes(), w.getnchannels()
-        pcm = np.frombuffer(w.readframes(n), dtype="<i2").reshape(-1, ch).T
-    return torch.from_numpy(pcm[:1].astype(np.float32) / 32768.0)
+    try:
+        with _wave.open(path_or_file, "rb") as w:
+            if w.getsampwidth() != 2:
+                raise ValueError("only 16-bit PCM wav is supported")
+            n, ch = w.getnframes(), w.getnchannels()
+            pcm = np.frombuffer(w.readframes(n), dtype="<i2").reshape(-1, ch).T
+        return torch.from_numpy(pcm[:1].astype(np.float32) / 32768.0)
+    except (ValueError, _wave.Error, EOFError) as e:
+        # flac / 24-bit / float wav (LibriSpeech's native format): whatever decoder the site has, as torchaudio.load did for the
+        # reference (data_module.py:153); neither is installed in this image
+        try:
+            import soundfile as sf
+            data, _sr = sf.read(path_or_file, dtype="float32", always_2d=True)
+            return torch.from_numpy(np.ascontiguousarray(data.T[:1]))
+        except ImportError:
+            pass
+        try:
+            import torchaudio
+            return torchaudio.load(path_or_file)[0][:1].float()
+        except ImportError:
+            raise ValueError("%s: %s (no soundfile / torchaudio available to decode other formats)" % (path_or_file, e)) from e
 
 
 class AudioParser:
@@ -51,6 +66,17 @@ class AudioParser:
         location = int(np.random.uniform(0, length - target_length))
         return x[:, location:target_length]
 
+    def crop_raw(self, x: torch.Tensor, weight: float = 0.98):
+        """The same two draws applied to the RAW waveform, for the device chain: the reference dithers and pre-emphasises the
+        whole clip and slices afterwards (:155-159), so the crop's first sample is ``y[loc] - 0.97 y[loc-1]``.  Returns
+        (row, lead): ``row`` = the slice with the sample before it in front when ``loc > 0`` (lead = 1, ``_lib.LEN_LEAD`` in the
+        length word handed to the mel kernel), which then produces exactly the reference's values."""
+        length = x.shape[1]
+        target_length = int(length * np.random.uniform(weight, 1))
+        location = int(np.random.uniform(0, length - target_length))
+        lead = 1 if (location > 0 and target_length > location) else 0
+        return x[:, location - lead:target_length], lead
+
     def draw_spec_augment(self, n_time: int, freq_mask: Union[int, float] = 27, time_mask: Union[int, float] = 0.07):
         """(rect_x, w_x, rect_y, w_y) with the draw order of spec_augment (:97-122)."""
         if isinstance(freq_mask, float):
@@ -67,9 +93,10 @@ class AudioParser:
         if isinstance(audio_path, str) and not os.path.exists(path=audio_path):
             raise Exception("音频路径不存在 " + audio_path)
         y = load_wav(audio_path)
+        lead = 0
         if mask:
-            y = self.sub_secquence(y, weight=0.98)
-        return self.features([y[0]], mask)[0]
+            y, lead = self.crop_raw(y, weight=0.98)
+        return self.features([y[0]], mask, leads=[lead])[0]
 
     # ---- the batched device front-end ---------------------------------------------------------------------------------------
     def device_dither(self):
@@ -103,23 +130,26 @@ class AudioParser:
             st["buf"][k] = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32).pin_memory()
         return st["buf"][k][:n]
 
-    def features(self, waves: Sequence[torch.Tensor], mask: bool, dither: bool = True):
+    def features(self, waves: Sequence[torch.Tensor], mask: bool, dither: bool = True, leads: Optional[Sequence[int]] = None):
         """list of (L_i,) f32 host waves -> (inputs, input_percentages) on the GPU: padded into a reused pinned buffer, ONE H2D
-        copy for the batch, then ``features_device``."""
+        copy for the batch, then ``features_device``.  leads[i] = 1: waves[i] starts with a lead-in sample (``crop_raw``)."""
         B = len(waves)
         L = max(int(w.numel()) for w in waves)
         host = self._staging(B * L).view(B, L)
         host.zero_()
         lens = torch.empty(B, dtype=torch.int32)
+        n_sig = torch.empty(B, dtype=torch.int32)
         for i, w in enumerate(waves):
             host[i, :w.numel()] = w.cpu() if w.is_cuda else w
-            lens[i] = w.numel()
+            ld = int(leads[i]) if leads is not None else 0
+            n_sig[i] = w.numel() - ld
+            lens[i] = (w.numel() - ld) | (_lib.LEN_LEAD if ld else 0)
         dev = self.device
         wave = host.to(dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self._stage["ev"][self._stage["k"]] = ev
-        aug = self.draw_aug_batch(lens).to(dev) if mask else None
+        aug = self.draw_aug_batch(n_sig).to(dev) if mask else None
         return self.features_device(wave, lens.to(dev), aug, dither)
 
     def _act_dtype(self):
@@ -206,8 +236,19 @@ class BucketBatchSampler(torch.utils.data.Sampler):
         return len(self._batches())
 
 
+def _rebuild_wave_batch(items, leads):
+    wb = WaveBatch(items)
+    wb.leads = leads
+    return wb
+
+
 class WaveBatch(tuple):
-    """(waves list, targets (B,Smax) int64, target_sizes (B) int32, paths, mask flag) from the workers."""
+    """(waves list, targets (B,Smax) int64, target_sizes (B) int32, paths, mask flag) from the workers.  ``leads`` (list of 0/1,
+    or None): waves[i] starts with a lead-in sample (``AudioParser.crop_raw``); it survives the DataLoader's pickling."""
+    leads = None
+
+    def __reduce__(self):
+        return (_rebuild_wave_batch, (tuple(self), self.leads))
 
 
 class LibriDataModule(LightningDataModule):
@@ -260,15 +301,19 @@ class LibriDataModule(LightningDataModule):
     # ---- host half of the collate: ragged waves + padded targets (data_module.py:231-247) ---------
     def _collate_wave(self, batch, mask: bool) -> WaveBatch:
         waves = [b[0] for b in batch]
+        leads = None
         if mask and getattr(self, "train_crop", True):   # training-time random sub-sequence (data_module.py:158-159)
-            waves = [self.audio_parser.sub_secquence(w.unsqueeze(0), weight=0.98)[0] for w in waves]
+            cr = [self.audio_parser.crop_raw(w.unsqueeze(0), weight=0.98) for w in waves]
+            waves, leads = [c[0][0] for c in cr], [c[1] for c in cr]
         max_trans = max(len(b[1]) for b in batch)
         targets = torch.zeros(len(batch), max_trans, dtype=torch.int64)
         target_sizes = torch.zeros(len(batch), dtype=torch.int32)
         for i, b in enumerate(batch):
             target_sizes[i] = len(b[1])
             targets[i, :len(b[1])] = torch.tensor(b[1], dtype=torch.int64)
-        return WaveBatch((waves, targets, target_sizes, [b[2] for b in batch], mask))
+        wb = WaveBatch((waves, targets, target_sizes, [b[2] for b in batch], mask))
+        wb.leads = leads
+        return wb
 
     def _collate_train(self, batch):
         return self._collate_wave(batch, True)
@@ -283,6 +328,6 @@ class LibriDataModule(LightningDataModule):
         if not isinstance(batch, WaveBatch):
             return batch
         waves, targets, target_sizes, paths, mask = batch
-        inputs, pct = self.audio_parser.features(waves, mask)
+        inputs, pct = self.audio_parser.features(waves, mask, leads=batch.leads)
         dev = inputs.device
         return inputs, targets.to(dev), pct, target_sizes.to(dev), paths

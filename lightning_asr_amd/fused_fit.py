@@ -21,7 +21,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ingest import BatchProducer, DevBatch, DeviceFeeder, PinnedRing, SR, fast_ingest_ok
 from .step import GraphedTrainStep, TrainStep, graph_dp_enabled
 
@@ -61,14 +61,18 @@ class HostWaveSource:
             B, L = len(waves), max(int(w.numel()) for w in waves)
             host = torch.zeros(B, L).pin_memory()
             lens = torch.empty(B, dtype=torch.int32)
+            leads = getattr(batch, "leads", None)            # crop_raw's lead-in samples (crop after pre-emphasis, data_module.py:157-159)
+            n_real = 0
             for i, w in enumerate(waves):
                 host[i, :w.numel()] = w
-                lens[i] = w.numel()
+                ld = int(leads[i]) if leads is not None else 0
+                lens[i] = (w.numel() - ld) | (_lib.LEN_LEAD if ld else 0)
+                n_real += w.numel() - ld
             db = DevBatch()
             db.pcm = host.to(self.device, non_blocking=True)
             db.lens, db.sizes, db.targets = lens.to(self.device), sizes.to(self.device), targets.to(self.device)
             db.aug = None
-            db.paths, db.B, db.ld, db.S, db.seconds = paths, B, L, targets.shape[1], float(lens.sum()) / SR
+            db.paths, db.B, db.ld, db.S, db.seconds = paths, B, L, targets.shape[1], float(n_real) / SR
             db.ready, db.dslot, db.index, db.key = None, -1, k, (B, L, targets.shape[1], False)
             db.mask, db.waited = mask, True
             yield db
@@ -170,7 +174,12 @@ class FusedLoop:
         try:
             g.targets.copy_(cur.targets)
             g.tgt_lens.copy_(cur.sizes)
-            g.capture(first_wave=cur.pcm, first_lens=cur.lens, first_aug=cur.aug)
+            # world > 1: NO eager warm-up passes.  They would issue real all-reduces on THIS rank only (each rank decides from its
+            # own batch shapes when to capture), pairing with the other ranks' training all-reduces.  The capture pass itself
+            # executes nothing, and the replay that follows issues exactly the one set of bucket collectives this step owes the
+            # group - the same sequence an eager rank issues - so ranks may capture at different steps, or never.  The warm-ups
+            # exist to settle lazy initialisation and the allocator; this shape has already run eagerly >= 2 times here.
+            g.capture(first_wave=cur.pcm, first_lens=cur.lens, first_aug=cur.aug, warmup=0 if self.ts.world > 1 else 2)
         except Exception as e:  # noqa: BLE001 - a runtime that refuses the capture: this shape stays eager
             logger.warning("hipGraph capture failed for batch shape %s (%s): eager launches", key, e)
             g.graph = None

@@ -33,11 +33,14 @@ def wav_info(path: str):
 
 
 def read_wav_batch(paths: Sequence[str], out: torch.Tensor, lens_out: torch.Tensor, crop_u: Optional[np.ndarray] = None,
-                   crop_weight: float = 0.98, n_threads: int = 8, expect_rate: int = 0) -> int:
+                   crop_weight: float = 0.98, n_threads: int = 8, expect_rate: int = 0, lead_in: bool = False) -> int:
     """Decode ``paths`` into ``out`` (1-D int16 host tensor, normally pinned) as rows of pitch ``ld`` (returned);
     ``lens_out`` (>= len(paths) int32 host tensor) receives the valid samples per row.  crop_u: (n, 2) float64 uniforms for the
     training-time sub-sequence (data_module.py:138-148), or None.  expect_rate > 0 refuses files of another sample rate; the
-    default takes any rate as it is, like the reference (data_module.py:153 drops the rate torchaudio.load returns)."""
+    default takes any rate as it is, like the reference (data_module.py:153 drops the rate torchaudio.load returns).
+    lead_in: a crop that starts past the file's first sample brings the sample before it along as the row's first entry and
+    flags its ``lens_out`` word with ``_lib.LEN_LEAD`` - the mel kernel then pre-emphasises the crop's first sample against it,
+    which is what cropping AFTER dither + pre-emphasis gives (data_module.py:155-159)."""
     n = len(paths)
     if out.dtype != torch.int16 or out.is_cuda or not out.is_contiguous():
         raise TypeError("read_wav_batch writes a contiguous int16 host tensor")
@@ -52,7 +55,7 @@ def read_wav_batch(paths: Sequence[str], out: torch.Tensor, lens_out: torch.Tens
             raise ValueError("crop_u must have shape (n, 2)")
         cu = crop_u.ctypes.data_as(C.c_void_p)
     _lib.call("lasr_wav_read_batch", arr, n, cu, float(crop_weight), out.data_ptr(), out.numel(), C.byref(ld), lens_out.data_ptr(),
-              int(expect_rate), int(n_threads))
+              int(expect_rate), int(n_threads), int(bool(lead_in)))
     return int(ld.value)
 
 
@@ -164,13 +167,13 @@ class BatchProducer(threading.Thread):
         lens = meta[o_lens:o_lens + B]
         while True:
             try:
-                ld = read_wav_batch(paths, ring.pcm[slot], lens, crop_u, self.crop_weight, self.n_threads)
+                ld = read_wav_batch(paths, ring.pcm[slot], lens, crop_u, self.crop_weight, self.n_threads, lead_in=self.crop)
                 break
             except _lib.LasrError as e:
                 if "do not fit the buffer" not in str(e):
                     raise
                 ring.grow(slot, capacity=int(ring.pcm[slot].numel() * 1.5) + 8 * B)    # a file longer than its manifest duration
-        lens_np = mnp[o_lens:o_lens + B]
+        lens_np = mnp[o_lens:o_lens + B] & (_lib.LEN_LEAD - 1)       # (the device words keep their lead-in flags; the host counts samples)
         mnp[o_sizes:o_sizes + B] = [a.size for a in ids]
         tg_np = mnp[o_tg:o_tg + 2 * B * S].view(np.int64).reshape(B, S)
         tg_np[:] = 0
@@ -206,6 +209,7 @@ class DeviceFeeder:
         self.pcm = [torch.empty(ring.capacity, dtype=torch.int16, device=self.device) for _ in range(n_slots)]
         self.meta = [torch.empty(ring.meta_words, dtype=torch.int32, device=self.device) for _ in range(n_slots)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._retired: list = []               # outgrown device blocks, kept alive until close()
         # device slots are handed back explicitly: (slot, event recorded on the compute stream after the last kernel that reads it).
         # The uploader (producer thread) BLOCKS here when every slot is in flight - it may run several batches ahead of the step.
         self.free_dev: "queue.Queue" = queue.Queue()
@@ -237,11 +241,19 @@ class DeviceFeeder:
         if k < 0:
             raise RuntimeError("device feeder closed")
         n = hb.B * hb.ld
-        if n > self.pcm[k].numel():
-            self.pcm[k] = torch.empty(n, dtype=torch.int16, device=self.device)
-        if hb.meta_words > self.meta[k].numel():
-            self.meta[k] = torch.empty(hb.meta_words, dtype=torch.int32, device=self.device)
         cs = self.copy_stream
+        if n > self.pcm[k].numel() or hb.meta_words > self.meta[k].numel():
+            # A batch outgrew its slot.  The new block is allocated UNDER THE COPY STREAM: the caching allocator keeps one pool per
+            # stream, so it cannot be a block the compute thread just freed with kernels still queued on the compute stream (the
+            # H2D copy below is not ordered against that stream).  The outgrown block is parked until close(): steps still in
+            # flight may be reading it, and `released` only orders the copy stream behind them, not the allocator.
+            with torch.cuda.stream(cs):
+                if n > self.pcm[k].numel():
+                    self._retired.append(self.pcm[k])
+                    self.pcm[k] = torch.empty(int(n * 1.25) + 64, dtype=torch.int16, device=self.device)
+                if hb.meta_words > self.meta[k].numel():
+                    self._retired.append(self.meta[k])
+                    self.meta[k] = torch.empty(int(hb.meta_words * 1.5) + 64, dtype=torch.int32, device=self.device)
         if released is not None:
             cs.wait_event(released)             # the step that read this device slot has finished with it
         with torch.cuda.stream(cs):
@@ -270,7 +282,29 @@ class DeviceFeeder:
         self.free_dev.put((db.dslot, ev))
 
 
-def fast_ingest_ok(dataset) -> bool:
-    """the native reader applies to the stock dataset (manifest of 16-bit PCM wav paths)"""
+def fast_ingest_ok(dataset, probe: int = 4) -> bool:
+    """the native reader applies to the stock dataset over a manifest of 16-bit PCM RIFF/WAVE files (what the reference's
+    scripts/get_libri.py writes).  The first, last and a few middle entries are probed with ``lasr_wav_info``: a manifest that
+    points at flac, 24-bit or float wav files keeps the DataLoader route (whatever ``load_wav`` can decode) instead of aborting
+    the fit on its first batch."""
     from .data_module import MyAudioDataset
-    return type(dataset).__getitem__ is MyAudioDataset.__getitem__ and hasattr(dataset, "datasets") and hasattr(dataset, "char2index")
+    if not (type(dataset).__getitem__ is MyAudioDataset.__getitem__ and hasattr(dataset, "datasets") and hasattr(dataset, "char2index")):
+        return False
+    cached = dataset.__dict__.get("_lasr_fast_ingest_ok")
+    if cached is not None:
+        return cached
+    n = len(dataset.datasets)
+    ok = True
+    for i in sorted({0, n - 1, *(n * k // probe for k in range(1, probe))}) if n else []:
+        try:
+            _frames, _ch, _rate, bits = wav_info(dataset.datasets[i]["audio_filepath"])
+            ok = ok and bits == 16
+        except _lib.LasrError:
+            ok = False
+        if not ok:
+            import logging
+            logging.getLogger(__name__).warning("native wav ingest off: %s is not a 16-bit PCM RIFF/WAVE file (falling back to the "
+                                                "DataLoader route)", dataset.datasets[i]["audio_filepath"])
+            break
+    dataset.__dict__["_lasr_fast_ingest_ok"] = ok
+    return ok

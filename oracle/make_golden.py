@@ -62,7 +62,27 @@ def checksum(t: torch.Tensor) -> np.ndarray:
     return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()])
 
 
-def run_reference(variant: str, labels, x, tg, pct, tsz, n_steps: int = 3, lr: float = 1e-2, wd: float = 1e-3):
+def swap_activation(model, act_mod):
+    """The reference imports Swish / Mish (models/QuartNet.py:5) but constructs nn.ReLU everywhere.  To pin the
+    oracle's ``act="swish"`` path, the unit epilogues of a reference model instance are replaced by the reference's OWN
+    activate_fun.Swish.Swish module: SeprationConv.relu (models/QuartNet.py:25,37), QuartNetBlock.last_relu (:69,77) and the
+    activation inside encoder.last_cnn2 (:148).  SELayer's internal ReLU (models/QuartNetContextSE.py:14) is part of the SE
+    MLP, not an epilogue, and stays."""
+    n = 0
+    for name, sub in model.named_modules():
+        for attr in ("relu", "last_relu"):
+            if isinstance(getattr(sub, attr, None), torch.nn.ReLU):
+                setattr(sub, attr, act_mod())
+                n += 1
+        if name.endswith("last_cnn2"):
+            for i, child in enumerate(sub):
+                if isinstance(child, torch.nn.ReLU):
+                    sub[i] = act_mod()
+                    n += 1
+    return n
+
+
+def run_reference(variant: str, labels, x, tg, pct, tsz, n_steps: int = 3, lr: float = 1e-2, wd: float = 1e-3, act: str = "relu"):
     sys.path.insert(0, REF)
     for m in list(sys.modules):
         if m == "models" or m.startswith("models.") or m.startswith("activate_fun") or m.startswith("scheduler"):
@@ -77,6 +97,9 @@ def run_reference(variant: str, labels, x, tg, pct, tsz, n_steps: int = 3, lr: f
     for (k, shp), v in zip(shapes, model.state_dict().values()):
         assert tuple(v.shape) == tuple(shp), (k, v.shape, shp)
     model.load_state_dict(R.formula_state(variant, n_class))
+    if act == "swish":
+        n_swapped = swap_activation(model, importlib.import_module("activate_fun.Swish").Swish)
+        assert n_swapped == len(R.block_table(variant)) * 2 + 2, n_swapped     # 2 per residual block + first_cnn + last_cnn2
     out = {}
     # eval-mode forward first (does not touch buffers)
     model.eval()
@@ -127,9 +150,9 @@ def run_reference(variant: str, labels, x, tg, pct, tsz, n_steps: int = 3, lr: f
     return out
 
 
-def run_oracle(variant: str, labels, x, tg, pct, tsz, n_steps: int = 3, lr: float = 1e-2, wd: float = 1e-3):
+def run_oracle(variant: str, labels, x, tg, pct, tsz, n_steps: int = 3, lr: float = 1e-2, wd: float = 1e-3, act: str = "relu"):
     n_class = len(labels) + 1
-    m = R.OracleModel(variant, n_class, mask=True, state=R.formula_state(variant, n_class))
+    m = R.OracleModel(variant, n_class, mask=True, act=act, state=R.formula_state(variant, n_class))
     out = {}
     m.training = False
     with torch.no_grad():
@@ -227,6 +250,23 @@ def main():
         print("  state after 3 NovoGrad steps ok (worst rel-L2 %.2e)" % worst)
         save = {k: v for k, v in ref.items() if not k.startswith("_")}
         np.savez_compressed(os.path.join(GOLD, "model_%s.npz" % variant), **save)
+
+    # Swish epilogues (north_star "BatchNorm + Swish"; activate_fun/Swish.py:9-10): the reference's own Swish module swapped into
+    # the reference model's epilogues - pins the oracle's act="swish" path (forward, gradients, one NovoGrad step)
+    for variant in ("plain", "context_se"):
+        print("variant", variant, "/ swish epilogues")
+        ref = run_reference(variant, labels, x, tg, pct, tsz, n_steps=1, act="swish")
+        ora = run_oracle(variant, labels, x, tg, pct, tsz, n_steps=1, act="swish")
+        for k in ("eval_logprobs", "logprobs", "nll", "t_lengths", "losses"):
+            check(ref[k], ora[k], k)
+        worst = 0.0
+        for i, (g_r, g_o) in enumerate(zip(ref["_grads"], ora["_grads"])):
+            rel = ((g_r - g_o).norm() / (g_r.norm() + 1e-20)).item()
+            worst = max(worst, rel)
+            assert rel <= 5e-3, ("grad", i, rel)
+        print("  grads ok (%d tensors, worst rel-L2 %.2e)" % (len(ref["_grads"]), worst))
+        save = {k: v for k, v in ref.items() if not k.startswith("_")}
+        np.savez_compressed(os.path.join(GOLD, "model_%s_swish.npz" % variant), **save)
 
     # large-vocab short case (cfg5 shape class): C = 4334, plain model, 1 step
     vocab = [c.strip() for c in open(os.path.join(REF, "data", "aishell1-vocab.txt"))]

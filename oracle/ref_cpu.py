@@ -134,14 +134,19 @@ def sub_sequence(y: torch.Tensor, u_len: float, u_loc: float, weight: float = 0.
 
 
 def parse_wave(y: torch.Tensor, dither: Optional[torch.Tensor] = None,
-               aug: Optional[Tuple[int, int, int, int]] = None, normalize: bool = True) -> torch.Tensor:
+               aug: Optional[Tuple[int, int, int, int]] = None, normalize: bool = True,
+               crop: Optional[Tuple[float, float]] = None) -> torch.Tensor:
     """(1, L) wave -> (1, 64, T) normalised log-mel, the chain of data_module.py:150-174
-    with the random dither passed in explicitly (None = dither off)."""
+    with the random dither passed in explicitly (None = dither off).  crop = (u_len, u_loc): the two
+    uniforms of the training-time ``sub_secquence``, applied where the reference applies it - AFTER
+    dither and pre-emphasis (:155-159), so the crop's first sample is y[loc] - 0.97 y[loc-1]."""
     if y.dtype != torch.float64:
         y = y.float()
     if dither is not None:
         y = y + DITHER * dither.to(y.dtype)
     y = preemphasis(y)
+    if crop is not None:
+        y = sub_sequence(y, crop[0], crop[1])
     db = amplitude_to_db(mel_power(y))
     if aug is not None:
         db = spec_augment_apply(db, *aug)

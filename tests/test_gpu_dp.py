@@ -425,6 +425,65 @@ def test_library_communicator_two_ranks_over_stub_rccl(dev, variant, n_buckets):
     assert ((got - ref).norm() / ref.norm()).item() < 1e-6
 
 
+def _fit_unequal_worker(rank, world, port, data_dirs, out, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      LASR_DIST_BACKEND="gloo", LASR_RCCL_PATH=STUB)
+    try:
+        from lightning_asr_amd.train import main
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        data = data_dirs[rank]
+        tr = main(["data.train_manifest=[%s]" % os.path.join(data, "train.json"), "data.val_manifest=%s" % os.path.join(data, "dev.json"),
+                   "data.test_manifest=%s" % os.path.join(data, "dev.json"), "data.labels=%s" % os.path.join(root, "data", "labels.txt"),
+                   "train.train_batch_size=2", "train.dev_batch_size=2", "train.total_epoch=1", "train.precision=16", "train.gpus=2",
+                   "train.warmup_steps=2", "data.train_crop=false", "output_dir=%s" % os.path.join(out, "rank%d" % rank)])
+        import torch.distributed as dist
+        f = tr.fused
+        q.put((rank, tr.global_step, f.graph_steps, f.eager_steps, f.native.params.cpu().numpy(), f.ts.comm is not None, None))
+        dist.barrier()
+        if f.ts.comm is not None:
+            f.ts.comm.close()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put((rank, None, 0, 0, None, False, traceback.format_exc()))
+
+
+def test_trainer_fit_two_ranks_capture_at_different_steps(dev, tmp_path):
+    """Trainer.fit with world = 2 where the ranks see DIFFERENT batch-shape sequences: rank 0 trains on equal-length
+    clips (its batch shape repeats: FusedLoop captures a hipGraph at its third occurrence and replays from then on), rank 1 on a
+    ragged corpus (every batch has its own shape: it stays eager for the whole epoch).  Each rank decides on its own when to capture,
+    so a capture must not issue a single collective of its own: over 12 steps per rank the bucket all-reduces of the replaying rank
+    and of the eager rank pair up one to one (the stub aborts on a barrier that never fills) and the replicas end on the same bits."""
+    import subprocess
+    import sys
+    import numpy as np
+    import torch.multiprocessing as mp
+    assert os.path.exists(STUB), "build tests/stub_rccl/libstubrccl.so (make)"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dirs = [str(tmp_path / "equal"), str(tmp_path / "ragged")]
+    for d, extra in zip(dirs, ([], ["--ragged", "--seed", "77"])):
+        subprocess.run([sys.executable, os.path.join(root, "tools", "make_synth_data.py"), "--out", d, "--n-train", "48", "--n-dev", "2",
+                        "--seconds", "3.0"] + extra, check=True)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_unequal_worker, args=(r, 2, port, dirs, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+    for r in res:
+        assert r[1] is not None, r[6]
+    assert res[0][1] == res[1][1] == 12           # 48 utterances / (2 ranks x batch 2)
+    assert res[0][5] and res[1][5]                # lasr_comm_* (over the stub) carried the exchange
+    assert res[0][2] >= 8 and res[0][3] <= 4, res[0][1:4]      # rank 0: eager until the shape came back a third time, then replays
+    assert res[1][2] == 0 and res[1][3] == 12, res[1][1:4]     # rank 1: no shape ever repeats
+    assert np.isfinite(res[0][4]).all() and np.array_equal(res[0][4], res[1][4])
+
+
 def _stub_graph_worker(rank, world, port, q):
     """eager staged data-parallel steps vs the same steps replayed from a captured hipGraph (collectives on the library's side
     stream INSIDE the capture), two ranks over the stub"""

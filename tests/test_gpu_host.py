@@ -198,3 +198,29 @@ def test_cfg1_plumbing_4x10s_one_step(dev, tmp_path):
     assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0
     ckpt = torch.load(out / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
     assert ckpt["global_step"] == 1 and len(ckpt["state_dict"]) == 184
+
+
+def test_train_main_with_swish_one_step(dev, tmp_path):
+    """conf `model.act=swish` (north_star "BatchNorm + Swish"; activate_fun/Swish.py:9-10) through train.main: one fused training
+    step (bf16, the step Trainer.fit drives) + validation + checkpoint; the native model really runs the Swish epilogues (its first
+    step's loss differs from the ReLU model's on the same data) and the checkpoint's hyper-parameters carry the activation."""
+    data = tmp_path / "swish"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_data.py"), "--out", str(data), "--n-train", "4",
+                    "--n-dev", "4", "--seconds", "3.0"], check=True)
+    from lightning_asr_amd.train import main
+    losses = {}
+    for act in ("swish", "relu"):
+        out = tmp_path / ("run_" + act)
+        tr = main(["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
+                   "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % os.path.join(ROOT, "data", "labels.txt"),
+                   "train.train_batch_size=4", "train.dev_batch_size=4", "train.total_epoch=1", "train.max_steps=1", "train.precision=16",
+                   "train.warmup_steps=0", "data.train_crop=false", "model.act=%s" % act, "output_dir=%s" % out])
+        assert tr.global_step == 1 and tr.fused is not None
+        assert tr.fused.native.cfg.act == {"relu": 1, "swish": 2}[act]
+        rec = tr.history[-1]
+        assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0 and np.isfinite(rec["val_loss"])
+        losses[act] = rec["train_loss"]
+        if act == "swish":
+            ckpt = torch.load(out / "checkpoints" / "last.ckpt", map_location="cpu", weights_only=False)
+            assert ckpt["hyper_parameters"].get("act") == "swish"
+    assert abs(losses["swish"] - losses["relu"]) > 1e-3 * abs(losses["relu"])

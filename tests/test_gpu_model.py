@@ -19,9 +19,40 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-def _native(variant, n_class, dev, dtype=torch.float32):
+def argmax_report(tag, am_gpu, lp_gpu, gold, noise=None):
+    """Bit-exactness of the token-id argmax against the reference fixture, with the numbers SURVEY 8d asks for: the count of
+    mismatching frames, the reference's own top-1 / top-2 log-prob margin at each of them, and the smallest margin over all frames.
+    A mismatch is only acceptable where the reference's margin is below twice `noise` (the measured f32 noise of the CPU oracle
+    against the same fixture: two classes whose log-probs are closer than what one f32 evaluation order moves them by have no
+    defined winner).  Written to gpurun_out/argmax_margins.json (copied to profiles/ per round)."""
+    import json
+    import os
+    ref_lp = torch.from_numpy(gold["logprobs"]).double()
+    top2 = ref_lp.topk(2, dim=-1).values
+    margin = (top2[..., 0] - top2[..., 1])                       # (B, T')
+    t_len = torch.from_numpy(gold["t_lengths"]).long()
+    valid = torch.arange(margin.shape[1]).unsqueeze(0) < t_len.unsqueeze(1)
+    ref_am = torch.from_numpy(gold["argmax"].astype("int64"))
+    mis = (am_gpu.cpu().long() != ref_am)
+    rec = {"frames": int(mis.numel()), "valid_frames": int(valid.sum()), "mismatches": int(mis.sum()), "mismatches_in_valid_frames": int((mis & valid).sum()),
+           "min_margin_all_frames": float(margin.min()), "min_margin_valid_frames": float(margin[valid].min()),
+           "margins_at_mismatches": [float(v) for v in margin[mis]],
+           "gpu_logp_max_abs_err": float((lp_gpu.cpu().double() - ref_lp).abs().max()), "oracle_f32_noise": noise}
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/argmax_margins.json"
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        cur = {}
+    cur[tag] = rec
+    with open(path, "w") as f:
+        json.dump(cur, f, indent=1, sort_keys=True)
+    return rec
+
+
+def _native(variant, n_class, dev, dtype=torch.float32, act="relu"):
     from lightning_asr_amd.engine import NativeModel
-    m = NativeModel(variant, n_class, mask=True, act="relu", dtype=dtype, device=dev)
+    m = NativeModel(variant, n_class, mask=True, act=act, dtype=dtype, device=dev)
     m.load_state_dict(R.formula_state(variant, n_class))
     return m
 
@@ -48,6 +79,8 @@ def test_plain_forward_matches_golden_f32(dev):
     assert err < 2e-4, err
     # bit-exact token-id argmax decode vs the reference CPU path
     assert np.array_equal(am.cpu().numpy().astype(np.int16), gold["argmax"])
+    rec = argmax_report("plain_golden_f32", am, lp, gold)
+    assert rec["mismatches"] == 0 and rec["min_margin_all_frames"] > 2 * rec["gpu_logp_max_abs_err"]     # no frame is even close to a tie
     for name in ["first_cnn", "block1", "block23", "block3", "block43", "block5", "last_cnn2"]:
         got = checksum(m.tap(name).transpose(1, 2).contiguous().cpu())
         assert np.abs(got - gold["tap_" + name]).max() < 1e-4, name
@@ -149,7 +182,15 @@ def test_context_variants_match_golden_f32(dev, variant):
     loss, nll, lp, am = m2.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
     assert np.abs(lp.cpu().numpy() - gold["logprobs"]).max() < 3e-3       # oracle itself is 2.4e-3 from the reference here
     assert np.abs(nll.cpu().numpy() - gold["nll"]).max() / np.abs(gold["nll"]).max() < 1e-4
-    assert (am.cpu().numpy().astype(np.int16) == gold["argmax"]).mean() > 0.995
+    # argmax: bit-exact, or different ONLY at frames where the reference's own top-1 / top-2 margin is inside the f32 noise of this
+    # model's CPU evaluation - measured right here as the distance between the pinned f32 oracle (explicit LSTM loop) and the
+    # reference fixture (ATen's LSTM) on the same weights and inputs (`oracle itself is 2.4e-3 from the reference`)
+    om = R.OracleModel(variant, 28, mask=True, state=R.formula_state(variant, 28))
+    om.training = True
+    with torch.no_grad():
+        noise = float((om(x, pct).double() - torch.from_numpy(gold["logprobs"]).double()).abs().max())
+    rec = argmax_report("%s_golden_f32" % variant, am, lp, gold, noise=noise)
+    assert rec["mismatches"] <= 2 and all(m <= 2 * noise for m in rec["margins_at_mismatches"]), rec
     ctx = m2.tap("ctx_in")[:, :, 256:].contiguous().cpu()            # the reference module returns (B, T, 80)
     assert np.abs(checksum(ctx) - gold["tap_context_rnn"]).max() < 1e-5
     norms = np.array([m2.view(t, m2.grads).norm().item() for t in m2.param_infos()])
@@ -163,6 +204,38 @@ def test_context_variants_match_golden_f32(dev, variant):
     from conftest import e2e_gate, record_measured
     record_measured("%s_golden_f32_grad_rel_l2_vs_f64_oracle" % variant, worst)
     assert worst < e2e_gate("%s_golden_f32_grad_rel_l2_vs_f64_oracle" % variant), sorted(rels.items(), key=lambda kv: -kv[1])[:5]
+
+
+@pytest.mark.parametrize("variant", ["plain", "context_se"])
+def test_swish_whole_plan_matches_golden_f32(dev, variant):
+    """model.act = swish (north_star "BatchNorm + Swish"; activate_fun/Swish.py:9-10) through the WHOLE native plan - every fused
+    epilogue, the SE units, the BN backward that rebuilds the pre-activation - against the fixture captured from the reference model
+    with its own Swish module in the epilogues, and full gradients against the f64 oracle.  Swish has no kink: no activation can
+    land on the other side of zero, so the end-to-end gradient bound is far below the ReLU models' one-flip level."""
+    from lightning_asr_amd import ops
+    from oracle import ref_bf16 as E
+    gold = np.load("tests/golden/model_%s_swish.npz" % variant)
+    x, tg, pct, tsz = golden_inputs()
+    m = _native(variant, 28, dev, act="swish")
+    feats = ops.bct_to_btc(x[:, 0].contiguous().to(dev))
+    lp_e, _ = m.forward(feats, pct.to(dev), training=False)
+    assert np.abs(lp_e.cpu().numpy() - gold["eval_logprobs"]).max() < 3e-4
+    m2 = _native(variant, 28, dev, act="swish")
+    loss, nll, lp, am = m2.loss_backward(feats, pct.to(dev), tg.to(dev), tsz.to(dev))
+    assert np.abs(lp.cpu().numpy() - gold["logprobs"]).max() < 3e-4
+    assert np.abs(nll.cpu().numpy() - gold["nll"]).max() / np.abs(gold["nll"]).max() < 1e-4
+    assert abs(loss.item() - gold["losses"][0]) / gold["losses"][0] < 1e-4
+    mism = int((am.cpu().numpy().astype(np.int16) != gold["argmax"]).sum())
+    assert mism == 0, mism                                    # bit-exact token-id argmax decode
+    norms = np.array([m2.view(t, m2.grads).norm().item() for t in m2.param_infos()])
+    assert np.abs(norms / gold["grad_norms"] - 1).max() < 5e-3
+    o = E.Bf16OracleModel(variant, 28, mask=True, act="swish", state=R.formula_state(variant, 28), dtype=torch.float64, emulate=False)
+    _, _, _, grads = E.loss_and_grads(o, x.double(), tg, pct, tsz)
+    rels = {t.name: rel_l2(m2.view(t, m2.grads), g) for t, g in zip(m2.param_infos(), grads)}
+    worst = max(rels.values())
+    from conftest import record_measured
+    record_measured("%s_swish_golden_f32_grad_rel_l2_vs_f64_oracle" % variant, worst)
+    assert worst < 2e-3, sorted(rels.items(), key=lambda kv: -kv[1])[:5]
 
 
 @pytest.mark.parametrize("variant", ["context", "context_se"])

@@ -86,6 +86,62 @@ def test_mel_shortest_clips(dev):
         R.parse_wave(wave[3:4, :192], dither[3:4, :192])
 
 
+def test_mel_crop_after_preemphasis_lead_in(dev, tmp_path):
+    """The reference dithers and pre-emphasises the WHOLE clip and crops afterwards (data_module.py:155-159): a crop's first
+    sample is y[loc] - 0.97 y[loc-1] (both dithered).  The build crops the raw waveform on the host; the sample before the crop
+    travels as a lead-in (LASR_LEN_LEAD in the length word).  Three routes against R.parse_wave(y, dither, crop=(u_len, u_loc)):
+    f32 rows with explicit noise, int16 rows straight from lasr_wav_read_batch(lead_in=1), and a crop starting at sample 0
+    (no lead-in: y[0] stays unfiltered, as in the reference)."""
+    import wave as wavmod
+    import numpy as np
+    from conftest import MEL_TOL
+    from lightning_asr_amd import _lib, ops
+    from lightning_asr_amd.ingest import read_wav_batch
+    g = torch.Generator().manual_seed(23)
+    n_files, L0 = 4, 24000
+    pcm = (0.1 * torch.randn(n_files, L0, generator=g)).clamp(-1, 1).mul(32767).round().to(torch.int16)
+    # a loud step right before / at the crop point makes the first sample's pre-emphasis term visible far above the tolerance
+    crop_u = np.array([[0.3, 0.9], [0.8, 0.5], [0.5, 0.0], [0.0, 0.999]])         # (u_len, u_loc); row 2: loc = 0 -> no lead-in
+    paths = []
+    for i in range(n_files):
+        tgt = int(L0 * (0.98 + 0.02 * crop_u[i, 0])); loc = int(crop_u[i, 1] * (L0 - tgt))
+        if loc > 0:
+            pcm[i, loc - 1] = 30000
+        p = str(tmp_path / ("c%d.wav" % i))
+        with wavmod.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm[i].numpy().tobytes())
+        paths.append(p)
+    out = torch.zeros(n_files * (L0 + 8), dtype=torch.int16)
+    lens_w = torch.zeros(n_files, dtype=torch.int32)
+    ld = read_wav_batch(paths, out, lens_w, crop_u, 0.98, n_threads=2, lead_in=True)
+    rows = out[:n_files * ld].view(n_files, ld)
+    leads = [(int(v) >> 30) & 1 for v in lens_w]
+    ns = [int(v) & (_lib.LEN_LEAD - 1) for v in lens_w]
+    assert leads == [1, 1, 0, 1]
+    y_full = pcm.float() / 32768.0
+    noise_full = torch.randn(n_files, L0, generator=g)
+    # the rows' explicit noise: the full clip's noise, cropped like the samples (lead-in included)
+    noise_rows = torch.zeros(n_files, ld)
+    for i in range(n_files):
+        tgt = int(L0 * (0.98 + 0.02 * crop_u[i, 0])); loc = int(crop_u[i, 1] * (L0 - tgt))
+        assert ns[i] == tgt - loc
+        assert torch.equal(rows[i, :ns[i] + leads[i]], pcm[i, loc - leads[i]:tgt])
+        noise_rows[i, :ns[i] + leads[i]] = noise_full[i, loc - leads[i]:tgt]
+    for wave_dev in (rows.to(dev), (rows.float() / 32768.0).to(dev)):          # int16 PCM and f32 rows
+        bft, _, frames, _ = ops.mel(wave_dev, lens_w.to(dev), noise_rows.to(dev), None, True)
+        for i in range(n_files):
+            ref64 = R.parse_wave(y_full[i:i + 1].double(), noise_full[i:i + 1].double(), crop=(float(crop_u[i, 0]), float(crop_u[i, 1])))
+            Tb = ref64.shape[2]
+            assert int(frames[i]) == Tb
+            err = max_rel(bft[i, :, :Tb], ref64[0])
+            assert err < MEL_TOL, (i, err)
+            # and the crop-first order (what the build did before: the first sample left unfiltered) is measurably different
+            if leads[i]:
+                tgt = int(L0 * (0.98 + 0.02 * crop_u[i, 0])); loc = int(crop_u[i, 1] * (L0 - tgt))
+                wrong = R.parse_wave(y_full[i:i + 1, loc:tgt].double(), noise_full[i:i + 1, loc:tgt].double())
+                assert max_rel(wrong[0], ref64[0]) > 10 * MEL_TOL
+
+
 def test_mel_db_and_specaugment(dev):
     from lightning_asr_amd import ops
     g = torch.Generator().manual_seed(5)

@@ -28,14 +28,14 @@ SWITCHES = [
 ]
 
 
-def _run(env_extra, variant="plain", n_class=28):
+def _run(env_extra, variant="plain", n_class=28, shape=()):
     env = dict(os.environ)
     for k in list(env):
         if k.startswith("LASR_") and k not in ("LASR_LIB_PATH",):
             del env[k]
     env.update(env_extra)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_probe.py"), variant, str(n_class)], env=env, capture_output=True,
-                         text=True, timeout=300)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "switch_probe.py"), variant, str(n_class)] + [str(a) for a in shape],
+                         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (env_extra, out.stderr[-2000:])
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
@@ -57,6 +57,24 @@ def test_kernel_switches_agree_with_the_default_paths(dev):
 def test_bn_inside_the_depthwise_forward_is_bit_identical(dev):
     """the BatchNorm + residual add + ReLU of a unit made in the staging loop of the next unit's depthwise forward (csrc/fused.h)
     performs bn_act_fwd_kernel's arithmetic operation for operation: loss, gradient norms and eval log-probs are the SAME numbers"""
+    # T' = 501 (the BASELINE clip length), ragged utterances, B = 8: every stride-1 depthwise layer takes the HALF-tile kernel
+    # (dwconv_s1_mfma_bn_kernel<*, 1>, the default path of the 256-channel layers at cfg2 / cfg5) - at the switch probe's default
+    # T' = 201 dwconv_fwd_bn declines (T <= 256) and both runs would make the same unfused launches (ADVICE r3)
+    for act in ("relu", "swish"):
+        shape = (8, 160000, 1, act)
+        fused, unfused = _run({}, shape=shape), _run({"LASR_BN_DW_FUSE": "0"}, shape=shape)
+        # the fused kernel really ran: 13 units (first_cnn ... block43) lose the BN-apply bracket of their own
+        assert unfused["prof_brackets"]["bn"] - fused["prof_brackets"]["bn"] == 13, (fused["prof_brackets"], unfused["prof_brackets"])
+        assert unfused["prof_brackets"]["dwconv"] == fused["prof_brackets"]["dwconv"]
+        fused.pop("prof_brackets"); unfused.pop("prof_brackets")
+        assert fused == unfused, (act, fused, unfused)
+    # full 512-frame tiles too (LASR_BN_DW_FUSE=2, B = 32: the 512-channel layers leave the half-tile form), same bits
+    shape = (32, 160000, 1, "relu")
+    a, b = _run({"LASR_BN_DW_FUSE": "2"}, shape=shape), _run({"LASR_BN_DW_FUSE": "0"}, shape=shape)
+    assert b["prof_brackets"]["bn"] - a["prof_brackets"]["bn"] == 13
+    a.pop("prof_brackets"); b.pop("prof_brackets")
+    assert a == b
+    # and at the probe's own short shape nothing is fused (T' = 201): the two builds of the step make the same launches
     assert _run({}) == _run({"LASR_BN_DW_FUSE": "0"})
 
 

@@ -63,14 +63,14 @@ def _ragged_batch(B, L_max, L_min, V, seed, chars_per_s=2.8):
 
 
 def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag, oracle_dtype=torch.float32, weights="random",
-                    lean=False, drop_p=0.0):
+                    lean=False, drop_p=0.0, act="relu"):
     from lightning_asr_amd import ops
     from lightning_asr_amd.engine import NativeModel
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     mode = "bf16" if dtype == torch.bfloat16 else "f32"
     tol = TOL[mode]
     state = R.random_state(variant, n_class, 0) if weights == "random" else R.formula_state(variant, n_class)
-    m = NativeModel(variant, n_class, mask=True, act="relu", dtype=dtype, device=dev)
+    m = NativeModel(variant, n_class, mask=True, act=act, dtype=dtype, device=dev)
     m.load_state_dict(state)
     if drop_p:
         m.set_dropout(drop_p, seed=12345)
@@ -99,10 +99,10 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     pct_c = pct.cpu()
     lens = R.mask_lengths(T, pct_c)
     assert m.tap("lens").cpu().tolist() == lens.tolist()
-    o = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
+    o = E.Bf16OracleModel(variant, n_class, mask=True, act=act, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
                           emulate=(mode == "bf16"))
     o.lean_head = lean
-    report = {"config": tag, "mode": mode, "B": B, "T_in": int(feats.shape[1]), "T": T, "C": n_class, "units": {}}
+    report = {"config": tag, "mode": mode, "act": act, "B": B, "T_in": int(feats.shape[1]), "T": T, "C": n_class, "units": {}}
     worst = {"act": 0.0, "grad_act": 0.0, "grad_param": 0.0}
 
     def note(unit, kind, key, val):
@@ -137,9 +137,10 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
             drop = (keep, 1.0 / (1.0 - thresh / 65536.0))
             report.setdefault("drop_kept_frac", {})[name] = keep.float().mean().item()
             assert abs(keep.float().mean().item() - (1 - drop_p)) < 5e-3, (name, keep.float().mean().item())
-        # ReLU mask from the GPU's output.  With dropout it is still right where it matters: a residual unit drops before the add
-        # (out > 0 <=> z > 0), first_cnn / last_cnn2 drop after the activation and a dropped element's gradient is zero anyway
-        r = E.run_unit(o, name, x_in, lens, dout, act_mask=out_gpu > 0, drop=drop)
+        # ReLU: derivative mask from the GPU's output.  With dropout it is still right where it matters: a residual unit drops before
+        # the add (out > 0 <=> z > 0), first_cnn / last_cnn2 drop after the activation and a dropped element's gradient is zero anyway.
+        # Swish (smooth: no element can change sides): the oracle differentiates its OWN pre-activation z, nothing is taken from the GPU
+        r = E.run_unit(o, name, x_in, lens, dout, act_mask=(out_gpu > 0) if act == "relu" else None, drop=drop)
         note(name, "act", "out", rel_l2(out_gpu, r["out"]))
         note(name, "act", "y", rel_l2(_bct(m.tap(name + ".y")), r["y"]))
         if "u" in r:
@@ -180,7 +181,7 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         note("head", "grad_param", "d." + k, rel_l2(gpu_grads[k], g.float()))
     report["worst"] = worst
     # end to end: the emulated oracle's own whole forward from the same features (loss only: see the module docstring)
-    o2 = E.Bf16OracleModel(variant, n_class, mask=True, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
+    o2 = E.Bf16OracleModel(variant, n_class, mask=True, act=act, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
                            emulate=(mode == "bf16"))
     if drop_p:
         report["worst"] = worst
@@ -224,6 +225,20 @@ def test_units_with_dropout(dev, variant, dtype):
 def test_units_cfg2_plain_bf16_bs32_10s(dev):
     wave, tg, tl = R.synth_batch(32, 160000, 100, 27, seed=1234)
     run_units_check(dev, "plain", 28, torch.bfloat16, wave, None, tg, tl, "cfg2_plain_bf16")
+
+
+def test_units_cfg2_plain_bf16_swish(dev):
+    """model.act = swish at the BASELINE size in the bench dtype: every unit of the plan - the half-tile depthwise forward that makes
+    the unit below's BN + add + Swish in its staging loop (dwconv_s1_mfma_bn_kernel), the sliced BN backward that rebuilds z and
+    applies swish'(z) - against the oracle differentiating its own pre-activation (activate_fun/Swish.py:9-10)."""
+    wave, tg, tl = R.synth_batch(32, 160000, 100, 27, seed=1234)
+    run_units_check(dev, "plain", 28, torch.bfloat16, wave, None, tg, tl, "cfg2_plain_bf16_swish", act="swish")
+
+
+def test_units_context_se_bf16_swish(dev):
+    """SE + Swish (the SE scale sits between BN and the activation: models/QuartNetContextSE.py:55), ragged batch, bf16"""
+    wave, lens, tg, tl = _ragged_batch(8, 96000, 60000, 27, seed=78)
+    run_units_check(dev, "context_se", 28, torch.bfloat16, wave, lens, tg, tl, "context_se_bf16_swish", act="swish")
 
 
 def test_units_cfg2_plain_f32_bs32_10s(dev):

@@ -208,6 +208,21 @@ def test_native_wav_batch_reader_matches_python_wave(tmp_path):
         loc = int(u[i, 1] * (L - tl))
         ref = (x[:, loc:tl][0] * 32768).to(torch.int16)
         assert int(lens[i]) == ref.numel() and torch.equal(out[i * ld2:i * ld2 + ref.numel()], ref)
+    # lead_in: the sample before the crop rides along (the reference crops AFTER pre-emphasis, data_module.py:157-159);
+    # a crop that starts at the file's first sample has none; stereo files hand over channel 0's
+    from lightning_asr_amd import _lib
+    u[0, 1] = 0.0
+    ld3 = ingest.read_wav_batch(paths, out, lens, crop_u=u, crop_weight=0.98, n_threads=2, lead_in=True)
+    for i, p in enumerate(paths):
+        x = load_wav(p)
+        L = x.shape[1]
+        tl = int(L * (0.98 + 0.02 * u[i, 0]))
+        loc = int(u[i, 1] * (L - tl))
+        lead = 1 if loc > 0 else 0
+        assert (int(lens[i]) >> 30) & 1 == lead and int(lens[i]) & (_lib.LEN_LEAD - 1) == tl - loc
+        ref = (x[:, loc - lead:tl][0] * 32768).to(torch.int16)
+        assert torch.equal(out[i * ld3:i * ld3 + ref.numel()], ref) and not out[i * ld3 + ref.numel():(i + 1) * ld3].any()
+    assert (int(lens[0]) >> 30) & 1 == 0 and ld3 >= max(int(v) & (_lib.LEN_LEAD - 1) for v in lens) + 1
     with pytest.raises(Exception, match="do not fit"):
         ingest.read_wav_batch(paths, out[:1000], lens)
     bad = tmp_path / "bad.wav"
@@ -363,3 +378,30 @@ def test_batch_producer_hands_errors_to_the_consumer_and_grows_a_short_slot(tmp_
     assert ring.pcm[out[0].slot].numel() >= 2 * 20000
     out, _ = drain([[0, 1]], 2 * 20000 + 64)
     assert isinstance(out[-1], BaseException) and "cannot open" in str(out[-1])
+
+
+def test_native_ingest_probes_the_manifest_before_it_takes_over(tmp_path):
+    """fast_ingest_ok: the native reader decodes 16-bit PCM RIFF/WAVE only; a manifest that points at anything else (flac, 24-bit
+    wav) keeps the DataLoader route instead of aborting the fit on its first batch"""
+    import json
+    import numpy as np
+    from lightning_asr_amd import ingest
+    from lightning_asr_amd.data_module import MyAudioDataset
+    labels = list("abc")
+    good = []
+    for i in range(5):
+        p = tmp_path / ("g%d.wav" % i)
+        _write_wav(p, np.zeros((400, 1), dtype=np.int16), 1)
+        good.append(str(p))
+    flac = tmp_path / "x.flac"
+    flac.write_bytes(b"fLaC" + b"\0" * 64)
+
+    def manifest(name, paths):
+        m = tmp_path / name
+        with open(m, "w") as f:
+            for p in paths:
+                f.write(json.dumps({"audio_filepath": p, "duration": 0.025, "text": "ab"}) + "\n")
+        return str(m)
+    assert ingest.fast_ingest_ok(MyAudioDataset([manifest("good.json", good)], labels))
+    assert not ingest.fast_ingest_ok(MyAudioDataset([manifest("mixed.json", good[:2] + [str(flac)] + good[2:])], labels, ), probe=8)
+    assert not ingest.fast_ingest_ok(MyAudioDataset([manifest("last.json", good + [str(flac)])], labels))

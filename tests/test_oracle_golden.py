@@ -37,6 +37,27 @@ def test_oracle_forward_matches_reference_golden(variant):
                 assert np.abs(checksum(m.taps[k[4:]]) - gold[k]).max() < 1e-6, k
 
 
+@pytest.mark.parametrize("variant", ["plain", "context_se"])
+def test_oracle_swish_matches_reference_golden(variant):
+    """act="swish" (activate_fun/Swish.py:9-10): the oracle against the reference model with its own Swish module swapped into
+    the unit epilogues (oracle/make_golden.py::swap_activation): forward, per-sample NLL, gradient norms, one NovoGrad step."""
+    gold = np.load("tests/golden/model_%s_swish.npz" % variant)
+    x, tg, pct, tsz = golden_inputs()
+    m = R.OracleModel(variant, 28, mask=True, act="swish", state=R.formula_state(variant, 28))
+    m.training = False
+    with torch.no_grad():
+        lp_e = m(x, pct)
+    assert np.abs(lp_e.numpy() - gold["eval_logprobs"]).max() < (1e-6 if variant == "plain" else 5e-5)
+    st = R.NovogradState(len(m.parameters()))
+    loss, grads = R.train_step(m, st, x, tg, pct, tsz, 1e-2, 1e-3)
+    assert abs(loss / gold["losses"][0] - 1) < 1e-5
+    norms = np.array([g.norm().item() for g in grads])
+    assert np.abs(norms / gold["grad_norms"] - 1).max() < (1e-5 if variant == "plain" else 2e-3)
+    assert np.abs(np.stack([checksum(p) for p in m.parameters()]) - gold["params_after_1"]).max() < (1e-6 if variant == "plain" else 1e-4)
+    # a different function from the ReLU model (the fixture is not a copy of model_<variant>.npz)
+    assert np.abs(gold["logprobs"] - np.load("tests/golden/model_%s.npz" % variant)["logprobs"]).max() > 1e-2
+
+
 def test_oracle_train_steps_match_reference_golden():
     gold = np.load("tests/golden/model_plain.npz")
     x, tg, pct, tsz = golden_inputs()
