@@ -198,6 +198,42 @@ def cpu_baseline(cfg_name: str, V: int):
             "thread_sweep_s_per_step": {str(k): v for k, v in sweep.items()}}
 
 
+def watchdog_sync(what: str, timeout_s: float = 180.0) -> None:
+    """the first replay of a captured step that holds RCCL collectives must COMPLETE before anything is timed: a capture failure falls
+    back to eager launches, a replay hang is caught here (exit code 3 with a message; never a re-exec) - step.sync_with_timeout"""
+    from lightning_asr_amd.step import sync_with_timeout
+    sync_with_timeout("bench.py: " + what, timeout_s)
+
+
+def comm_record(ts, n_steps: int, use_graph: bool, buckets_per_step: int):
+    """bench.py's `comm` object (N > 1, or LASR_FORCE_OVERLAP=1 on one GPU): which path carries the gradient exchange and, measured
+    with events inside liblasr during the eager roofline steps (lasr_comm_timing), how long each bucket's all-reduce took on the side
+    stream (peers' arrival included) and how long the optimiser's stream actually stalled at lasr_comm_wait - the exposed part."""
+    rec = {"path": "lasr_comm (librccl called by liblasr on its own side stream)" if ts.comm is not None else "torch.distributed all_reduce",
+           "timed_region_launch": "hipGraph replay (collectives inside the capture)" if use_graph else "eager",
+           "staged_backward": bool(ts.overlap and (ts.world > 1 or ts.force_staged)), "buckets_per_step": buckets_per_step,
+           "rccl_library": os.environ.get("LASR_RCCL_PATH", "librccl.so"),
+           "max_channels": os.environ.get("NCCL_MAX_NCHANNELS"), "world": ts.world}
+    if ts.comm is None:
+        rec["note"] = "no per-bucket timing on the torch.distributed fallback path"
+        return rec
+    coll, waits = ts.comm.timing_collect()
+    ts.comm.timing(False)
+    if not coll or n_steps <= 0:
+        return rec
+    per_step = max(1, len(coll) // n_steps)
+    buckets = []
+    for k in range(per_step):
+        xs = coll[k::per_step]
+        us = sum(x[0] for x in xs) / len(xs)
+        mb = xs[0][1] / 1e6
+        buckets.append({"mb": mb, "allreduce_us": us, "algbw_gbs": mb * 1e3 / us if us > 0 else None})
+    rec.update({"buckets": buckets, "exposed_wait_us_per_step": sum(waits) / n_steps if waits else None,
+                "allreduce_us_per_step": sum(b["allreduce_us"] for b in buckets),
+                "measured_over": "%d eager steps after the timed region (events on the side stream / the optimiser's stream)" % n_steps})
+    return rec
+
+
 def write_corpus(root: str, cfg: dict, labels, B: int, n_files_batches: int, n_steps: int, seed: int):
     """synthetic wav corpus (0.1 N(0,1) at 16 kHz, 16-bit PCM) + a JSON-lines manifest in the reference's format
     (scripts/get_libri.py:135) with n_steps * B lines cycling over n_files_batches * B files; one epoch = n_steps batches"""
@@ -230,7 +266,7 @@ def write_corpus(root: str, cfg: dict, labels, B: int, n_files_batches: int, n_s
     return man, dev_man
 
 
-def trainer_path(args, cfg):
+def trainer_path(args, cfg, emit: bool = True, steps=None, warmup=None):
     """The metric through the reference's own surface: python -m lightning_asr_amd.train's objects (LibriDataModule, LightingModule,
     Trainer.fit) over a synthetic wav corpus.  Timed: K consecutive training steps of Trainer.fit after W warm-up steps, bracketed
     by barrier + synchronize - including wav decode (host threads), int16 H2D, random crop + SpecAugment draws, dither, and the
@@ -247,7 +283,9 @@ def trainer_path(args, cfg):
     from lightning_asr_amd.lightning_compat import Trainer, seed_everything
     from lightning_asr_amd.train import LightingModule
     labels = [c.strip() for c in open(os.path.join(ROOT, cfg["vocab"]), encoding="utf-8").readlines()]
-    V, B, W, K = len(labels), args.batch, args.warmup, args.steps
+    V, B = len(labels), args.batch
+    W = args.warmup if warmup is None else warmup
+    K = args.steps if steps is None else steps
     root = tempfile.mkdtemp(prefix="lasr_bench_rank%d_" % rank)
     man, dev_man = write_corpus(root, cfg, labels, B, 8, W + K + 2, 1234 + rank)
     seed_everything(0)
@@ -314,7 +352,9 @@ def trainer_path(args, cfg):
                      "traffic": None, "kernel": "whole step (SURVEY 8d algorithmic bytes: %.1f MB)" % (step_bytes / 1e6),
                      "step_frac": step_gbs / PEAK_HBM_GBS},
     }
-    print(json.dumps(out), flush=True)
+    if emit:
+        print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
@@ -335,6 +375,8 @@ def main():
     ap.add_argument("--path", default=os.environ.get("LASR_BENCH_PATH", "step"), choices=["step", "trainer"],
                     help="step: TrainStep on batches resident in HBM (default); trainer: manifest -> LibriDataModule -> Trainer.fit")
     ap.add_argument("--ingest-threads", type=int, default=8, help="--path trainer: host threads decoding wav files (data.num_worker)")
+    ap.add_argument("--no-trainer-record", dest="trainer_record", action="store_false",
+                    help="skip the `trainer` sub-record (20 steps through Trainer.fit) of the default one-GPU line")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.path == "trainer":
@@ -467,8 +509,13 @@ def main():
                            prefetch_lens=None if nxt is None else nxt[1], want_logp=False)   # the training step reads loss + argmax only
         return graphs[i % len(batches)].replay()
 
-    for _ in range(args.warmup):
+    for k_ in range(args.warmup):
         loss, *_ = one_step()
+        if k_ == 0 and use_graph and (world > 1 or ts.force_staged):
+            watchdog_sync("the first replay of the captured data-parallel step")
+    if args.warmup == 0 and use_graph and (world > 1 or ts.force_staged):
+        loss, *_ = one_step()                      # (never time a graph with collectives that has not completed once)
+        watchdog_sync("the first replay of the captured data-parallel step")
     barrier()
     audio_s[0] = 0.0
     t0 = time.perf_counter()
@@ -495,9 +542,14 @@ def main():
         n_prof = len(batches)
     if rank == 0:
         lib.lasr_prof_enable(1)
+        if ts.comm is not None:
+            ts.comm.timing(True)
     for _ in range(n_prof):
         one_step(eager=True)       # (the in-library event brackets live in the launch path: a graph replay does not pass through it)
     torch.cuda.synchronize()
+    comm_rec = None
+    if rank == 0 and (world > 1 or ts.force_staged):
+        comm_rec = comm_record(ts, n_prof, use_graph, int(os.environ.get("LASR_DP_BUCKETS", "2")))
     if rank == 0:
         lib.lasr_prof_enable(0)
         NK = 8
@@ -549,6 +601,25 @@ def main():
     if dist is not None:
         dist.barrier()
 
+    # ---- the drop-in path in the same record: K = 20 steps of the SAME metric through the reference's own surface (manifest ->
+    # LibriDataModule -> LightingModule -> Trainer.fit; wav decode, int16 H2D, random crop + SpecAugment, dither, per-step decode + WER
+    # inside the timed region).  One GPU only: Trainer owns its process group.  ~5 s including the synthetic corpus.
+    trainer_rec = None
+    if world == 1 and dist is None and args.trainer_record and not args.no_cpu_baseline:      # (--no-cpu-baseline = the lean run the profiling scripts use)
+        del graphs
+        torch.cuda.synchronize()
+        try:
+            tr_out = trainer_path(args, cfg, emit=False, steps=20, warmup=5)
+            c_ = tr_out["config"]
+            trainer_rec = {"what": "the same metric through LibriDataModule + LightingModule + Trainer.fit (bench.py --path trainer), 5 warm-up + 20 timed steps",
+                           "value": tr_out["value"], "unit": tr_out["unit"], "ms_per_step": tr_out["ms_per_step"], "steps": 20, "warmup": 5,
+                           "vs_step_line": tr_out["ms_per_step"] / ms_per_step, "host_ms_per_step": c_["host_ms_per_step"],
+                           "hip_graph_steps": c_["hip_graph_steps"], "eager_steps": c_["eager_steps"], "train_crop": c_["train_crop"],
+                           "ingest": c_["ingest"], "ingest_threads": c_["ingest_threads"], "padding_frac": c_["padding_frac"],
+                           "included": c_["included"], "final_loss": tr_out["final_loss"]}
+        except Exception as e:      # the headline number above stands on its own; say why the sub-record is missing
+            trainer_rec = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -572,8 +643,12 @@ def main():
         "final_loss": final_loss,
         "roofline": roofline,
     }
+    if comm_rec is not None:
+        out["comm"] = comm_rec
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config, V)
+    if trainer_rec is not None:
+        out["trainer"] = trainer_rec
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -561,6 +561,16 @@ int lasr_comm_allreduce_ranges(lasr_comm_t* comm, float* base, const int64_t* lo
                                void* producer_stream);
 int lasr_comm_broadcast(lasr_comm_t* comm, float* buf, int64_t count, int root, void* producer_stream);
 int lasr_comm_wait(lasr_comm_t* comm, void* consumer_stream);
+/* lasr_comm_init caps RCCL's channel count (the persistent workgroups a collective keeps resident on the CUs it shares with the
+ * backward) unless NCCL_MAX_NCHANNELS is already set: LASR_COMM_MAX_CHANNELS (default 8; 0 = RCCL's own default).
+ * Timing of the exchange (bench.py's `comm` record; eager launches only): with timing on, every collective is bracketed by events on
+ * the side stream and every lasr_comm_wait by events on the consumer stream.  lasr_comm_timing_collect synchronises them and returns,
+ * in call order, coll_us[i] / coll_bytes[i] (duration and payload of collective i, peers' arrival included) and wait_us[j] (how long
+ * consumer stream j-th wait actually stalled: the part of the exchange backward did not hide); at most max_recs entries are written,
+ * *n_coll / *n_waits are the numbers recorded since timing was switched on.                                                      */
+int lasr_comm_timing(lasr_comm_t* comm, int on);
+int lasr_comm_timing_collect(lasr_comm_t* comm, int max_recs, double* coll_us, double* coll_bytes, int* n_coll, double* wait_us,
+                             int* n_waits);
 
 #ifdef __cplusplus
 }

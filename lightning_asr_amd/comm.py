@@ -94,3 +94,17 @@ class Communicator:
     def wait(self) -> None:
         """the current stream waits for every collective issued so far (device-side; the host does not block)"""
         call("lasr_comm_wait", self._h, _stream())
+
+    # ---- timing (bench.py's `comm` record) -----------------------------------------------------------------------------------
+    def timing(self, on: bool) -> None:
+        """bracket every collective (side stream) and every wait (consumer stream) with events from now on; eager launches only"""
+        call("lasr_comm_timing", self._h, int(bool(on)))
+
+    def timing_collect(self, max_recs: int = 4096):
+        """([(us, bytes) per collective, in call order], [us each ``wait`` actually stalled the consumer stream])"""
+        us = (C.c_double * max_recs)()
+        by = (C.c_double * max_recs)()
+        wt = (C.c_double * max_recs)()
+        nc, nw = C.c_int32(0), C.c_int32(0)
+        call("lasr_comm_timing_collect", self._h, max_recs, us, by, C.byref(nc), wt, C.byref(nw))
+        return [(us[i], by[i]) for i in range(min(nc.value, max_recs))], [wt[i] for i in range(min(nw.value, max_recs))]

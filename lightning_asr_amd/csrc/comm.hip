@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <vector>
 #include <rccl/rccl.h>
 
 namespace lasr {
@@ -31,6 +32,7 @@ struct RcclApi {
 };
 
 static RcclApi g_rccl;
+static constexpr int kDefaultMaxChannels = 8;   // see lasr_comm_init
 
 static int load_rccl() {
   if (g_rccl.handle) return 0;
@@ -78,6 +80,12 @@ static int nccl_fail(ncclResult_t r, const char* what) {
 
 using namespace lasr;
 
+// one timed collective (lasr_comm_timing): events on the side stream around the ncclAllReduce / group
+struct CommRec { hipEvent_t a, b; double bytes; };
+// one timed lasr_comm_wait: events on the CONSUMER stream right before and right after its wait for the side stream -
+// their distance is the part of the exchange that backward did not hide (what the optimiser launch actually waited)
+struct WaitRec { hipEvent_t a, b; };
+
 struct lasr_comm {
   ncclComm_t comm = nullptr;
   hipStream_t side = nullptr;        // library-owned: every collective of this communicator runs here
@@ -85,6 +93,16 @@ struct lasr_comm {
   hipEvent_t ev_out = nullptr;       // side stream -> consumer stream
   int world = 1, rank = 0, device = 0;
   int64_t calls = 0;
+  bool timing = false;
+  std::vector<CommRec> recs;
+  std::vector<WaitRec> waits;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t timed_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
 };
 
 extern "C" int lasr_comm_unique_id(void* id_out, size_t id_bytes) {
@@ -102,6 +120,21 @@ extern "C" int lasr_comm_init(lasr_comm_t** out, const void* unique_id, size_t i
   LASR_CHECK_ARG(world >= 1 && rank >= 0 && rank < world && device >= 0, "lasr_comm_init: world=%d rank=%d device=%d", world, rank, device);
   LASR_TRY(load_rccl());
   LASR_HIP(hipSetDevice(device), "hipSetDevice");
+  // RCCL's channel count = the number of persistent workgroups its collective kernels keep resident for as long as a bucket is on
+  // the wire.  Every hot kernel of the backward is sized as ONE round of workgroups over the 256 CUs, so a CU held by a channel
+  // sends a 252-tile GEMM into a second round (measured on one GPU with the stand-in's CU-holding mode: DESIGN 5, profiles/
+  // r04_cu_sharing.json).  The step needs ~30 GB/s of all-reduce bandwidth to hide its 17.8 MB bucket under half a backward, which
+  // a few channels deliver: cap them unless the user already chose (an NCCL_MAX_NCHANNELS in the environment wins;
+  // LASR_COMM_MAX_CHANNELS=0 leaves RCCL's default).
+  {
+    const char* capv = getenv("LASR_COMM_MAX_CHANNELS");
+    const int cap = capv ? atoi(capv) : kDefaultMaxChannels;
+    if (cap > 0 && !getenv("NCCL_MAX_NCHANNELS")) {
+      char buf[16];
+      snprintf(buf, sizeof(buf), "%d", cap);
+      setenv("NCCL_MAX_NCHANNELS", buf, 0);
+    }
+  }
   lasr_comm* c = new lasr_comm();
   c->world = world; c->rank = rank; c->device = device;
   ncclUniqueId id;
@@ -122,6 +155,9 @@ extern "C" int lasr_comm_destroy(lasr_comm_t* c) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto& w : c->waits) { (void)hipEventDestroy(w.a); (void)hipEventDestroy(w.b); }
+  for (auto& e : c->pool) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
   return 0;
@@ -140,7 +176,10 @@ static int order_after(lasr_comm* c, void* producer) {
 extern "C" int lasr_comm_allreduce(lasr_comm_t* c, float* buf, int64_t count, void* producer_stream) {
   LASR_CHECK_ARG(c && buf && count > 0, "lasr_comm_allreduce: null pointer / empty bucket");
   LASR_TRY(order_after(c, producer_stream));
+  CommRec rec{nullptr, nullptr, (double)count * sizeof(float)};
+  if (c->timing) { rec.a = c->timed_event(); rec.b = c->timed_event(); (void)hipEventRecord(rec.a, c->side); }
   LASR_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->comm, c->side), "ncclAllReduce");
+  if (c->timing) { (void)hipEventRecord(rec.b, c->side); c->recs.push_back(rec); }
   c->calls += 1;
   return 0;
 }
@@ -150,12 +189,16 @@ extern "C" int lasr_comm_allreduce_ranges(lasr_comm_t* c, float* base, const int
   LASR_CHECK_ARG(c && base && lo && hi && n_ranges > 0 && n_ranges <= 64, "lasr_comm_allreduce_ranges: bad argument");
   for (int i = 0; i < n_ranges; ++i) LASR_CHECK_ARG(lo[i] >= 0 && hi[i] > lo[i], "lasr_comm_allreduce_ranges: range %d", i);
   LASR_TRY(order_after(c, producer_stream));
+  CommRec rec{nullptr, nullptr, 0.0};
+  for (int i = 0; i < n_ranges; ++i) rec.bytes += (double)(hi[i] - lo[i]) * sizeof(float);
+  if (c->timing) { rec.a = c->timed_event(); rec.b = c->timed_event(); (void)hipEventRecord(rec.a, c->side); }
   LASR_NCCL(g_rccl.GroupStart(), "ncclGroupStart");      // one fused launch for the pieces of a bucket
   for (int i = 0; i < n_ranges; ++i) {
     ncclResult_t r = g_rccl.AllReduce(base + lo[i], base + lo[i], (size_t)(hi[i] - lo[i]), ncclFloat32, ncclSum, c->comm, c->side);
     if (r != ncclSuccess) { (void)g_rccl.GroupEnd(); return nccl_fail(r, "ncclAllReduce"); }
   }
   LASR_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+  if (c->timing) { (void)hipEventRecord(rec.b, c->side); c->recs.push_back(rec); }
   c->calls += 1;
   return 0;
 }
@@ -170,6 +213,47 @@ extern "C" int lasr_comm_broadcast(lasr_comm_t* c, float* buf, int64_t count, in
 extern "C" int lasr_comm_wait(lasr_comm_t* c, void* consumer_stream) {
   LASR_CHECK_ARG(c, "lasr_comm_wait: null communicator");
   LASR_HIP(hipEventRecord(c->ev_out, c->side), "hipEventRecord(side)");
+  WaitRec w{nullptr, nullptr};
+  if (c->timing) { w.a = c->timed_event(); w.b = c->timed_event(); (void)hipEventRecord(w.a, as_stream(consumer_stream)); }
   LASR_HIP(hipStreamWaitEvent(as_stream(consumer_stream), c->ev_out, 0), "hipStreamWaitEvent(consumer)");
+  if (c->timing) { (void)hipEventRecord(w.b, as_stream(consumer_stream)); c->waits.push_back(w); }
+  return 0;
+}
+
+// Timing of the exchange for bench.py's `comm` record (eager steps only: the events are recorded by these host calls).
+extern "C" int lasr_comm_timing(lasr_comm_t* c, int on) {
+  LASR_CHECK_ARG(c, "lasr_comm_timing: null communicator");
+  if (on) {
+    for (auto& r : c->recs) { c->pool.push_back(r.a); c->pool.push_back(r.b); }
+    for (auto& w : c->waits) { c->pool.push_back(w.a); c->pool.push_back(w.b); }
+    c->recs.clear(); c->waits.clear();
+  }
+  c->timing = on != 0;
+  return 0;
+}
+
+extern "C" int lasr_comm_timing_collect(lasr_comm_t* c, int max_recs, double* coll_us, double* coll_bytes, int* n_coll, double* wait_us,
+                                        int* n_waits) {
+  LASR_CHECK_ARG(c && n_coll && n_waits && max_recs >= 0, "lasr_comm_timing_collect: bad argument");
+  int nc = 0, nw = 0;
+  for (auto& r : c->recs) {
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e, "lasr_comm_timing_collect");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e, "lasr_comm_timing_collect");
+    if (nc < max_recs && coll_us && coll_bytes) { coll_us[nc] = 1e3 * (double)t; coll_bytes[nc] = r.bytes; }
+    ++nc;
+  }
+  for (auto& w : c->waits) {
+    hipError_t e = hipEventSynchronize(w.b);
+    if (e != hipSuccess) return hip_fail(e, "lasr_comm_timing_collect");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, w.a, w.b);
+    if (e != hipSuccess) return hip_fail(e, "lasr_comm_timing_collect");
+    if (nw < max_recs && wait_us) wait_us[nw] = 1e3 * (double)t;
+    ++nw;
+  }
+  *n_coll = nc; *n_waits = nw;
   return 0;
 }

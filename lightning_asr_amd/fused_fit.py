@@ -201,6 +201,12 @@ class FusedLoop:
         if g is not None:
             g.prime(feats, pct)
             loss, nll, _, am = g.step(nxt.pcm, cur.targets, cur.sizes, nxt.lens, nxt.aug)
+            if ts.world > 1 and not getattr(g, "_replayed_once", False):
+                # the first replay of a graph with collectives in it must be seen to complete (a capture failure falls back to
+                # eager launches above; a replay hang would otherwise surface at the next metrics read, without a reason)
+                from .step import sync_with_timeout
+                sync_with_timeout("Trainer.fit: the first replay of the captured data-parallel step", hard_exit=False)
+                g._replayed_once = True
             self._pf = (nxt.index, g.F_cur, g.pct_cur)
             self.graph_steps += 1
         else:

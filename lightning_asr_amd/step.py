@@ -367,3 +367,26 @@ def graph_dp_enabled() -> bool:
     """hipGraph capture of the data-parallel step (ncclAllReduce on the library's side stream inside the capture): on by default,
     ``LASR_GRAPH_DP=0`` keeps multi-rank steps eager"""
     return os.environ.get("LASR_GRAPH_DP", "1") != "0"
+
+
+def sync_with_timeout(what: str, timeout_s: float = 180.0, hard_exit: bool = True) -> None:
+    """Wait for everything enqueued on the current stream, but not for ever.  The first replay of a hipGraph that holds RCCL
+    collectives is the one thing of the data-parallel step that a capture *failure* cannot catch: a replay that hangs would sit in
+    ``synchronize()`` until somebody's outer limit.  On timeout the rank reports and leaves with exit code 3 (``hard_exit``; no
+    re-exec, no retry - the ranks' collective sequences are unknown by then) or raises ``TimeoutError``."""
+    import sys
+    import time
+    ev = torch.cuda.Event()
+    ev.record()
+    t0 = time.perf_counter()
+    while not ev.query():
+        if time.perf_counter() - t0 > timeout_s:
+            msg = ("%s did not complete within %.0f s on rank %s - a hang inside the graph-replayed data-parallel step (RCCL collectives "
+                   "captured on the library's side stream).  Re-run with LASR_GRAPH_DP=0 (eager launches) or LASR_COMM=torch "
+                   "(torch.distributed's all-reduce)." % (what, timeout_s, os.environ.get("RANK", "0")))
+            if not hard_exit:
+                raise TimeoutError(msg)
+            sys.stderr.write("lightning_asr_amd: " + msg + "\n")
+            sys.stderr.flush()
+            os._exit(3)
+        time.sleep(0.002)

@@ -67,6 +67,45 @@ __global__ void sum_kernel(Ptrs src, int world, float* out, size_t n) {
 
 ncclResult_t hip2nccl(hipError_t e) { return e == hipSuccess ? ncclSuccess : ncclUnhandledCudaError; }
 
+// ---- CU-holding mode (what does sharing the CUs with RCCL's channel kernels cost the backward?) -------------------------
+// Real RCCL keeps one persistent workgroup per channel resident for as long as a bucket is on the wire.  With
+//   LASR_STUB_HOLD_CUS=n        every all-reduce is accompanied, on the same stream, by a kernel of n workgroups of 256 threads that
+//                               each claim LASR_STUB_HOLD_LDS_KB of LDS (default 96: more than half a CU's 160 KB, so the n workgroups
+//                               sit on n DIFFERENT CUs and no 144 KB GEMM / depthwise workgroup fits beside one - the pessimistic
+//                               model of a channel kernel) and spin on the constant-rate clock for the time the
+//   LASR_STUB_WIRE_GBS=g        payload would spend on the wire at algorithm bandwidth g GB/s (default 85: ~150 GB/s bus bandwidth on
+//   LASR_STUB_LAT_US=l          a ring of 8) plus l microseconds of latency (default 20)
+// - also on a 1-rank communicator, so bench.py's LASR_FORCE_OVERLAP=1 step on ONE GPU prices the interference for n = 8 .. 64.
+// Every wave leaves the loop when the clock says so: the grid always drains.
+int env_int(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
+double env_dbl(const char* k, double dflt) { const char* v = getenv(k); return v ? atof(v) : dflt; }
+
+__global__ __launch_bounds__(256) void hold_kernel(long long ticks, float* sink) {
+  extern __shared__ float lds[];
+  const long long t0 = wall_clock64();               // constant 100 MHz counter
+  float acc = 0.f;
+  lds[threadIdx.x] = (float)threadIdx.x;
+  while (wall_clock64() - t0 < ticks) {
+    acc += lds[(threadIdx.x * 7 + (int)acc) & 255];  // a little LDS + VALU traffic, like a copy loop between its network waits
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (acc == -1.f) sink[0] = acc;                    // (never true: keeps the loop)
+}
+
+hipError_t hold_cus(size_t bytes, hipStream_t st) {
+  static const int n = env_int("LASR_STUB_HOLD_CUS", 0);
+  if (n <= 0) return hipSuccess;
+  static const double gbs = env_dbl("LASR_STUB_WIRE_GBS", 85.0), lat = env_dbl("LASR_STUB_LAT_US", 20.0);
+  static const int lds_kb = env_int("LASR_STUB_HOLD_LDS_KB", 96);
+  static float* sink = nullptr;
+  if (!sink && hipMalloc(&sink, 256) != hipSuccess) return hipErrorOutOfMemory;
+  const double us = lat + (double)bytes / (gbs * 1e3);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(hold_kernel, dim3(n), dim3(256), (size_t)lds_kb * 1024, st, (long long)(us * 100.0), sink);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -126,9 +165,10 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
   StubComm* c = reinterpret_cast<StubComm*>(comm);
   if (!c || dt != ncclFloat32 || op != ncclSum) return ncclInvalidArgument;
   if (c->world == 1) {
-    if (send != recv) return hip2nccl(hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, st));
-    return ncclSuccess;
+    if (send != recv) { hipError_t e = hipMemcpyAsync(recv, send, count * sizeof(float), hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return hip2nccl(e); }
+    return hip2nccl(hold_cus(count * sizeof(float), st));
   }
+  { hipError_t e = hold_cus(count * sizeof(float), st); if (e != hipSuccess) return hip2nccl(e); }
   const size_t chunk = kStageBytes / sizeof(float);
   for (size_t off = 0; off < count; off += chunk) {
     const size_t n = count - off < chunk ? count - off : chunk;

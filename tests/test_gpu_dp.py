@@ -578,3 +578,39 @@ def test_staged_step_with_real_rccl_replays_from_a_graph_one_rank(dev, monkeypat
         out.append(m.params.clone())
     assert torch.equal(out[0], out[1])
     comm.close()
+
+
+def test_bench_two_ranks_over_stub_prints_the_comm_record(dev, tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), rehearsed on ONE GPU over the
+    stand-in for librccl in its CU-holding mode: the N > 1 line must explain itself - which path carried the exchange, graph or
+    eager, per-bucket all-reduce time on the side stream, and the wait the optimiser's stream was actually exposed to (VERDICT r3 #1c).
+    The first replay of the captured step passes the watchdog."""
+    import json
+    import subprocess
+    import sys
+    assert os.path.exists(STUB), "build tests/stub_rccl/libstubrccl.so (make)"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LASR_BENCH_BACKEND="gloo", LASR_RCCL_PATH=STUB, LASR_STUB_HOLD_CUS="8", LASR_DP_BUCKETS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LASR_COMM", "LASR_GRAPH_DP", "LASR_FORCE_OVERLAP"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--batch", "8"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["hip_graph"] is True
+    c = d["comm"]
+    assert c["path"].startswith("lasr_comm") and c["world"] == 2 and c["staged_backward"] and c["buckets_per_step"] == 2
+    assert c["timed_region_launch"].startswith("hipGraph")
+    assert len(c["buckets"]) == 2
+    assert c["buckets"][0]["mb"] > c["buckets"][1]["mb"] > 1.0             # 17.8 MB, then 3.4 MB (reverse layer order)
+    assert abs(sum(b["mb"] for b in c["buckets"]) - 4 * 5044572 / 1e6) < 1e-3
+    # the stand-in holds its CUs for latency + bytes / wire bandwidth: the bracket on the side stream cannot be shorter
+    for b in c["buckets"]:
+        assert b["allreduce_us"] >= 20.0 + b["mb"] * 1e3 / 85.0 - 1.0, b
+    assert c["exposed_wait_us_per_step"] is not None and c["exposed_wait_us_per_step"] >= 0.0
+    assert "trainer" not in d and "cpu_baseline" not in d                     # one-GPU extras stay out of the N > 1 line

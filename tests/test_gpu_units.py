@@ -108,6 +108,10 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     def note(unit, kind, key, val):
         report["units"].setdefault(unit, {})[key] = val
         worst[kind] = max(worst[kind], val)
+        if os.environ.get("LASR_UNITS_NOASSERT"):          # diagnosis: collect the whole report, fail at the end
+            if val >= tol[kind]:
+                report.setdefault("over_tolerance", []).append((unit, key, val, tol[kind]))
+            return
         assert val < tol[kind], (tag, unit, key, val, tol[kind])
 
     def grad_of(name, c):
@@ -180,6 +184,11 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     for k, g in rh["grads"].items():
         note("head", "grad_param", "d." + k, rel_l2(gpu_grads[k], g.float()))
     report["worst"] = worst
+    if report.get("over_tolerance"):
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/unit_parity_%s.json" % tag, "w") as f:
+            json.dump(report, f, indent=1)
+        raise AssertionError((tag, report["over_tolerance"]))
     # end to end: the emulated oracle's own whole forward from the same features (loss only: see the module docstring)
     o2 = E.Bf16OracleModel(variant, n_class, mask=True, act=act, state={k: v.clone() for k, v in state.items()}, dtype=oracle_dtype,
                            emulate=(mode == "bf16"))
