@@ -572,6 +572,15 @@ def main():
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
             else:
                 traffic_src = "stale: %s was measured on build %s, this is %s" % (os.path.relpath(tpath, ROOT), tj.get("source_id"), source_id())
+        # whole-step traffic at the L2s' memory side (every kernel; same two PMC passes, tools/pmc_traffic.py::whole_step)
+        step_traffic, step_traffic_src = None, None
+        spath = os.path.join(ROOT, "profiles", "step_traffic_%s_%s.json" % (args.config, args.dtype))
+        if os.path.exists(spath):
+            sj = json.load(open(spath))
+            if sj.get("source_id") == source_id():
+                step_traffic, step_traffic_src = sj.get("traffic_mb_per_step"), os.path.relpath(spath, ROOT)
+            else:
+                step_traffic_src = "stale: %s was measured on build %s, this is %s" % (os.path.relpath(spath, ROOT), sj.get("source_id"), source_id())
         if args.dtype == "f32":
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
@@ -594,6 +603,7 @@ def main():
                          "algorithmic_gflop_per_step": gemm_fl / n_prof / 1e9, "algorithmic_mb_per_step": gemm_by / n_prof / 1e6,
                          "mfma_frac": gemm_fl / (gemm_ms * 1e-3) / 1e12 / (PEAK_BF16_MFMA_TF if args.dtype == "bf16" else PEAK_F32_MFMA_TF),
                          "step_frac": step_gbs / PEAK_HBM_GBS, "step_achieved_gbs": step_gbs, "step_algorithmic_mb": step_bytes / 1e6,
+                         "step_traffic_mb": step_traffic, "step_traffic_source": step_traffic_src,
                          "classes": classes,
                          "classes_note": "HIP-event brackets inside liblasr during %d extra eager steps (times include ~event_overhead_us "
                                          "per bracket; a BN bracket spans the 2-3 launches of a unit's pass)" % n_prof,

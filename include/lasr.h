@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define LASR_VERSION 102   /* 101: lasr_mel_fwd_src / lasr_wav_read_batch / lasr_step_metrics / lasr_model_set_prefetch_src
-                              102: LASR_LEN_LEAD (crop after pre-emphasis), lasr_wav_read_batch(lead_in), lasr_train_tail, lasr_comm_* timing */
+                              102: LASR_LEN_LEAD (crop after pre-emphasis), lasr_wav_read_batch(lead_in), lasr_comm_timing* */
 
 enum { LASR_F32 = 0, LASR_BF16 = 1 };
 enum { LASR_ACT_NONE = 0, LASR_ACT_RELU = 1, LASR_ACT_SWISH = 2 };
@@ -440,7 +440,7 @@ int64_t lasr_model_param_elems(const lasr_model_t* m);
 int64_t lasr_model_buffer_elems(const lasr_model_t* m);
 int64_t lasr_model_out_frames(const lasr_model_t* m, int64_t T_in);
 size_t lasr_model_workspace_bytes(lasr_model_t* m, int64_t B, int64_t T_in, int64_t S_max);
-/* Named intermediate ("tap": unit name, "<unit>.y", "<unit>.y2", "<unit>.u", "ctx_in", "logits", "grad_logits", "lens";
+/* Named intermediate ("tap": unit name, "<unit>.y", "<unit>.y2", "<unit>.u", "<unit>.se_hidden" (f32 [B][1][C/8]), "ctx_in", "logits", "grad_logits", "lens";
  * after a staged backward call "bwd.g_cur" = d(input of the last unit processed), "bwd.g_prev" = d(its output), both
  * [N][c] at the head of an [N][cmax] allocation) inside the workspace: returns its byte offset, or -1.            */
 int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, int64_t T_in, int64_t S_max, int64_t shape[3]);

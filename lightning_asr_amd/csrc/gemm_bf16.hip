@@ -871,7 +871,10 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
   static const int big_min = getenv("LASR_GEMM_BIG_MIN_TILES") ? atoi(getenv("LASR_GEMM_BIG_MIN_TILES")) : 120;
   int64_t nmax = 0;
   for (int i = 0; i < n; ++i) nmax = std::max<int64_t>(nmax, g[i].N);
-  const bool narrow = nmax <= 256;          // 256x128 tiles: two tile columns for the 256-channel layers
+  // LASR_GEMM_FORCE_NARROW=1: 256x128 tiles for the wide layers too (504 workgroups, two rounds on an idle chip).  A/B switch for the
+  // N > 1 step: beside RCCL's channel kernels a 252-tile launch runs two rounds as soon as 5 CUs are taken
+  static const bool force_narrow = getenv("LASR_GEMM_FORCE_NARROW") && atoi(getenv("LASR_GEMM_FORCE_NARROW")) != 0;
+  const bool narrow = nmax <= 256 || force_narrow;          // 256x128 tiles: two tile columns for the 256-channel layers
   const int btn = narrow ? 128 : 256;
   int64_t big_tiles = 0;
   for (int i = 0; i < n; ++i) big_tiles += cdiv(g[i].M, big::BTM) * cdiv(g[i].N, btn) * gz[i];

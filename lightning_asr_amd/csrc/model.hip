@@ -416,6 +416,7 @@ extern "C" int64_t lasr_model_tap(lasr_model_t* m, const char* name, int64_t B, 
     if (n == u.tap + ".y") { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_y; }
     if (n == u.tap + ".y2" && u.has_res) { shape[0] = B; shape[1] = p.T; shape[2] = u.co; return (int64_t)u.o_y2; }
     if (n == u.tap + ".u" && u.has_dw) { shape[0] = B; shape[1] = p.T; shape[2] = u.ci; return (int64_t)u.o_u; }
+    if (n == u.tap + ".se_hidden" && u.has_se) { shape[0] = B; shape[1] = 1; shape[2] = u.co / 8; return (int64_t)u.o_se_hid; }   // f32: relu(W1 pooled)
   }
   // gradient ping-pong buffers of the (staged) backward: after a stage that ended at unit i, "bwd.g_cur" holds d(input of unit i)
   // and "bwd.g_prev" still holds d(output of unit i); both are [N][c] tensors at the head of an [N][cmax] allocation

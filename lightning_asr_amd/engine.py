@@ -248,7 +248,7 @@ class NativeModel:
         if off < 0:
             raise KeyError(name)
         shp = tuple(shape[i] for i in range(3))
-        if name in ("logits", "grad_logits", "lse"):
+        if name in ("logits", "grad_logits", "lse") or name.endswith(".se_hidden"):
             dt = torch.float32
         elif name == "lens":
             return self._ws[off:off + 4 * B].view(torch.int32)

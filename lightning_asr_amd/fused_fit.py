@@ -189,10 +189,13 @@ class FusedLoop:
     def step(self, cur: DevBatch, nxt: Optional[DevBatch], batch_idx: int):
         ts, native = self.ts, self.native
         stream = torch.cuda.current_stream()
-        for b in (cur, nxt):          # once per batch, and not at all when its copies have already completed (issued two steps ahead)
+        for b in (cur, nxt):          # once per batch: the compute stream is ordered behind the batch's H2D copies (issued two steps ahead)
             if b is not None and not b.waited:
                 b.waited = True
-                if b.ready is not None and not b.ready.query():
+                # (no `ready.query()` first: hipEventQuery drains the runtime's pending submissions - measured 1.13 ms of host time
+                #  per call here, half of the whole step's enqueue time, profiles/r04_trainer_host_profile.txt; a wait on an event
+                #  that has already completed costs the stream nothing)
+                if b.ready is not None:
                     stream.wait_event(b.ready)
         if self.on_host_batch is not None:
             self.on_host_batch(cur)

@@ -115,6 +115,7 @@ class Bf16OracleModel(R.OracleModel):
         self.drop = None              # (keep mask (B, C, T) of the unit being run, 1/(1-p)): the GPU's own mask (run_unit)
         self.lean_head = False        # large-vocabulary head of csrc/ctc_lean.hip: the logits themselves are a bf16 tensor
         self.forced_mask: Optional[torch.Tensor] = None      # consumed by the next activation (run_unit)
+        self.forced_se_mask: Optional[torch.Tensor] = None   # (B, C/8) derivative mask of the SE MLP's inner ReLU, consumed by the next _sep
         for k, v in self.state.items():
             if v.is_floating_point():
                 # BatchNorm always in f64: its backward subtracts the two largest components of the incoming gradient, and
@@ -170,7 +171,13 @@ class Bf16OracleModel(R.OracleModel):
         z = self._bn(y, prefix + ".bn")
         if self.variant == "context_se":
             pooled = z.mean(dim=2)
-            g = torch.sigmoid(F.linear(F.relu(F.linear(pooled, s[prefix + ".se.fc.0.weight"])), s[prefix + ".se.fc.2.weight"]))
+            h = F.linear(pooled, s[prefix + ".se.fc.0.weight"])
+            if self.forced_se_mask is not None:      # the SE MLP's own ReLU (models/QuartNetContextSE.py:14) has the same near-zero
+                sm, self.forced_se_mask = self.forced_se_mask, None     # ambiguity as the unit's: B x C/8 values, ONE flip = 3e-2 of dW1
+                h = _ActForcedMask.apply(h, sm)
+            else:
+                h = F.relu(h)
+            g = torch.sigmoid(F.linear(h, s[prefix + ".se.fc.2.weight"]))
             z = z * g.unsqueeze(2)
         if not last:
             return self.st(self._dropout(self._act(z)))
@@ -291,12 +298,13 @@ def _unit_params(model: R.OracleModel, prefixes) -> Dict[str, torch.Tensor]:
 
 
 def run_unit(model: Bf16OracleModel, unit: str, x_in: torch.Tensor, lens: torch.Tensor, dout: Optional[torch.Tensor],
-             act_mask: Optional[torch.Tensor] = None, drop=None):
+             act_mask: Optional[torch.Tensor] = None, drop=None, se_mask: Optional[torch.Tensor] = None):
     """One unit of the plan from ITS OWN stored input: forward (training-mode BN) and, if ``dout`` is given, backward.
     act_mask: the GPU's `out > 0` (ReLU derivative; see _ActForcedMask).
     Returns {"u","y","y2","out","dx", "grads": {key: tensor}} (absent entries omitted)."""
     model.training, model.keep_taps, model.taps = True, True, {}
     model.forced_mask = act_mask
+    model.forced_se_mask = se_mask    # the GPU's own `se_hidden > 0` (B, C/8), SE units only
     model.drop = drop                 # (keep mask (B, C, T), 1/(1-p)) or None
     params = _unit_params(model, _prefixes(model.variant, unit))
     for p in params.values():
@@ -326,6 +334,7 @@ def run_unit(model: Bf16OracleModel, unit: str, x_in: torch.Tensor, lens: torch.
         p.requires_grad_(False)
         p.grad = None
     model.keep_taps, model.taps, model.drop = False, {}, None
+    model.forced_mask = model.forced_se_mask = None
     return res
 
 

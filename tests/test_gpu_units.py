@@ -144,7 +144,11 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         # ReLU: derivative mask from the GPU's output.  With dropout it is still right where it matters: a residual unit drops before
         # the add (out > 0 <=> z > 0), first_cnn / last_cnn2 drop after the activation and a dropped element's gradient is zero anyway.
         # Swish (smooth: no element can change sides): the oracle differentiates its OWN pre-activation z, nothing is taken from the GPU
-        r = E.run_unit(o, name, x_in, lens, dout, act_mask=(out_gpu > 0) if act == "relu" else None, drop=drop)
+        # SE units: the excite MLP's inner ReLU (B x C/8 values per unit) gets the same treatment - its derivative mask is the GPU's own
+        # `se_hidden > 0`.  Measured without it (context_se, Swish epilogues, where nothing else can flip): ONE hidden unit on the other
+        # side of zero = 3.0e-2 of d(fc.0.weight) and 3.9e-3 of d(bn.bias) in that unit, everything else of the model at <= 5e-4
+        se_mask = (m.tap(name + ".se_hidden").view(B, -1).cpu() > 0) if (variant == "context_se" and name != "last_cnn2") else None
+        r = E.run_unit(o, name, x_in, lens, dout, act_mask=(out_gpu > 0) if act == "relu" else None, drop=drop, se_mask=se_mask)
         note(name, "act", "out", rel_l2(out_gpu, r["out"]))
         note(name, "act", "y", rel_l2(_bct(m.tap(name + ".y")), r["y"]))
         if "u" in r:

@@ -13,5 +13,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
       > $root/gpurun_out/pmc_${cfg}_$c.log 2>&1 || { tail -5 $root/gpurun_out/pmc_${cfg}_$c.log; exit 1; }
 done
 mkdir -p $root/profiles
-python3 $root/tools/pmc_traffic.py $root/gpurun_out/pmc_${cfg}_FETCH_SIZE $root/gpurun_out/pmc_${cfg}_WRITE_SIZE gemm_bf16 $root/gpurun_out/gemm_traffic_${cfg}_${dtype}.json $cfg
+python3 $root/tools/pmc_traffic.py $root/gpurun_out/pmc_${cfg}_FETCH_SIZE $root/gpurun_out/pmc_${cfg}_WRITE_SIZE gemm_bf16 $root/gpurun_out/gemm_traffic_${cfg}_${dtype}.json $cfg $root/gpurun_out/step_traffic_${cfg}_${dtype}.json
 rm -rf $root/gpurun_out/pmc_${cfg}_FETCH_SIZE $root/gpurun_out/pmc_${cfg}_WRITE_SIZE
