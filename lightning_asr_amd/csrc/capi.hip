@@ -31,6 +31,7 @@ extern "C" const char* lasr_last_error(void) { return lasr::g_err; }
 // stream they are launched on; lasr_prof_collect() synchronises the events and returns the sums.
 #include <vector>
 namespace lasr {
+static constexpr int kNtLoadsDefault = 0;      // (set from the same-call A/B of round 4: profiles/r04_nt_loads.txt)
 struct ProfRec { hipEvent_t a, b; int kind; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -54,6 +55,13 @@ int prof_begin(int kind, hipStream_t st, double flops, double bytes) {
 }
 void prof_end(int token, hipStream_t st) {
   if (token >= 0 && token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, st);
+}
+}  // namespace lasr
+
+namespace lasr {
+int nt_loads_mask() {
+  static const int v = getenv("LASR_NT_LOADS") ? atoi(getenv("LASR_NT_LOADS")) : kNtLoadsDefault;
+  return v;
 }
 }  // namespace lasr
 

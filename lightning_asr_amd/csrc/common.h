@@ -107,6 +107,20 @@ template <>
 struct Vec<bf16_t> {
   static constexpr int kN = 8;
   __device__ static __forceinline__ uint4 raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  // 16 bytes with the non-temporal hint (global_load_dwordx4 ... nt): for tensors read ONCE, long after they were written (the forward
+  // tensors the backward re-reads).  Measured on this machine (tools/micro/hbm_bw.hip, profiles/r04_hbm_bw.txt): a 96 MB tensor read
+  // back after 1.5 GB of other read + write traffic takes 32.5 us with default loads and 21.8 us with nt loads - a default load
+  // allocates its line in the memory-side cache, which by then is full of dirty lines that have to be written back first.
+  template <bool NTL>
+  __device__ static __forceinline__ uint4 raw_if_nt(const bf16_t* p) {
+    if constexpr (NTL) {
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+      return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+      return *reinterpret_cast<const uint4*>(p);
+    }
+  }
   __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[8]) {
     o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
     o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -129,6 +143,11 @@ struct Vec<bf16_t> {
 // out1[i - split] (out1 may be null).  One launch, 32 columns x 8 partial lanes per block (norm.hip).
 int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, float* out0, int64_t split, float* out1,
                            hipStream_t st);
+
+// LASR_NT_LOADS: bit mask of the backward kernels that read their COLD operands (forward tensors saved for backward) with
+// non-temporal loads: 1 = BN backward statistics (y, y2), 2 = BN backward apply (y, y2), 4 = depthwise backward (x),
+// 8 = stage-batched 1x1 weight gradients (dy, dy2, u, x).  Default: see nt_loads_mask() in capi.hip (measured per site).
+int nt_loads_mask();
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every outstanding GLOBAL load and store
 // of the wave must retire before the barrier (workgroup-scope release of global memory).  Inside a per-time-step recurrence

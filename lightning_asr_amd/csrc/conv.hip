@@ -1085,7 +1085,7 @@ struct DwUni {
   int Tlen, C, k, gx, B, gz, total;
 };
 
-template <int NKS, int NW>
+template <int NKS, int NW, bool NTL = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kernel(DwUni a) {
   using K = dwu::Cfg<NKS, NW>;
   using namespace dwu;
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
         const bool ok = t >= 0 && t < Tlen && cc < C;
         const size_t off = (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8);
         const uint4 l0 = *reinterpret_cast<const uint4*>(db + off);
-        const uint4 l1 = *reinterpret_cast<const uint4*>(xb + off);
+        const uint4 l1 = Vec<bf16_t>::raw_if_nt<NTL>(xb + off);      // the unit's forward input: written ~1.5 ms and > 2 GB of traffic ago
         const uint32_t mk = ok ? 0xffffffffu : 0u;
         vd[r][h] = make_uint4(l0.x & mk, l0.y & mk, l0.z & mk, l0.w & mk);
         vx[r][h] = make_uint4(l1.x & mk, l1.y & mk, l1.z & mk, l1.w & mk);
@@ -1567,16 +1567,19 @@ extern "C" int lasr_dwconv_bwd_fused(const void* x, const void* dy, const float*
       u.gz = gz;
       u.total = (int)(u.gx * B * gz);
       const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 4.0 * (double)B * T * C * k, (double)B * T * C * (addend ? 4 : 3) * 2);
-#define LASR_DWU(N_, W_)                                                                                                          \
+      const bool ntl = (nt_loads_mask() & 4) != 0;
+#define LASR_DWU(N_, W_) do { if (ntl) LASR_DWU2(N_, W_, true); else LASR_DWU2(N_, W_, false); } while (0)
+#define LASR_DWU2(N_, W_, NT_)                                                                                                    \
   do {                                                                                                                            \
     using Kc = dwu::Cfg<N_, W_>;                                                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_bwd_uni_kernel<N_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_bwd_uni_kernel<N_, W_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     const unsigned grid = (unsigned)((u.total + 15) / 16 * 16);                                                                     \
-    hipLaunchKernelGGL((dwconv_bwd_uni_kernel<N_, W_>), dim3(grid), dim3(64 * W_), Kc::SMEM, as_stream(stream), u);                  \
+    hipLaunchKernelGGL((dwconv_bwd_uni_kernel<N_, W_, NT_>), dim3(grid), dim3(64 * W_), Kc::SMEM, as_stream(stream), u);             \
   } while (0)
       if (u32) { if (nks == 1) LASR_DWU(1, 4); else if (nks == 2) LASR_DWU(2, 4); else LASR_DWU(3, 4); }
       else { if (nks == 1) LASR_DWU(1, 8); else if (nks == 2) LASR_DWU(2, 8); else if (nks == 3) LASR_DWU(3, 8); else LASR_DWU(4, 8); }
 #undef LASR_DWU
+#undef LASR_DWU2
       prof_end(tok, as_stream(stream));
       LASR_LAUNCH_CHECK("dwconv_bwd_uni_kernel");
       *n_partials = (int)B * gz;

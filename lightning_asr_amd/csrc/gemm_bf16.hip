@@ -66,7 +66,7 @@ __device__ __forceinline__ uint4 mask_chunk(const uint4& v, int nvalid) {
   return make_uint4(v.x & dm(0), v.y & dm(1), v.z & dm(2), v.w & dm(3));
 }
 
-template <bool TRANS, int ROWS, int NT, int NCH = 4>
+template <bool TRANS, int ROWS, int NT, int NCH = 4, bool NTL = false>
 __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, uint4 (&reg)[NCH]) {
   constexpr int RCH = ROWS / 8;
   const int tid = threadIdx.x;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, i
     uint32_t off;
     if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), ((kend + 7) & ~7) - 8);
     else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), ((R + 7) & ~7) - 8);
-    reg[p] = *reinterpret_cast<const uint4*>(X + off);
+    reg[p] = Vec<bf16_t>::raw_if_nt<NTL>(X + off);
   }
 }
 
@@ -96,14 +96,14 @@ __device__ __forceinline__ void store_vec(char* __restrict__ s, const uint4 (&re
 }
 
 // single-chunk forms (chunk p of the thread), for K loops that spread the staging between MFMA groups
-template <bool TRANS, int ROWS, int NT>
+template <bool TRANS, int ROWS, int NT, bool NTL = false>
 __device__ __forceinline__ uint4 load_chunk(const bf16_t* __restrict__ X, int ld, int R, int r0, int k0, int kend, int p) {
   constexpr int RCH = ROWS / 8;
   const int c = threadIdx.x + NT * p;
   uint32_t off;
   if (!TRANS) off = (uint32_t)min(r0 + (c >> 3), R - 1) * (uint32_t)ld + (uint32_t)min(k0 + ((c & 7) << 3), ((kend + 7) & ~7) - 8);
   else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), ((R + 7) & ~7) - 8);
-  return *reinterpret_cast<const uint4*>(X + off);
+  return Vec<bf16_t>::raw_if_nt<NTL>(X + off);
 }
 template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_>
 __device__ __forceinline__ void store_chunk(char* __restrict__ s, const uint4& v, int k0, int kend, int p) {
@@ -495,7 +495,7 @@ __device__ __forceinline__ uint4 load_chunk_dual(const Bf16Args& g, int m0, int 
   return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
 }
 
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false>
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false, bool NTL = false>
 __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char* __restrict__ sB, char* __restrict__ dA,
                                          char* __restrict__ dB, f32x16 (&acc)[big::Cfg<NARROW>::MI][2], uint4 (&ra)[4],
                                          uint4 (&rb)[big::Cfg<NARROW>::NCB], const Bf16Args& g, int m0, int n0, int k_store,
@@ -533,9 +533,9 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
     }
     if constexpr (LOAD) {
       if constexpr (DUAL) ra[ks] = load_chunk_dual(g, m0, k_load, ks, kma);
-      else ra[ks] = load_chunk<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, k_load, kend, ks);
-      if constexpr (CF::NCB == 4) rb[ks] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
-      else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
+      else ra[ks] = load_chunk<TRANS_A, BTM, NT, NTL>(g.A, g.lda, g.M, m0, k_load, kend, ks);
+      if constexpr (CF::NCB == 4) rb[ks] = load_chunk<TRANS_B, CF::BN, NT, NTL>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
+      else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT, NTL>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
     }
   }
 }
@@ -551,7 +551,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 
 // one 256 x 256 (256 x 128) output tile `lid` of problem g; SLAB: split-K slice into the f32 slab g.split_ws (no LDS image,
 // no statistics) - shared by the two-problem kernel and the many-problem weight-gradient kernel
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB, bool DUAL = false>
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB, bool DUAL = false, bool NTL = false>
 __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int lid) {
 #ifdef LASR_GEMM_STAMPS
   unsigned long long* stamps = g_stamps;
@@ -602,9 +602,9 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
 #pragma unroll
     for (int p = 0; p < 4; ++p) ra[p] = load_chunk_dual(g, m0, kbeg, p, kma);
   } else {
-    load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
+    load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
   }
-  load_vec<TRANS_B, BTN, NT, CF::NCB>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
+  load_vec<TRANS_B, BTN, NT, CF::NCB, NTL>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
   store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
   store_vec<TRANS_B, BTN, NT, LD_KC, CF::LDRB, CF::NCB>(smem + OPER, rb, kbeg, kend);
   if (nk > 1) {
@@ -612,9 +612,9 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
 #pragma unroll
       for (int p = 0; p < 4; ++p) ra[p] = load_chunk_dual(g, m0, kbeg + TK, p, kma);
     } else {
-      load_vec<TRANS_A, BTM, NT>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
+      load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
     }
-    load_vec<TRANS_B, BTN, NT, CF::NCB>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
+    load_vec<TRANS_B, BTN, NT, CF::NCB, NTL>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
   }
   __syncthreads();
   LASR_STAMP(1);
@@ -624,7 +624,7 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     for (; it + 2 < nk; ++it) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
+      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL, NTL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
                                              kbeg + (it + 2) * TK, kend, wm, wn, lane, kma);
       __syncthreads();
     }
@@ -836,11 +836,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dual_kernel(Bf16Batch gb) {
 // The stage-batched 1x1 weight gradients on the 256 x 256 tile: C_i = A_i^T B_i with A_i [K][M_i], B_i [K][N_i]
 // (K = B*T' = 16 032 rows of dy and of the layer input), split-K slices into f32 slabs.  One workgroup per CU and
 // slice; the K loop of this tile runs at ~1.3 PFLOP/s against ~0.7 for the 128 x 128 form.
+// NTL: operand loads with the non-temporal hint - every operand of a stage's weight gradients (dy, dy2, u, x of all its units) is read
+// here for the last time, most of it cold; the slabs this launch WRITES are what the reduction right behind it reads
+template <bool NTL>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi gm) {
   const int lid_all = xcd_remap(blockIdx.x, gm.total);
   int i = 0;
   while (i + 1 < gm.n && gm.start[i + 1] <= lid_all) ++i;   // workgroup-uniform scan of at most 32 entries
-  gemm_bf16_big_tile<true, true, false, true>(gm.p[i], lid_all - gm.start[i]);
+  gemm_bf16_big_tile<true, true, false, true, false, NTL>(gm.p[i], lid_all - gm.start[i]);
 }
 
 static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
@@ -978,7 +981,8 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
   m.n = n; m.total = total;
   if (big_tile) {
     if (!vec) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: the 256-row tile needs 16-byte aligned operand rows");
-    hipLaunchKernelGGL(gemm_bf16_big_multi_kernel, dim3((unsigned)total), dim3(big::NT), 0, st, m);
+    if (nt_loads_mask() & 8) hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<true>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
+    else hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<false>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
     LASR_LAUNCH_CHECK("gemm_bf16_big_multi_kernel");
     return 0;
   }

@@ -554,7 +554,7 @@ static constexpr int kSlCh = 64, kSlThreads = 512, kSlLanes = 64;
 // SE (ContextSE units): a chunk is one utterance (rpc = T'), so the excite scale of the thread's 8 channels is a register constant
 // and the partial rows ARE the per-utterance sums P[b][4][C] the excite backward starts from (sums of the gradient at the BN
 // output without the SE factors, as bn_bwd_stats_kernel(per_utt)).
-template <bool HAS2, bool SE>
+template <bool HAS2, bool SE, bool NTL = false>
 __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                   const float* __restrict__ coef, const float* __restrict__ saved,
                                                                   const bf16_t* __restrict__ y2, const float* __restrict__ coef2,
@@ -585,9 +585,9 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const uint32_t off = (uint32_t)min(rb + i * kSlLanes, rows - 1) * (uint32_t)C + (uint32_t)c;
-      rd[i] = Vec<bf16_t>::raw(dout + off);
-      ry[i] = Vec<bf16_t>::raw(y + off);
-      if (HAS2) rr[i] = Vec<bf16_t>::raw(y2 + off);
+      rd[i] = Vec<bf16_t>::raw(dout + off);                     // (written a moment ago by the unit above: default policy)
+      ry[i] = Vec<bf16_t>::raw_if_nt<NTL>(y + off);
+      if (HAS2) rr[i] = Vec<bf16_t>::raw_if_nt<NTL>(y2 + off);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
 // utterance's scale and pooled-path gradient as register constants (a chunk is one utterance).
 // RB: rows in flight per thread; WPE: waves per SIMD the register allocation must leave room for (2 = one 512-thread workgroup per
 // CU, 4 = two).
-template <bool HAS2, bool SE, int RB = 2, int WPE = 2>
+template <bool HAS2, bool SE, int RB = 2, int WPE = 2, bool NTL = false>
 __global__ __launch_bounds__(512, WPE) void bn_bwd_apply_sliced_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                                   const bf16_t* __restrict__ y2, const float* __restrict__ partials,
                                                                   int nchunk, const float* __restrict__ tab_in, const float* __restrict__ se,
@@ -710,8 +710,8 @@ __global__ __launch_bounds__(512, WPE) void bn_bwd_apply_sliced_kernel(const bf1
     for (int u = 0; u < RB; ++u) {
       off[u] = (uint32_t)min(rb + u * kSlLanes, rows - 1) * (uint32_t)C + (uint32_t)c;
       rd[u] = Vec<bf16_t>::raw(dout + off[u]);
-      ry[u] = Vec<bf16_t>::raw(y + off[u]);
-      if (HAS2) rr2[u] = Vec<bf16_t>::raw(y2 + off[u]);
+      ry[u] = Vec<bf16_t>::raw_if_nt<NTL>(y + off[u]);
+      if (HAS2) rr2[u] = Vec<bf16_t>::raw_if_nt<NTL>(y2 + off[u]);
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
@@ -957,10 +957,13 @@ static int bn_bwd_stats_impl(const void* dout, const void* y, const float* coef,
   if (const int rpc = bn_sliced_rpc(dtype, rows, C, se_scale != nullptr, da.step != nullptr, per_utt, sums != nullptr)) {
     const dim3 grid((unsigned)(C / kSlCh), (unsigned)cdiv(rows, rpc));
     float* partials = reinterpret_cast<float*>(workspace);
-    if (y2) hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<true, false>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
-                               coef, saved, (const bf16_t*)y2, coef2, saved2, nullptr, partials, (int)rows, (int)C, act, rpc);
-    else hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<false, false>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, (const bf16_t*)y,
-                            coef, saved, (const bf16_t*)y2, coef2, saved2, nullptr, partials, (int)rows, (int)C, act, rpc);
+#define LASR_STATS_SL(H2_, NT_)                                                                                                         \
+  hipLaunchKernelGGL((bn_bwd_stats_sliced_kernel<H2_, false, NT_>), grid, dim3(kSlThreads), 0, as_stream(stream), (const bf16_t*)dout, \
+                     (const bf16_t*)y, coef, saved, (const bf16_t*)y2, coef2, saved2, nullptr, partials, (int)rows, (int)C, act, rpc)
+    const bool ntl = (nt_loads_mask() & 1) != 0;
+    if (y2) { if (ntl) LASR_STATS_SL(true, true); else LASR_STATS_SL(true, false); }
+    else { if (ntl) LASR_STATS_SL(false, true); else LASR_STATS_SL(false, false); }
+#undef LASR_STATS_SL
     LASR_LAUNCH_CHECK("bn_bwd_stats_sliced_kernel");
     return 0;
   }
@@ -1031,8 +1034,10 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
     // the cfg2 step, one call: split 1 / 2 / 3 / 4 = 2.228 / 2.191 / 2.220 / 2.235 ms.  (The statistics pass does not gain from the
     // same treatment: 2.219 with both split against 2.198.)  The arithmetic per element is unchanged.
     static const int asplit = getenv("LASR_BN_APPLY_SPLIT") ? atoi(getenv("LASR_BN_APPLY_SPLIT")) : 2;
-#define LASR_APPLY_SL(H2_, RB_, W_, RPC_, G_)                                                                                          \
-  hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<H2_, false, RB_, W_>), G_, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, \
+    const bool ntl = (nt_loads_mask() & 2) != 0;
+#define LASR_APPLY_SL(H2_, RB_, W_, RPC_, G_) do { if (ntl) LASR_APPLY_SL2(H2_, RB_, W_, RPC_, G_, true); else LASR_APPLY_SL2(H2_, RB_, W_, RPC_, G_, false); } while (0)
+#define LASR_APPLY_SL2(H2_, RB_, W_, RPC_, G_, NT_)                                                                                    \
+  hipLaunchKernelGGL((bn_bwd_apply_sliced_kernel<H2_, false, RB_, W_, NT_>), G_, dim3(kSlThreads), 0, st, (const bf16_t*)dout, (const bf16_t*)y, \
                      (const bf16_t*)y2, partials, nchunk, nullptr, nullptr, nullptr, coef, saved, gamma, coef2, saved2, gamma2,          \
                      1.0f / (float)rows, row_lens, (bf16_t*)dy, (bf16_t*)dy2, dgamma, dbeta, dgamma2, dbeta2, (int)rows, (int)T_, (int)C, \
                      act, RPC_)
@@ -1045,6 +1050,7 @@ extern "C" int lasr_bn_act_bwd_apply_drop(const void* dout, const void* y, const
       if (y2) LASR_APPLY_SL(true, 2, 2, rpc, grid); else LASR_APPLY_SL(false, 2, 2, rpc, grid);
     }
 #undef LASR_APPLY_SL
+#undef LASR_APPLY_SL2
     LASR_LAUNCH_CHECK("bn_bwd_apply_sliced_kernel");
     return 0;
   }
