@@ -190,7 +190,10 @@ def test_context_variants_match_golden_f32(dev, variant):
     with torch.no_grad():
         noise = float((om(x, pct).double() - torch.from_numpy(gold["logprobs"]).double()).abs().max())
     rec = argmax_report("%s_golden_f32" % variant, am, lp, gold, noise=noise)
-    assert rec["mismatches"] <= 2 and all(m <= 2 * noise for m in rec["margins_at_mismatches"]), rec
+    # measured on the MI355X (profiles/r04_argmax_margins.json): 0 mismatching frames of 404 for both variants (the gate was
+    # "> 99.5 % agreement" before); smallest reference margin 2.1e-4 / 4.8e-4 against a GPU log-prob error of 1.5e-5: bit-exact
+    assert rec["mismatches"] == 0, rec
+    assert rec["min_margin_all_frames"] > 2 * rec["gpu_logp_max_abs_err"], rec
     ctx = m2.tap("ctx_in")[:, :, 256:].contiguous().cpu()            # the reference module returns (B, T, 80)
     assert np.abs(checksum(ctx) - gold["tap_context_rnn"]).max() < 1e-5
     norms = np.array([m2.view(t, m2.grads).norm().item() for t in m2.param_infos()])
