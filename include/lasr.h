@@ -561,8 +561,9 @@ int lasr_comm_allreduce_ranges(lasr_comm_t* comm, float* base, const int64_t* lo
                                void* producer_stream);
 int lasr_comm_broadcast(lasr_comm_t* comm, float* buf, int64_t count, int root, void* producer_stream);
 int lasr_comm_wait(lasr_comm_t* comm, void* consumer_stream);
-/* lasr_comm_init caps RCCL's channel count (the persistent workgroups a collective keeps resident on the CUs it shares with the
- * backward) unless NCCL_MAX_NCHANNELS is already set: LASR_COMM_MAX_CHANNELS (default 8; 0 = RCCL's own default).
+/* LASR_COMM_MAX_CHANNELS=n (> 0) makes lasr_comm_init set NCCL_MAX_NCHANNELS=n (the persistent workgroups a collective keeps resident
+ * on the CUs it shares with the backward) unless that variable is already set; default 0 = RCCL's own choice (measured: the
+ * interference grows with the LENGTH of the exchange, not with the CUs it holds - DESIGN 5).
  * Timing of the exchange (bench.py's `comm` record; eager launches only): with timing on, every collective is bracketed by events on
  * the side stream and every lasr_comm_wait by events on the consumer stream.  lasr_comm_timing_collect synchronises them and returns,
  * in call order, coll_us[i] / coll_bytes[i] (duration and payload of collective i, peers' arrival included) and wait_us[j] (how long

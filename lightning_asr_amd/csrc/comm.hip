@@ -32,7 +32,7 @@ struct RcclApi {
 };
 
 static RcclApi g_rccl;
-static constexpr int kDefaultMaxChannels = 8;   // see lasr_comm_init
+static constexpr int kDefaultMaxChannels = 0;   // 0 = RCCL's own choice (see lasr_comm_init)
 
 static int load_rccl() {
   if (g_rccl.handle) return 0;
@@ -120,12 +120,12 @@ extern "C" int lasr_comm_init(lasr_comm_t** out, const void* unique_id, size_t i
   LASR_CHECK_ARG(world >= 1 && rank >= 0 && rank < world && device >= 0, "lasr_comm_init: world=%d rank=%d device=%d", world, rank, device);
   LASR_TRY(load_rccl());
   LASR_HIP(hipSetDevice(device), "hipSetDevice");
-  // RCCL's channel count = the number of persistent workgroups its collective kernels keep resident for as long as a bucket is on
-  // the wire.  Every hot kernel of the backward is sized as ONE round of workgroups over the 256 CUs, so a CU held by a channel
-  // sends a 252-tile GEMM into a second round (measured on one GPU with the stand-in's CU-holding mode: DESIGN 5, profiles/
-  // r04_cu_sharing.json).  The step needs ~30 GB/s of all-reduce bandwidth to hide its 17.8 MB bucket under half a backward, which
-  // a few channels deliver: cap them unless the user already chose (an NCCL_MAX_NCHANNELS in the environment wins;
-  // LASR_COMM_MAX_CHANNELS=0 leaves RCCL's default).
+  // RCCL's channel count = the number of persistent workgroups its collective kernels keep resident while a bucket is on the wire.
+  // Measured on one GPU with the stand-in's CU-holding mode (profiles/r04_cu_sharing.json): the backward loses the SAME
+  // ~0.11 ms whether 2 or 64 CUs are held and whatever LDS they claim - what costs is a second busy hardware queue for the length of
+  // the window (+0.09 / +0.11 / +0.15 ms for a 0.12 / 0.22 / 0.44 ms window), not the CUs taken.  So the exchange should be as SHORT
+  // as RCCL can make it: no channel cap by default.  LASR_COMM_MAX_CHANNELS=n (> 0) sets NCCL_MAX_NCHANNELS for experiments on the
+  // real fabric; an NCCL_MAX_NCHANNELS already in the environment wins.
   {
     const char* capv = getenv("LASR_COMM_MAX_CHANNELS");
     const int cap = capv ? atoi(capv) : kDefaultMaxChannels;
