@@ -343,7 +343,11 @@ def trainer_path(args, cfg, emit: bool = True, steps=None, warmup=None):
                    "ingest": f.source_kind, "ingest_threads": args.ingest_threads, "train_crop": crop,
                    "hip_graph_steps": f.graph_steps, "eager_steps": f.eager_steps, "lean_head": bool(f.native.lean_head),
                    "host_ms_per_step": {"waiting_for_ingest": 1e3 * f.ingest_wait_s / max(tr.global_step, 1),
-                                        "enqueuing_the_step": 1e3 * f.host_step_s / max(tr.global_step, 1)},
+                                        "enqueuing_the_step": 1e3 * f.host_step_s / max(tr.global_step, 1),
+                                        "enqueue_cpu_time": 1e3 * f.host_cpu_s / max(tr.global_step, 1),
+                                        "note": "enqueuing_the_step is wall time inside FusedLoop.step: once the GPU's queue is full the runtime "
+                                                "makes the thread wait, so a GPU-bound loop reads ~the step time there; enqueue_cpu_time is the "
+                                                "thread's CPU time (time.thread_time) over the same calls"},
                    "included": "wav decode on host threads, int16 H2D, random sub-sequence crop + SpecAugment draws, in-kernel dither, "
                                "per-step greedy decode + edit distance + loss/WER accumulation (train.py:79-81), all of TrainStep",
                    "excluded": "validation, checkpoint writes (epoch-end work; the timed steps sit inside one epoch)"},

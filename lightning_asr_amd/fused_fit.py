@@ -147,7 +147,9 @@ class FusedLoop:
         self.audio_seconds = 0.0
         self.samples_real = self.samples_padded = 0      # padding bookkeeping: sum of valid samples / of B * row pitch
         self.ingest_wait_s = 0.0                         # host time spent waiting for the next batch from the ingest (0 = never starved)
-        self.host_step_s = 0.0                           # host time spent enqueuing steps
+        self.host_step_s = 0.0                           # host WALL time inside step(): includes every moment the runtime made the
+                                                         # thread wait for room in the GPU's queue (a GPU-bound loop shows ~the step time here)
+        self.host_cpu_s = 0.0                            # CPU time of this thread inside step() (time.thread_time): the work the host did
         self.on_host_batch = getattr(trainer, "_fused_on_batch", None)  # test hook: called with every DevBatch before it is trained on
 
     # ---- one step ------------------------------------------------------------------------------------------------------
@@ -271,11 +273,13 @@ class FusedLoop:
                 t0 = time.perf_counter()
                 b = next(it, None)
                 t1 = time.perf_counter()
+                c1 = time.thread_time()
                 if b is not None:
                     window.append(b)
                 self.step(cur, nxt, batch_idx)
                 self.ingest_wait_s += t1 - t0
                 self.host_step_s += time.perf_counter() - t1
+                self.host_cpu_s += time.thread_time() - c1
                 src.release(cur)
                 tr.global_step += 1
                 batch_idx += 1

@@ -151,6 +151,35 @@ def test_trainer_uses_the_lean_head_for_a_large_vocabulary(dev, tmp_path):
     assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0 and np.isfinite(rec["val_loss"])
 
 
+def test_aishell2_labels_take_the_host_cer_path(dev, tmp_path):
+    """data/aishell2-labels.txt (5 206 labels; its first line is a blank, so `c.strip()` at train.py:217 makes label 0 the EMPTY
+    string): C = 5207 through train.main in bf16.  The lean head carries the step (256 <= C <= 9216); the CER units of such a
+    vocabulary are not token ids (an emitted label 0 adds no character to the joined string, utils/asr_metrics.py:215-216), so the
+    metric must take the host path every step - and agree with the reference's definition on a hand-made case."""
+    from lightning_asr_amd.utils.asr_metrics import WER
+    vocab = os.path.join(ROOT, "data", "aishell2-labels.txt")
+    labels = [c.strip() for c in open(vocab, encoding="utf-8").readlines()]
+    assert len(labels) == 5206 and labels[0] == "" and all(len(c) == 1 for c in labels[1:]) and len(set(labels)) == 5206
+    w = WER(labels, use_cer=True)
+    assert not w.device_ok
+    blank = len(labels)
+    ids = torch.tensor([[5, 0, blank, 7, 7, blank, 9]], dtype=torch.int32, device=dev)     # collapses to labels 5, 0 (= ''), 7, 9
+    tg = torch.tensor([[5, 7, 8]])
+    val = float(w(ids, tg, torch.tensor([3]), torch.tensor([7], dtype=torch.int32, device=dev)))
+    assert val == pytest.approx(1 / 3)               # "ab?" vs "abc"-like: the empty label is invisible, one substitution of three
+    data = _corpus(tmp_path, n_train=8, seconds=3.0, ragged=True, labels=vocab)
+    from lightning_asr_amd.train import main
+    tr = main(["data.train_manifest=[%s]" % (data / "train.json"), "data.val_manifest=%s" % (data / "dev.json"),
+               "data.test_manifest=%s" % (data / "dev.json"), "data.labels=%s" % vocab, "train.train_batch_size=4",
+               "train.dev_batch_size=4", "train.total_epoch=1", "train.precision=16", "train.warmup_steps=0",
+               "output_dir=%s" % (tmp_path / "run")])
+    assert tr.fused is not None and tr.global_step == 2
+    assert tr.fused.native.n_class == 5207 and tr.fused.native.lean_head and tr.fused.native._last_logp is None
+    assert not tr.fused.model.wer.device_ok
+    rec = tr.history[-1]
+    assert np.isfinite(rec["train_loss"]) and rec["train_loss"] > 0 and np.isfinite(rec["train_wer"]) and np.isfinite(rec["val_wer"])
+
+
 def test_bucketed_fit_keeps_padding_under_ten_percent(dev, tmp_path):
     """BASELINE cfg5 'bucketed padding': data.bucket_by_length from the config, ragged 2-8 s manifest"""
     data = _corpus(tmp_path, n_train=96, seconds=8.0, ragged=True)

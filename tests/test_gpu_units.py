@@ -183,7 +183,23 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         assert lp_err < tol["logp_abs"], (tag, "logp", lp_err)
     assert report["head"]["nll_rel"] < tol["nll"], (tag, "nll", report["head"]["nll_rel"])
     assert torch.equal(am.cpu().long(), rh["logp"].argmax(-1)) or (am.cpu().long() != rh["logp"].argmax(-1)).float().mean() < 1e-4
-    note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(rh["glogits"].float()) if lean else rh["glogits"]))
+    if lean:
+        # The lean head STORES d(logits) in bf16.  Against the oracle's (rounded) gradient the relative L2 distance is then the bf16
+        # quantisation floor itself: two tensors whose unrounded values differ by the dense head's own 4.5e-4 (the lattice evaluates
+        # lse on v_exp_f32 / v_log_f32, torch's CPU ctc_loss on libm - measured on the f32 gradient of the dense head, same batch)
+        # land on different bf16 neighbours for ~11 % of the elements, each such flip is one ulp = 2^-8 relative:
+        # sqrt(0.11) * 3.9e-3 = 1.3e-3; measured 1.20e-3 (profiles/r04_unit_parity_cfg5_aishell_bf16_lean.json), reported below.
+        # What the kernel can be held to is tighter and elementwise: every stored value is a bf16 NEIGHBOUR of the oracle's f32
+        # value, i.e. within half an ulp plus that f32-level noise - on all but a vanishing fraction of the 111 M elements.
+        x = rh["glogits"].float()
+        ulp = torch.pow(2.0, torch.floor(torch.log2(x.abs().clamp_min(1e-30))) - 7)        # bf16: 8 significant bits
+        bad = ((glogits_gpu - x).abs() > 0.5 * ulp + 2e-3 * x.abs() + 1e-12)
+        report["head"]["glogits_not_a_bf16_neighbour_frac"] = bad.double().mean().item()
+        report["head"]["glogits_rel_l2_vs_unrounded_oracle"] = rel_l2(glogits_gpu, x)
+        assert report["head"]["glogits_not_a_bf16_neighbour_frac"] < 1e-4, (tag, report["head"])
+        note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(x)))
+    else:
+        note("head", "grad_act", "glogits", rel_l2(glogits_gpu, rh["glogits"]))
     note("head", "grad_act", "dx", rel_l2(_bct(units["last_cnn2"]["g_prev"][:N * 1024].view(B, T, 1024)), rh["dx"]))
     for k, g in rh["grads"].items():
         note("head", "grad_param", "d." + k, rel_l2(gpu_grads[k], g.float()))
