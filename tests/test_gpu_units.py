@@ -195,6 +195,14 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         ulp = torch.pow(2.0, torch.floor(torch.log2(x.abs().clamp_min(1e-30))) - 7)        # bf16: 8 significant bits
         bad = ((glogits_gpu - x).abs() > 0.5 * ulp + 2e-3 * x.abs() + 1e-12)
         report["head"]["glogits_not_a_bf16_neighbour_frac"] = bad.double().mean().item()
+        if bool(bad.any()):      # diagnosis: which elements, and by how much
+            rr = (glogits_gpu[bad] / x[bad]).double()
+            report["head"]["bad_ratio_quantiles"] = [float(v) for v in torch.quantile(rr[torch.isfinite(rr)][:2000000], torch.tensor([0.01, 0.25, 0.5, 0.75, 0.99], dtype=torch.float64))]
+            report["head"]["bad_abs_x_quantiles"] = [float(v) for v in torch.quantile(x[bad].abs().double()[:2000000], torch.tensor([0.01, 0.5, 0.99], dtype=torch.float64))]
+            report["head"]["all_abs_x_quantiles"] = [float(v) for v in torch.quantile(x.abs().double().flatten()[:2000000], torch.tensor([0.01, 0.5, 0.99], dtype=torch.float64))]
+            report["head"]["bad_frac_by_utterance"] = [float(v) for v in bad.double().mean(dim=(1, 2))]
+            report["head"]["bad_x_zero_frac"] = float((x[bad] == 0).double().mean())
+            report["head"]["bad_gpu_zero_frac"] = float((glogits_gpu[bad] == 0).double().mean())
         report["head"]["glogits_rel_l2_vs_unrounded_oracle"] = rel_l2(glogits_gpu, x)
         assert report["head"]["glogits_not_a_bf16_neighbour_frac"] < 1e-4, (tag, report["head"])
         note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(x)))
