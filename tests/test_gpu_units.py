@@ -204,6 +204,10 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
             report["head"]["bad_x_zero_frac"] = float((x[bad] == 0).double().mean())
             report["head"]["bad_gpu_zero_frac"] = float((glogits_gpu[bad] == 0).double().mean())
         report["head"]["glogits_rel_l2_vs_unrounded_oracle"] = rel_l2(glogits_gpu, x)
+        if report["head"]["glogits_not_a_bf16_neighbour_frac"] >= 1e-4:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open("gpurun_out/lean_diag_%s.json" % tag, "w") as f:
+                json.dump(report["head"], f, indent=1)
         assert report["head"]["glogits_not_a_bf16_neighbour_frac"] < 1e-4, (tag, report["head"])
         note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(x)))
     else:
