@@ -28,9 +28,4 @@ int launch_gemm_bf16_dual(const GemmArgs& g, const void* A2, int64_t lda2, int64
 int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st);
 int launch_gemm_bf16_rowstat(const GemmArgs& g, float* row_stat, int32_t* row_arg, int* n_col_tiles, hipStream_t st);
 
-// PROBE side channel of LASR_GEMM_BNA_PROBE (gemm_bf16.hip::bna_apply): second A tensors of the NEXT bf16 launch (one per problem)
-extern const void* g_bna_probe[32];
-extern int g_bna_probe_n;
-int bna_probe_mask();
-
 }  // namespace lasr

@@ -443,7 +443,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
 // launch is 16 K steps per workgroup between a prologue and a 32 MB partial-slab epilogue; batched, a stage needs
 // a third of the slices for the same number of workgroups, so slices are 3x longer and the slabs 3x smaller.
 static constexpr int kMaxMulti = 32;
-static constexpr int kMaxMultiProbe = 32;
 struct Bf16Multi { Bf16Args p[kMaxMulti]; int start[kMaxMulti + 1]; int n, total; };
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_multi_kernel(Bf16Multi gm) {
@@ -496,31 +495,11 @@ __device__ __forceinline__ uint4 load_chunk_dual(const Bf16Args& g, int m0, int 
   return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
 }
 
-// ---- PROBE (LASR_GEMM_BNA_PROBE, off by default; DESIGN 6 "BN-backward apply folded into the GEMM staging"): what would it cost
-// the data-gradient and weight-gradient launches to make their A operand on the fly as  dy = G (.) d + B (.) y + C  from TWO tensors
-// instead of reading a finished dy?  The probe instantiation loads a second tensor (the unit's real y / y2) chunk for chunk, pulls the
-// three per-channel constants of the chunk's 8 channels from an LDS table and applies the affine before the LDS store - with the
-// table holding (1, 0, 0), so the results stay exactly what they were and only the cost is real.
-__device__ __forceinline__ uint4 bna_apply(const uint4& dv, const uint4& yv, const float* __restrict__ tabG, const float* __restrict__ tabB,
-                                           const float* __restrict__ tabC) {
-  float d[8], y[8], G[8], Bc[8], Cc[8], o[8];
-  Vec<bf16_t>::unpack(dv, d);
-  Vec<bf16_t>::unpack(yv, y);
-  *reinterpret_cast<float4*>(G) = *reinterpret_cast<const float4*>(tabG); *reinterpret_cast<float4*>(G + 4) = *reinterpret_cast<const float4*>(tabG + 4);
-  *reinterpret_cast<float4*>(Bc) = *reinterpret_cast<const float4*>(tabB); *reinterpret_cast<float4*>(Bc + 4) = *reinterpret_cast<const float4*>(tabB + 4);
-  *reinterpret_cast<float4*>(Cc) = *reinterpret_cast<const float4*>(tabC); *reinterpret_cast<float4*>(Cc + 4) = *reinterpret_cast<const float4*>(tabC + 4);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = fmaf(G[j], d[j], fmaf(Bc[j], y[j], Cc[j]));
-  return Vec<bf16_t>::pack(o);
-}
-static constexpr int kBnaTabC = 1024;            // channels the probe's LDS table covers (3 x 1024 floats = 12 KB)
-
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false, bool NTL = false, bool BNA = false>
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false, bool NTL = false>
 __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char* __restrict__ sB, char* __restrict__ dA,
                                          char* __restrict__ dB, f32x16 (&acc)[big::Cfg<NARROW>::MI][2], uint4 (&ra)[4],
                                          uint4 (&rb)[big::Cfg<NARROW>::NCB], const Bf16Args& g, int m0, int n0, int k_store,
-                                         int k_load, int kend, int wm, int wn, int lane, const uint32_t (&kma)[4],
-                                         uint4 (&ry)[BNA ? 4 : 1], const float* __restrict__ s_bna) {
+                                         int k_load, int kend, int wm, int wn, int lane, const uint32_t (&kma)[4]) {
   using namespace big;
   using CF = Cfg<NARROW>;
   constexpr int MI = CF::MI;
@@ -548,12 +527,6 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
       // 8-byte row-major LDS writes (the natural order left 2-byte writes: 128 ds_write_b16 per lane, 9 us per launch)
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cur][ni], a[cur][mi], acc[mi][ni], 0, 0, 0);
     if constexpr (STORE) {
-      if constexpr (BNA) {
-        // channels of this chunk: K-contiguous A ([row][channel]): k_store + 8 (c & 7); row-contiguous A ([k][channel]): m0 + 8 (c % 32)
-        const int c = threadIdx.x + NT * ks;
-        const int ch = (!TRANS_A ? k_store + ((c & 7) << 3) : m0 + ((c % (BTM / 8)) << 3)) & (kBnaTabC - 8);
-        ra[ks] = bna_apply(ra[ks], ry[ks], s_bna + ch, s_bna + kBnaTabC + ch, s_bna + 2 * kBnaTabC + ch);
-      }
       store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
       if constexpr (CF::NCB == 4) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks], k_store, kend, ks);
       else if (ks < CF::NCB) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks < CF::NCB ? ks : 0], k_store, kend, ks);
@@ -561,7 +534,6 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
     if constexpr (LOAD) {
       if constexpr (DUAL) ra[ks] = load_chunk_dual(g, m0, k_load, ks, kma);
       else ra[ks] = load_chunk<TRANS_A, BTM, NT, NTL>(g.A, g.lda, g.M, m0, k_load, kend, ks);
-      if constexpr (BNA) ry[ks] = load_chunk<TRANS_A, BTM, NT, NTL>(g.A2, g.lda, g.M, m0, k_load, kend, ks);
       if constexpr (CF::NCB == 4) rb[ks] = load_chunk<TRANS_B, CF::BN, NT, NTL>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
       else if (ks < CF::NCB) rb[ks < CF::NCB ? ks : 0] = load_chunk<TRANS_B, CF::BN, NT, NTL>(g.B, g.ldb, g.N, n0, k_load, kend, ks);
     }
@@ -579,7 +551,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 
 // one 256 x 256 (256 x 128) output tile `lid` of problem g; SLAB: split-K slice into the f32 slab g.split_ws (no LDS image,
 // no statistics) - shared by the two-problem kernel and the many-problem weight-gradient kernel
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB, bool DUAL = false, bool NTL = false, bool BNA = false>
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool SLAB, bool DUAL = false, bool NTL = false>
 __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int lid) {
 #ifdef LASR_GEMM_STAMPS
   unsigned long long* stamps = g_stamps;
@@ -617,11 +589,6 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   uint4 ra[4], rb[CF::NCB];
-  uint4 ry[BNA ? 4 : 1];
-  __shared__ __attribute__((aligned(16))) float s_bna[BNA ? 3 * kBnaTabC : 4];
-  if constexpr (BNA) {                                   // the probe's table: G = 1, B = 0, C = 0 (a real fold would copy the unit's constants)
-    for (int i = tid; i < 3 * kBnaTabC; i += NT) s_bna[i] = i < kBnaTabC ? 1.f : 0.f;
-  }
   uint32_t kma[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // DUAL: row masks of this thread's four A chunks
   if constexpr (DUAL) {
 #pragma unroll
@@ -637,16 +604,6 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   } else {
     load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
   }
-  if constexpr (BNA) {
-    load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A2, g.lda, g.M, m0, kbeg, kend, ry);
-    __syncthreads();                                     // the table is in LDS
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int c = tid + NT * p;
-      const int ch = (!TRANS_A ? kbeg + ((c & 7) << 3) : m0 + ((c % (BTM / 8)) << 3)) & (kBnaTabC - 8);
-      ra[p] = bna_apply(ra[p], ry[p], s_bna + ch, s_bna + kBnaTabC + ch, s_bna + 2 * kBnaTabC + ch);
-    }
-  }
   load_vec<TRANS_B, BTN, NT, CF::NCB, NTL>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
   store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
   store_vec<TRANS_B, BTN, NT, LD_KC, CF::LDRB, CF::NCB>(smem + OPER, rb, kbeg, kend);
@@ -657,7 +614,6 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     } else {
       load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A, g.lda, g.M, m0, kbeg + TK, kend, ra);
     }
-    if constexpr (BNA) load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A2, g.lda, g.M, m0, kbeg + TK, kend, ry);
     load_vec<TRANS_B, BTN, NT, CF::NCB, NTL>(g.B, g.ldb, g.N, n0, kbeg + TK, kend, rb);
   }
   __syncthreads();
@@ -668,21 +624,20 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     for (; it + 2 < nk; ++it) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL, NTL, BNA>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
-                                             kbeg + (it + 2) * TK, kend, wm, wn, lane, kma, ry, s_bna);
+      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL, NTL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
+                                             kbeg + (it + 2) * TK, kend, wm, wn, lane, kma);
       __syncthreads();
     }
     if (it + 1 < nk) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, NARROW, true, false, DUAL, false, BNA>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
-                                              wm, wn, lane, kma, ry, s_bna);
+      big_step<TRANS_A, TRANS_B, NARROW, true, false, DUAL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK, 0, kend,
+                                              wm, wn, lane, kma);
       __syncthreads();
       ++it;
     }
     const char* sA = smem + (it & 1) * BUF;
-    big_step<TRANS_A, TRANS_B, NARROW, false, false, DUAL, false, BNA>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane, kma,
-                                                                       ry, s_bna);
+    big_step<TRANS_A, TRANS_B, NARROW, false, false, DUAL>(sA, sA + OPER, nullptr, nullptr, acc, ra, rb, g, m0, n0, 0, 0, kend, wm, wn, lane, kma);
     __syncthreads();
   }
   LASR_STAMP(2);
@@ -864,12 +819,12 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
 #endif
 }
 
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool BNA = false>
+template <bool TRANS_A, bool TRANS_B, bool NARROW>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_kernel(Bf16Batch gb) {
   const int lid_all = xcd_remap(blockIdx.x, gb.total);
   const bool second = lid_all >= gb.tiles0;
   const Bf16Args& g = second ? gb.p[1] : gb.p[0];
-  gemm_bf16_big_tile<TRANS_A, TRANS_B, NARROW, false, false, false, BNA>(g, second ? lid_all - gb.tiles0 : lid_all);
+  gemm_bf16_big_tile<TRANS_A, TRANS_B, NARROW, false>(g, second ? lid_all - gb.tiles0 : lid_all);
 }
 
 // Folded eval form of a residual unit: out = act([u_masked | x] . [a W | a2 Wr]^T + (b + b2)), one problem per launch,
@@ -883,21 +838,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dual_kernel(Bf16Batch gb) {
 // slice; the K loop of this tile runs at ~1.3 PFLOP/s against ~0.7 for the 128 x 128 form.
 // NTL: operand loads with the non-temporal hint - every operand of a stage's weight gradients (dy, dy2, u, x of all its units) is read
 // here for the last time, most of it cold; the slabs this launch WRITES are what the reduction right behind it reads
-template <bool NTL, bool BNA = false>
+template <bool NTL>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi gm) {
   const int lid_all = xcd_remap(blockIdx.x, gm.total);
   int i = 0;
   while (i + 1 < gm.n && gm.start[i + 1] <= lid_all) ++i;   // workgroup-uniform scan of at most 32 entries
-  gemm_bf16_big_tile<true, true, false, true, false, NTL, BNA>(gm.p[i], lid_all - gm.start[i]);
-}
-
-// PROBE side channel (never set in the product path): the second tensors of the next bf16 launches (see bna_apply).  model.hip fills
-// it right before a data-gradient / weight-gradient launch when LASR_GEMM_BNA_PROBE asks for it; the launcher consumes and clears it.
-const void* g_bna_probe[kMaxMultiProbe] = {};
-int g_bna_probe_n = 0;
-int bna_probe_mask() {
-  static const int v = getenv("LASR_GEMM_BNA_PROBE") ? atoi(getenv("LASR_GEMM_BNA_PROBE")) : 0;
-  return v;
+  gemm_bf16_big_tile<true, true, false, true, false, NTL>(gm.p[i], lid_all - gm.start[i]);
 }
 
 static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
@@ -950,16 +896,6 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
   if (stat_tiles)
     for (int i = 0; i < n; ++i) stat_tiles[i] = b.p[i].gm;
   const dim3 grid1((unsigned)b.total);
-  if (use_big && g_bna_probe_n == n && !transA && transB && (bna_probe_mask() & 1)) {   // PROBE: data-gradient launch with a second A tensor
-    for (int i = 0; i < n; ++i) b.p[i].A2 = reinterpret_cast<const bf16_t*>(g_bna_probe[i]);
-    if (n == 1) b.p[1].A2 = b.p[0].A2;
-    g_bna_probe_n = 0;
-    if (narrow) hipLaunchKernelGGL((gemm_bf16_big_kernel<false, true, true, true>), grid1, dim3(big::NT), 0, st, b);
-    else hipLaunchKernelGGL((gemm_bf16_big_kernel<false, true, false, true>), grid1, dim3(big::NT), 0, st, b);
-    LASR_LAUNCH_CHECK("gemm_bf16_big_kernel(bna probe)");
-    return 0;
-  }
-  g_bna_probe_n = 0;
   if (use_big) {
 #define LASR_BIG_CASE(TA_, TB_)                                                                              \
   do {                                                                                                     \
@@ -1045,14 +981,6 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
   m.n = n; m.total = total;
   if (big_tile) {
     if (!vec) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: the 256-row tile needs 16-byte aligned operand rows");
-    if (g_bna_probe_n == n && (bna_probe_mask() & 2)) {                 // PROBE: weight-gradient launch with a second A tensor per problem
-      for (int i = 0; i < n; ++i) m.p[i].A2 = reinterpret_cast<const bf16_t*>(g_bna_probe[i]);
-      g_bna_probe_n = 0;
-      hipLaunchKernelGGL((gemm_bf16_big_multi_kernel<false, true>), dim3((unsigned)total), dim3(big::NT), 0, st, m);
-      LASR_LAUNCH_CHECK("gemm_bf16_big_multi_kernel(bna probe)");
-      return 0;
-    }
-    g_bna_probe_n = 0;
     if (nt_loads_mask() & 8) hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<true>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
     else hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<false>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
     LASR_LAUNCH_CHECK("gemm_bf16_big_multi_kernel");

@@ -5,7 +5,6 @@
 #include "common.h"
 #include "mel.h"
 #include "fused.h"
-#include "gemm.h"
 #include <string>
 #include <vector>
 #include <math.h>
@@ -637,13 +636,9 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
 // ~3 rounds of resident workgroups (512 at two per CU): a single unit needs 16 slices for that, a stage of 6-13 units
 // needs 2-6, so every workgroup runs 3-8x more K steps between its prologue and its slab write-out.
 static int flush_wgrads(std::vector<lasr_gemm_problem>& probs, std::vector<float*>& slabs, std::vector<lasr_reduce_desc>& pending,
-                        void* stream, const std::vector<const void*>* probe_y = nullptr) {
+                        void* stream) {
   const int split = wgrad_split();   // the cap the slabs were sized for; the library picks the slice count for its tile form
   int splits[32];
-  if (probe_y && (bna_probe_mask() & 2) && probe_y->size() == probs.size()) {   // PROBE (off by default), see gemm_bf16.hip::bna_apply
-    for (size_t i = 0; i < probs.size(); ++i) g_bna_probe[i] = (*probe_y)[i];
-    g_bna_probe_n = (int)probs.size();
-  }
   LASR_TRY(lasr_gemm_multi_split_partials(probs.data(), (int)probs.size(), split, slabs.data(), splits, stream));
   for (size_t i = 0; i < probs.size(); ++i)
     pending.push_back({slabs[i], reinterpret_cast<float*>(probs[i].C), probs[i].M * probs[i].N, splits[i]});
@@ -715,7 +710,6 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   std::vector<lasr_reduce_desc> pending;
   std::vector<lasr_gemm_problem> wprobs;
   std::vector<float*> wslabs;
-  std::vector<const void*> wprobe;     // PROBE only: the y / y2 tensor beside each deferred weight-gradient problem
   for (int ui = unit_hi; ui >= unit_stop; --ui) {
     const Unit& u = m->units[ui];
     const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
@@ -772,9 +766,9 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       if (u.has_res) pr[1] = {dy2, x_in, grads + u.w_res, u.co, u.ci, N, nullptr, nullptr, 0, nullptr};
       if (defer_w) {
         float* slab = atf(ws, u.o_wgp);
-        if (wprobs.size() + (u.has_res ? 2 : 1) > 32) { LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream, &wprobe)); wprobe.clear(); }   // (the launch takes 32 problems)
-        wprobs.push_back(pr[0]); wslabs.push_back(slab); wprobe.push_back(at(ws, u.o_y));
-        if (u.has_res) { wprobs.push_back(pr[1]); wslabs.push_back(slab + u.wgp_bytes / (2 * sizeof(float))); wprobe.push_back(at(ws, u.o_y2)); }
+        if (wprobs.size() + (u.has_res ? 2 : 1) > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));   // (the launch takes 32 problems)
+        wprobs.push_back(pr[0]); wslabs.push_back(slab);
+        if (u.has_res) { wprobs.push_back(pr[1]); wslabs.push_back(slab + u.wgp_bytes / (2 * sizeof(float))); }
       } else {
         LASR_TRY(lasr_gemm_batch(pr, u.has_res ? 2 : 1, dt, LASR_F32, 1, 1, wgrad_split(), scratch, sb, stream));
       }
@@ -787,9 +781,6 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       pr[0] = {dy, wptr(m, params, ws, u.w_pw), at(ws, p.o_du), N, u.ci, u.co, nullptr, nullptr, 0, nullptr};
       const bool with_res = u.has_res && need_dx;
       if (with_res) pr[1] = {dy2, wptr(m, params, ws, u.w_res), at(ws, p.o_dxr), N, u.ci, u.co, nullptr, nullptr, 0, nullptr};
-      if (bna_probe_mask() & 1) {     // PROBE (off by default): the launch also reads the unit's y / y2 and applies an identity affine
-        g_bna_probe[0] = at(ws, u.o_y); g_bna_probe[1] = u.has_res ? at(ws, u.o_y2) : at(ws, u.o_y); g_bna_probe_n = with_res ? 2 : 1;
-      }
       LASR_TRY(lasr_gemm_batch(pr, with_res ? 2 : 1, dt, dt, 0, 1, 1, scratch, sb, stream));
       // depthwise dW from (x, du); dx = flipped depthwise conv of du (+ residual dx)
       const bool fused_dw = defer && need_dx && u.stride == 1;   // both in one launch (falls back inside for other dtypes / shapes)
@@ -807,7 +798,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
         LASR_TRY(lasr_dwconv_wgrad(x_in, at(ws, p.o_du), grads + u.w_dw, dt, B, Tx, u.ci, u.k, u.stride, scratch, sb, stream));
       }
       if (pending.size() + wprobs.size() > 60) {
-        if (!wprobs.empty()) { LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream, &wprobe)); wprobe.clear(); }
+        if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
         LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));
         pending.clear();
       }
@@ -849,7 +840,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       cur ^= 1;
     }
   }
-  if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream, &wprobe));
+  if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
   if (!pending.empty()) {   // the stage's gradients are final
     double rb = 0;
     for (const lasr_reduce_desc& d : pending) rb += (double)d.n * (d.n_partials + 1) * sizeof(float);
