@@ -9,6 +9,7 @@
 // floats per half-wave (conflict-free ds_read_b32) whatever the global layout was.
 #include "common.h"
 #include "gemm.h"
+#include "lstm_body.h"
 #include <cmath>
 #include <climits>
 #include <stdlib.h>
@@ -488,8 +489,39 @@ extern "C" int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, in
   return 0;
 }
 
+static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,
+                            const lstm::BwdArgs* lstm_job, int lstm_utts);
+
 extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs,
                                               int* splits, void* stream) {
+  return multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, nullptr, 0);
+}
+
+int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits,
+                                                    const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f,
+                                                    const float* whh_r, const int32_t* lens, int64_t B, int64_t T_, const float* saved,
+                                                    float* dg_f, float* dg_r, float* dwhh_f, float* dwhh_r, void* workspace,
+                                                    size_t workspace_bytes, void* stream) {
+  static const bool off = getenv("LASR_LSTM_BESIDE_WGRAD") && atoi(getenv("LASR_LSTM_BESIDE_WGRAD")) == 0;
+  if (off || dtype != LASR_BF16 || B % 8 != 0 || B > 128 || n_probs < 1) return 1;
+  int64_t tiles_big = 0;
+  for (int i = 0; i < n_probs; ++i) {
+    const lasr_gemm_problem& q = probs[i];
+    if (q.M % 8 || q.N % 8 || reinterpret_cast<uintptr_t>(q.A) % 16 || reinterpret_cast<uintptr_t>(q.B) % 16 || q.K < 1024) return 1;
+    tiles_big += cdiv(q.M, 256) * cdiv(q.N, 256);
+  }
+  if (tiles_big + B > 256) return 1;                       // the recurrences and one slice of every tile must make ONE round
+  LASR_CHECK_ARG(dout && whh_f && whh_r && lens && saved && dg_f && dg_r && dwhh_f && dwhh_r && workspace, "gemm + BiLSTM grid: null pointer");
+  if (workspace_bytes < lasr_bilstm_bwd_workspace_bytes(B)) return fail(LASR_E_WORKSPACE, "gemm + BiLSTM grid: workspace");
+  float* pwhh = reinterpret_cast<float*>(workspace);
+  const lstm::BwdArgs a = {dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved, dg_f, dg_r, pwhh};
+  LASR_TRY(multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, &a, (int)B));
+  // pwhh is [B][2][G*H]: sum over b (lstm.hip)
+  return launch_reduce_partials(pwhh, (int)B, (int64_t)2 * lstm::G * lstm::H, dwhh_f, (int64_t)lstm::G * lstm::H, dwhh_r, as_stream(stream));
+}
+
+static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,
+                            const lstm::BwdArgs* lstm_job, int lstm_utts) {
   LASR_CHECK_ARG(probs && slabs && splits && n_probs >= 1 && n_probs <= 32 && split_k >= 1 && split_k <= 1024,
                  "lasr_gemm_multi_split_partials: bad argument");
   GemmArgs g[32];
@@ -515,7 +547,7 @@ extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, in
     // one round of workgroups, as many CUs as the slice count reaches (measured on the 71-tile stage of the plain model:
     // 3 slices / 213 workgroups 175 us, 5 / 355 180 us, 7 / 497 194 us, 10 / 710 198 us: a second round costs its
     // prologue and another 256 KB slab per tile)
-    split = (int)std::min<int64_t>(std::max<int64_t>(256 / std::max<int64_t>(tiles_big, 1), 1), std::min(split_k, 16));
+    split = (int)std::min<int64_t>(std::max<int64_t>((256 - lstm_utts) / std::max<int64_t>(tiles_big, 1), 1), std::min(split_k, 16));   // (CUs the recurrences take)
   } else {
     split = (int)std::min<int64_t>(std::max<int64_t>(cdiv(1536, tiles_small), 1), split_k);
   }
@@ -540,7 +572,8 @@ extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, in
     by += (double)(probs[i].M * probs[i].K + probs[i].N * probs[i].K) * 2 + (double)probs[i].M * probs[i].N * 4;
   }
   const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
-  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st);
+  if (lstm_job && !big_tile) { prof_end(tok, st); return fail(LASR_E_SHAPE, "gemm + BiLSTM grid needs the 256-row tile form"); }
+  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st, lstm_job, lstm_utts);
   prof_end(tok, st);
   return rc;
 }

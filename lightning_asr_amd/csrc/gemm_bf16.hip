@@ -11,6 +11,7 @@
 //                  transpose), so no operand is ever transposed through HBM or VALU.
 // bf16 results leave through an LDS transpose so every global store is 16 B per lane.
 #include "gemm.h"
+#include "lstm_body.h"
 #include <algorithm>
 #include <stdlib.h>
 
@@ -846,6 +847,32 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi g
   gemm_bf16_big_tile<true, true, false, true, false, NTL>(gm.p[i], lid_all - gm.start[i]);
 }
 
+// The stage's weight gradients with the BiLSTM backward recurrences of the context branch in the SAME grid (Context / ContextSE,
+// round 4): the first n_wg workgroups run two recurrences each - the forward and the reverse direction of one utterance: same length,
+// so their per-step barriers pair up without an idle phase - in 192-thread slots (three whole waves; lanes 160-191 compute on clamped
+// indices and store nothing, waves 6 and 7 leave at once); the GEMM tiles follow.  The recurrence is ~870 ns of dependent instructions
+// per frame whatever else runs, the weight gradients of the units above block3 do not depend on it: 437 us on 64 small workgroups
+// with 190 CUs idle becomes 437 us with the stage's biggest launch inside it.  Operands 16 steps ahead (the GEMM tiles next door
+// keep the memory system busy: 8 steps of look-ahead stalled).
+struct LstmJob { lstm::BwdArgs a; int n_wg; int n_utt; };
+template <bool NTL>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_lstm_kernel(Bf16Multi gm, LstmJob job) {
+  if ((int)blockIdx.x < job.n_wg) {                       // workgroup-uniform
+    __shared__ lstm::BwdSmem sm[2];
+    const int slot = threadIdx.x / 192;
+    if (slot >= 2) return;                                // (a finished wave is not waited for by s_barrier)
+    const int b = blockIdx.x, dir = slot;
+    int len = job.a.lens[b];
+    if (len > job.a.Tt) len = (int)job.a.Tt;
+    lstm::bilstm_bwd_body<bf16_t, true, 16, true>(job.a, b, dir, (int)threadIdx.x - slot * 192, 192, sm[slot], [] { lds_barrier(); }, len);
+    return;
+  }
+  const int lid_all = xcd_remap((int)blockIdx.x - job.n_wg, gm.total);
+  int i = 0;
+  while (i + 1 < gm.n && gm.start[i + 1] <= lid_all) ++i;   // workgroup-uniform scan of at most 32 entries
+  gemm_bf16_big_tile<true, true, false, true, false, NTL>(gm.p[i], lid_all - gm.start[i]);
+}
+
 static int fill_args(Bf16Args& a, const GemmArgs& g, int tm, int tn, int gz) {
   const int64_t lim = (int64_t)1 << 31;
   const int64_t gn = cdiv(g.N, tn), gm = cdiv(g.M, tm);
@@ -964,7 +991,7 @@ int launch_gemm_bf16_rowstat(const GemmArgs& g, float* row_stat, int32_t* row_ar
 }
 
 // n <= 32 split-K problems with f32 slab output, both operands row-contiguous ([K][M], [K][N]: weight gradients)
-int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st) {
+int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job, int lstm_utts) {
   if (n < 1 || n > kMaxMulti) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: 1..%d problems", kMaxMulti);
   Bf16Multi m;
   bool vec = true;
@@ -981,11 +1008,19 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
   m.n = n; m.total = total;
   if (big_tile) {
     if (!vec) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: the 256-row tile needs 16-byte aligned operand rows");
+    if (lstm_job) {                                        // the context branch's recurrences ride in this grid (bf16 model)
+      LstmJob job; job.a = *lstm_job; job.n_wg = (lstm_utts + 7) / 8 * 8; job.n_utt = lstm_utts;
+      if (job.n_wg != lstm_utts) return fail(LASR_E_SHAPE, "gemm + BiLSTM grid: the batch must be a multiple of 8 utterances");
+      hipLaunchKernelGGL(gemm_bf16_big_multi_lstm_kernel<false>, dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      LASR_LAUNCH_CHECK("gemm_bf16_big_multi_lstm_kernel");
+      return 0;
+    }
     if (nt_loads_mask() & 8) hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<true>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
     else hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<false>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
     LASR_LAUNCH_CHECK("gemm_bf16_big_multi_kernel");
     return 0;
   }
+  if (lstm_job) return fail(LASR_E_SHAPE, "gemm + BiLSTM grid needs the 256-row tile form");
   if (vec) hipLaunchKernelGGL(gemm_bf16_multi_kernel<true>, dim3((unsigned)total), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(gemm_bf16_multi_kernel<false>, dim3((unsigned)total), dim3(256), 0, st, m);
   LASR_LAUNCH_CHECK("gemm_bf16_multi_kernel");

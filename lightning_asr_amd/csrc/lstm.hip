@@ -8,11 +8,12 @@
 // (utterance, direction): thread j owns gate row j with its 40 recurrent weights in registers, the
 // hidden state lives in LDS.  All LSTM arithmetic is f32.
 #include "common.h"
+#include "lstm_body.h"
 #include <math.h>
 
 namespace lasr {
 
-static constexpr int H = 40, G = 4 * H;  // hidden size, gate rows
+using lstm::H; using lstm::G; using lstm::kPre; using lstm::sigmoid_fast; using lstm::tanh_fast; using lstm::quad_bcast;
 
 // Latency work: a time step is ~200 dependent instructions per wave, so the kernels are built around what sits ON that chain.
 //   * thread (u, q) = (tid >> 2, tid & 3) owns gate row q*H + u: the four gates of a hidden unit live in one quad and meet
@@ -25,15 +26,6 @@ static constexpr int H = 40, G = 4 * H;  // hidden size, gate rows
 //     made every step wait for the previous step's stores to retire (forward 352 us, backward 525 us for T' = 501).
 static constexpr int kLstmThreads = G;     // one thread per gate row (2.5 waves: the hardware masks the missing lanes, no `tid < G` branches -
                                            // a divergent branch around the step's loads made the compiler drain vmcnt at its join)
-static constexpr int kPre = 8;
-
-__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanh_fast(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
-template <int Q>
-__device__ __forceinline__ float quad_bcast(float v) {   // lane Q of every quad -> the whole quad
-  constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true));
-}
 
 // gx [B][T][G] f32 per direction (x W_ih^T, no bias); saved [B][T][2][G + 2H]: gates(i,f,g,o) | c | h
 // out: columns [col0 + dir*H, +H) of a [B][T][ldo] tensor in T (zeros for t >= len).
@@ -106,99 +98,13 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* _
   }
 }
 
-// dout: columns [col0 + dir*H, +H) of a [B][T][ldd] tensor in T (gradient w.r.t. the LSTM output).
-// dg [B][T][G] f32 per direction = gradient w.r.t. the gate pre-activations (zero rows for t >= len);
-// pwhh [B][2][G][H] = this utterance's contribution to dW_hh.
+// the backward recurrence: lstm_body.h (shared with the grid that runs it beside the stage's weight-gradient GEMMs)
 template <typename T>
-__global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(const T* __restrict__ dout, int64_t ldd, int64_t col0,
-                                                                  const float* __restrict__ whh_f, const float* __restrict__ whh_r,
-                                                                  const int32_t* __restrict__ lens, int64_t Tt, const float* __restrict__ saved,
-                                                                  float* __restrict__ dg_f, float* __restrict__ dg_r, float* __restrict__ pwhh) {
-  __shared__ __attribute__((aligned(16))) float s_dg[G];
-  __shared__ __attribute__((aligned(16))) float s_hprev[H];
-  __shared__ float s_part[4][H];
-  const int b = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
-  const int u = tid >> 2, q = tid & 3, j = q * H + u;                    // gate-gradient role
-  const int kk = tid % H, p = tid / H;                                  // dh_prev role: hidden index kk, rows 40p .. 40p+39
-  const float* whh = dir ? whh_r : whh_f;
-  float* dg = (dir ? dg_r : dg_f) + (int64_t)b * Tt * G;
-  int len = lens[b];
-  if (len > Tt) len = (int)Tt;
-  float wt[H], dw[H];
-#pragma unroll
-  for (int qq = 0; qq < H; ++qq) { wt[qq] = whh[(p * H + qq) * H + kk]; dw[qq] = 0.f; }
-  for (int64_t i = (int64_t)len * G + tid; i < Tt * G; i += kLstmThreads) dg[i] = 0.f;
-  if (tid < H) { s_part[0][tid] = 0.f; s_part[1][tid] = 0.f; s_part[2][tid] = 0.f; s_part[3][tid] = 0.f; }
-  // per-step operands, kPre steps ahead: every lane its own gate; lane q of a quad one of (c, c_prev, h_prev, d(out)) of unit u
-  auto fetch = [&](int s, float& ga, float& gb) {
-    const int t = dir ? len - 1 - s : s;
-    const int tp = dir ? t + 1 : t - 1;
-    const float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
-    const float* sp = saved + (((int64_t)b * Tt + (s > 0 ? tp : t)) * 2 + dir) * (G + 2 * H);
-    ga = sv[j];
-    // lane q of the quad: c, c_prev, h_prev (one f32 load from a selected address) or d(out) (a T load): both issued by every
-    // lane, the right one selected - no divergent branch around a load
-    const float* src = q == 0 ? sv + G + u : (q == 1 ? sp + G + u : sp + G + H + u);
-    const float vs = *src;
-    const float vd = Elem<T>::ld(dout + ((int64_t)b * Tt + t) * ldd + col0 + dir * H + u);
-    const float v = q == 3 ? vd : vs;
-    gb = (s == 0 && (q == 1 || q == 2)) ? 0.f : v;       // no previous step: c_prev = h_prev = 0
-  };
-  float ra[kPre], rb_[kPre];
-#pragma unroll
-  for (int k = 0; k < kPre; ++k) {
-    ra[k] = 0.f; rb_[k] = 0.f;
-    if (len - 1 - k >= 0) fetch(len - 1 - k, ra[k], rb_[k]);
-  }
-  float dc_next = 0.f;
-  __syncthreads();
-  for (int s0 = len - 1; s0 >= 0; s0 -= kPre) {
-#pragma unroll
-    for (int k = 0; k < kPre; ++k) {
-      const int s = s0 - k;
-      if (s >= 0) {   // workgroup-uniform
-        const int t = dir ? len - 1 - s : s;
-        const float a = ra[k], x = rb_[k];
-        fetch(max(s - kPre, 0), ra[k], rb_[k]);          // unconditional (clamped): see the forward kernel
-        const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
-        const float c = quad_bcast<0>(x), cprev = quad_bcast<1>(x), hprev = quad_bcast<2>(x), dy = quad_bcast<3>(x);
-        const float dh = dy + (s_part[0][u] + s_part[1][u]) + (s_part[2][u] + s_part[3][u]);    // + dh from step s+1
-        const float tc = tanh_fast(c);
-        const float d_o = dh * tc * og * (1.f - og);
-        const float dc = fmaf(dh * og, 1.f - tc * tc, dc_next);
-        float mine;
-        if (q == 0) mine = dc * gg * ig * (1.f - ig);
-        else if (q == 1) mine = dc * cprev * fg * (1.f - fg);
-        else if (q == 2) mine = dc * ig * (1.f - gg * gg);
-        else mine = d_o;
-        dc_next = dc * fg;
-        s_dg[j] = mine;                        // (s_part is rewritten only after the second barrier below: no hazard with the reads above)
-        dg[(int64_t)t * G + j] = mine;
-        if (q == 0) s_hprev[u] = hprev;
-        lds_barrier();
-        {
-          const float my = s_dg[tid];          // row tid of dW_hh
-          float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-          for (int q4 = 0; q4 < H; q4 += 4) {
-            const float4 hv = *reinterpret_cast<const float4*>(s_hprev + q4);
-            dw[q4] = fmaf(my, hv.x, dw[q4]); dw[q4 + 1] = fmaf(my, hv.y, dw[q4 + 1]);
-            dw[q4 + 2] = fmaf(my, hv.z, dw[q4 + 2]); dw[q4 + 3] = fmaf(my, hv.w, dw[q4 + 3]);
-            const float4 gv = *reinterpret_cast<const float4*>(s_dg + p * H + q4);
-            acc0 = fmaf(wt[q4], gv.x, acc0); acc1 = fmaf(wt[q4 + 1], gv.y, acc1);
-            acc0 = fmaf(wt[q4 + 2], gv.z, acc0); acc1 = fmaf(wt[q4 + 3], gv.w, acc1);
-          }
-          s_part[p][kk] = acc0 + acc1;
-        }
-        lds_barrier();
-      }
-    }
-  }
-  {
-    float* o = pwhh + (((int64_t)b * 2 + dir) * G + tid) * H;
-#pragma unroll
-    for (int qq = 0; qq < H; ++qq) o[qq] = dw[qq];
-  }
+__global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(lstm::BwdArgs a) {
+  __shared__ lstm::BwdSmem sm;
+  int len = a.lens[blockIdx.x];
+  if (len > a.Tt) len = (int)a.Tt;
+  lstm::bilstm_bwd_body<T, false, kPre, true>(a, blockIdx.x, blockIdx.y, threadIdx.x, kLstmThreads, sm, [] { lds_barrier(); }, len);
 }
 
 // dst[n][dcol0 + c] = src[n][scol0 + c] for c < ncols (optionally += ), with dtype conversion
@@ -249,12 +155,9 @@ extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int
   float* pwhh = reinterpret_cast<float*>(workspace);
   dim3 grid((unsigned)B, 2);
   hipStream_t st = as_stream(stream);
-  if (dtype == LASR_F32)
-    hipLaunchKernelGGL(bilstm_bwd_kernel<float>, grid, dim3(kLstmThreads), 0, st, (const float*)dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved,
-                       dg_f, dg_r, pwhh);
-  else
-    hipLaunchKernelGGL(bilstm_bwd_kernel<bf16_t>, grid, dim3(kLstmThreads), 0, st, (const bf16_t*)dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved,
-                       dg_f, dg_r, pwhh);
+  const lstm::BwdArgs a = {dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved, dg_f, dg_r, pwhh};
+  if (dtype == LASR_F32) hipLaunchKernelGGL(bilstm_bwd_kernel<float>, grid, dim3(kLstmThreads), 0, st, a);
+  else hipLaunchKernelGGL(bilstm_bwd_kernel<bf16_t>, grid, dim3(kLstmThreads), 0, st, a);
   LASR_LAUNCH_CHECK("bilstm_bwd_kernel");
   // pwhh is [B][2][G*H]: sum over b with a stride of 2*G*H -> view as B partials of 2*G*H columns, split at G*H
   return launch_reduce_partials(pwhh, (int)B, (int64_t)2 * G * H, dwhh_f, (int64_t)G * H, dwhh_r, st);

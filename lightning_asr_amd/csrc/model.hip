@@ -5,6 +5,7 @@
 #include "common.h"
 #include "mel.h"
 #include "fused.h"
+#include "gemm.h"
 #include <string>
 #include <vector>
 #include <math.h>
@@ -817,6 +818,26 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       // g[cur] holds d(cat) [N][336].  Back through the BiLSTM, then
       // d(block23 out) = d(cat)[:, :256] + dG_f W_ih_f + dG_r W_ih_r  -> g[cur^1]
       const void* x23 = at(ws, m->units[ui - 1].o_out);
+      // The recurrence (437 us of dependent steps on 2 B small workgroups) next to the 1x1 weight gradients collected so far in this
+      // stage - the units above block3 and block3's own: they do not depend on it - in ONE grid (gemm_bf16.hip,
+      // gemm_bf16_big_multi_lstm_kernel; LASR_LSTM_BESIDE_WGRAD=0: the two launches one after the other).  `scratch` holds the
+      // recurrence's dW_hh partials; the GEMM part writes only its slabs.
+      int beside = 1;
+      if (!wprobs.empty() && wprobs.size() <= 32) {
+        int splits[32];
+        beside = gemm_multi_split_partials_with_bilstm_bwd(wprobs.data(), (int)wprobs.size(), wgrad_split(), wslabs.data(), splits,
+                                                           at(ws, p.o_g[cur]), dt, 336, 256, params + m->lstm.w_hh[0], params + m->lstm.w_hh[1],
+                                                           lens, B, T, atf(ws, p.o_lstm_saved), atf(ws, p.o_dg[0]), atf(ws, p.o_dg[1]),
+                                                           grads + m->lstm.w_hh[0], grads + m->lstm.w_hh[1], scratch, sb, stream);
+        if (beside < 0 || beside > 1) return beside;
+        if (beside == 0) {
+          for (size_t i = 0; i < wprobs.size(); ++i)
+            pending.push_back({wslabs[i], reinterpret_cast<float*>(wprobs[i].C), wprobs[i].M * wprobs[i].N, splits[i]});
+          wprobs.clear();
+          wslabs.clear();
+        }
+      }
+      if (beside == 1)
       LASR_TRY(lasr_bilstm_bwd(at(ws, p.o_g[cur]), dt, 336, 256, params + m->lstm.w_hh[0], params + m->lstm.w_hh[1], lens, B, T,
                                atf(ws, p.o_lstm_saved), atf(ws, p.o_dg[0]), atf(ws, p.o_dg[1]), grads + m->lstm.w_hh[0],
                                grads + m->lstm.w_hh[1], scratch, sb, stream));

@@ -88,3 +88,9 @@ def test_context_se_switches(dev):
     base = _run({}, variant="context_se")
     for env in ({"LASR_SE_UNFUSED_BWD": "1"}, {"LASR_NO_FUSE": "1"}):
         _close(_run(env, variant="context_se"), base, env)
+    # the BiLSTM backward recurrence inside the grid of the stage's weight-gradient launch (default) against the two launches one
+    # after the other: the same kernels' arithmetic on the same operands - the same numbers
+    sep = _run({"LASR_LSTM_BESIDE_WGRAD": "0"}, variant="context_se")
+    a, b = dict(base), dict(sep)
+    assert a.pop("prof_brackets") is not None and b.pop("prof_brackets") is not None
+    assert a == b, (a, b)
