@@ -197,9 +197,15 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         o64 = E.Bf16OracleModel(variant, n_class, mask=True, act=act, state={k: v.clone() for k, v in state.items()}, dtype=torch.float64,
                                 emulate=True)
         o64.lean_head = True
-        x = E.run_head(o64, _bct(m.tap("last_cnn2")).double(), pct_c, tg, tl)["glogits"].float()
+        rh64 = E.run_head(o64, _bct(m.tap("last_cnn2")).double(), pct_c, tg, tl)
+        x = rh64["glogits"].float()
+        # d(logits) = (softmax - occupancy) / B.  The softmax part is exact to f32 rounding; the occupancy part (target and blank
+        # columns, 1 % of the elements) comes out of an f32 log-domain lattice whose alpha + beta - nll are sums of up to 801 terms
+        # of magnitude ~8 (|log p| at C = 4334): measured against the f64 lattice it is off by up to ~1 % on ~5 % of those elements
+        # - torch's own f32 ctc_loss does no better - so the occupancy term gets a 2 % allowance, everything else 0.2 %
+        occ = (torch.exp(rh64["logp"].double()) / B - rh64["glogits"].double()).abs().float()
         ulp = torch.pow(2.0, torch.floor(torch.log2(x.abs().clamp_min(1e-30))) - 7)        # bf16: 8 significant bits
-        bad = ((glogits_gpu - x).abs() > 0.5 * ulp + 2e-3 * x.abs() + 1e-12)
+        bad = ((glogits_gpu - x).abs() > 0.5 * ulp + 2e-3 * x.abs() + 2e-2 * occ + 1e-12)
         report["head"]["glogits_not_a_bf16_neighbour_frac"] = bad.double().mean().item()
         if bool(bad.any()):      # diagnosis: which elements, and by how much
             rr = (glogits_gpu[bad] / x[bad]).double()
