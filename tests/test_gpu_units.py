@@ -221,7 +221,10 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
             with open("gpurun_out/lean_diag_%s.json" % tag, "w") as f:
                 json.dump(report["head"], f, indent=1)
         assert report["head"]["glogits_not_a_bf16_neighbour_frac"] < 1e-4, (tag, report["head"])
-        note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(x)))
+        # relative L2 like for like: against the oracle head in the plan's own arithmetic class (f32 lattice), as in every other unit;
+        # against the f64 lattice the figure is the f32 lattice's own accuracy at T' = 801 (reported, not gated: torch's is the same)
+        report["head"]["glogits_rel_l2_vs_f64_oracle_rounded"] = rel_l2(glogits_gpu, E.rb(x))
+        note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(rh["glogits"].float())))
     else:
         note("head", "grad_act", "glogits", rel_l2(glogits_gpu, rh["glogits"]))
     note("head", "grad_act", "dx", rel_l2(_bct(units["last_cnn2"]["g_prev"][:N * 1024].view(B, T, 1024)), rh["dx"]))
