@@ -855,7 +855,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi g
 // with 190 CUs idle becomes 437 us with the stage's biggest launch inside it.  Operands 16 steps ahead (the GEMM tiles next door
 // keep the memory system busy: 8 steps of look-ahead stalled).
 struct LstmJob { lstm::BwdArgs a; int n_wg; int n_utt; };
-template <bool NTL>
+template <bool NTL, int KP>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_lstm_kernel(Bf16Multi gm, LstmJob job) {
   if ((int)blockIdx.x < job.n_wg) {                       // workgroup-uniform
     __shared__ lstm::BwdSmem sm[2];
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_lstm_kernel(Bf16Mu
     const int b = blockIdx.x, dir = slot;
     int len = job.a.lens[b];
     if (len > job.a.Tt) len = (int)job.a.Tt;
-    lstm::bilstm_bwd_body<bf16_t, true, 16, true>(job.a, b, dir, (int)threadIdx.x - slot * 192, 192, sm[slot], [] { lds_barrier(); }, len);
+    lstm::bilstm_bwd_body<bf16_t, true, KP, true>(job.a, b, dir, (int)threadIdx.x - slot * 192, 192, sm[slot], [] { lds_barrier(); }, len);
     return;
   }
   const int lid_all = xcd_remap((int)blockIdx.x - job.n_wg, gm.total);
@@ -1011,7 +1011,10 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
     if (lstm_job) {                                        // the context branch's recurrences ride in this grid (bf16 model)
       LstmJob job; job.a = *lstm_job; job.n_wg = (lstm_utts + 7) / 8 * 8; job.n_utt = lstm_utts;
       if (job.n_wg != lstm_utts) return fail(LASR_E_SHAPE, "gemm + BiLSTM grid: the batch must be a multiple of 8 utterances");
-      hipLaunchKernelGGL(gemm_bf16_big_multi_lstm_kernel<false>, dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      static const int kp = getenv("LASR_LSTM_KP") ? atoi(getenv("LASR_LSTM_KP")) : 16;      // A/B: look-ahead of the recurrence's operand ring
+      if (kp >= 32) hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 32>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      else if (kp <= 8) hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 8>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      else hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 16>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
       LASR_LAUNCH_CHECK("gemm_bf16_big_multi_lstm_kernel");
       return 0;
     }
