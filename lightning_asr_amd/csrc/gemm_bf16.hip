@@ -852,8 +852,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi g
 // so their per-step barriers pair up without an idle phase - in 192-thread slots (three whole waves; lanes 160-191 compute on clamped
 // indices and store nothing, waves 6 and 7 leave at once); the GEMM tiles follow.  The recurrence is ~870 ns of dependent instructions
 // per frame whatever else runs, the weight gradients of the units above block3 do not depend on it: 437 us on 64 small workgroups
-// with 190 CUs idle becomes 437 us with the stage's biggest launch inside it.  Operands 16 steps ahead (the GEMM tiles next door
-// keep the memory system busy: 8 steps of look-ahead stalled).
+// with 190 CUs idle becomes ~500 us with the stage's biggest launch inside it (cfg4 step 3.751 -> 3.646 ms).
 struct LstmJob { lstm::BwdArgs a; int n_wg; int n_utt; };
 template <bool NTL, int KP>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_lstm_kernel(Bf16Multi gm, LstmJob job) {
@@ -1011,10 +1010,9 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
     if (lstm_job) {                                        // the context branch's recurrences ride in this grid (bf16 model)
       LstmJob job; job.a = *lstm_job; job.n_wg = (lstm_utts + 7) / 8 * 8; job.n_utt = lstm_utts;
       if (job.n_wg != lstm_utts) return fail(LASR_E_SHAPE, "gemm + BiLSTM grid: the batch must be a multiple of 8 utterances");
-      static const int kp = getenv("LASR_LSTM_KP") ? atoi(getenv("LASR_LSTM_KP")) : 16;      // A/B: look-ahead of the recurrence's operand ring
-      if (kp >= 32) hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 32>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
-      else if (kp <= 8) hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 8>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
-      else hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 16>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      // look-ahead of the recurrence's operand ring: measured in the cfg4 step, one call (profiles/r04_cfg4_lstm_beside_wgrad.txt):
+      // 8 steps 3.646 ms, 16 steps 3.662, 32 steps 3.665 (the two launches one after the other: 3.751) - the stand-alone kernel's 8
+      hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, lstm::kPre>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
       LASR_LAUNCH_CHECK("gemm_bf16_big_multi_lstm_kernel");
       return 0;
     }
