@@ -614,3 +614,22 @@ def test_bench_two_ranks_over_stub_prints_the_comm_record(dev, tmp_path):
         assert b["allreduce_us"] >= 20.0 + b["mb"] * 1e3 / 85.0 - 1.0, b
     assert c["exposed_wait_us_per_step"] is not None and c["exposed_wait_us_per_step"] >= 0.0
     assert "trainer" not in d and "cpu_baseline" not in d                     # one-GPU extras stay out of the N > 1 line
+
+
+def test_replay_watchdog_times_out_instead_of_hanging(dev):
+    """step.sync_with_timeout - what bench.py and Trainer.fit put behind the FIRST replay of a captured step that holds collectives:
+    it returns as soon as the stream drains, and when the stream does not drain in time it raises (hard_exit=False) / leaves with
+    exit code 3 (bench.py) with a message that names the switches to fall back with - it never blocks for ever in synchronize()."""
+    import time
+    from lightning_asr_amd.step import sync_with_timeout
+    x = torch.zeros(1, device=dev)
+    x += 1
+    t0 = time.perf_counter()
+    sync_with_timeout("an idle stream", timeout_s=5.0, hard_exit=False)        # drains at once
+    assert time.perf_counter() - t0 < 1.0
+    torch.cuda._sleep(int(3e9))                                                 # ~1.3 s of a spinning kernel on the current stream
+    t0 = time.perf_counter()
+    with pytest.raises(TimeoutError, match="LASR_GRAPH_DP=0"):
+        sync_with_timeout("a stream that is stuck", timeout_s=0.2, hard_exit=False)
+    assert 0.15 < time.perf_counter() - t0 < 1.0
+    torch.cuda.synchronize()
