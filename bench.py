@@ -301,6 +301,7 @@ def trainer_path(args, cfg, emit: bool = True, steps=None, warmup=None):
     class Clock:
         t0 = t1 = None
         a0 = a1 = 0.0
+        h0 = h1 = (0.0, 0.0, 0.0)
 
         def on_train_batch_end(self, tr):
             if tr.global_step in (W, W + K):
@@ -308,10 +309,12 @@ def trainer_path(args, cfg, emit: bool = True, steps=None, warmup=None):
                     import torch.distributed as dist
                     dist.barrier()
                 torch.cuda.synchronize()
+                f_ = tr.fused
+                snap = (f_.ingest_wait_s, f_.host_step_s, f_.host_cpu_s)
                 if tr.global_step == W:
-                    self.t0, self.a0 = time.perf_counter(), tr.fused.audio_seconds
+                    self.t0, self.a0, self.h0 = time.perf_counter(), f_.audio_seconds, snap
                 else:
-                    self.t1, self.a1 = time.perf_counter(), tr.fused.audio_seconds
+                    self.t1, self.a1, self.h1 = time.perf_counter(), f_.audio_seconds, snap
     clock = Clock()
     tr = Trainer(max_epochs=1, max_steps=W + K, default_root_dir=os.path.join(root, "run"), device=dev, check_val_every_n_epoch=1000,
                  callbacks=[clock], log_every_n_steps=50)
@@ -342,9 +345,9 @@ def trainer_path(args, cfg, emit: bool = True, steps=None, warmup=None):
                    "audio_seconds_per_step_per_gpu": audio / K, "padding_frac": 1.0 - f.samples_real / max(f.samples_padded, 1),
                    "ingest": f.source_kind, "ingest_threads": args.ingest_threads, "train_crop": crop,
                    "hip_graph_steps": f.graph_steps, "eager_steps": f.eager_steps, "lean_head": bool(f.native.lean_head),
-                   "host_ms_per_step": {"waiting_for_ingest": 1e3 * f.ingest_wait_s / max(tr.global_step, 1),
-                                        "enqueuing_the_step": 1e3 * f.host_step_s / max(tr.global_step, 1),
-                                        "enqueue_cpu_time": 1e3 * f.host_cpu_s / max(tr.global_step, 1),
+                   "host_ms_per_step": {"waiting_for_ingest": 1e3 * (clock.h1[0] - clock.h0[0]) / K,      # (over the K timed steps)
+                                        "enqueuing_the_step": 1e3 * (clock.h1[1] - clock.h0[1]) / K,
+                                        "enqueue_cpu_time": 1e3 * (clock.h1[2] - clock.h0[2]) / K,
                                         "note": "enqueuing_the_step is wall time inside FusedLoop.step: once the GPU's queue is full the runtime "
                                                 "makes the thread wait, so a GPU-bound loop reads ~the step time there; enqueue_cpu_time is the "
                                                 "thread's CPU time (time.thread_time) over the same calls"},
