@@ -561,12 +561,6 @@ int lasr_comm_allreduce_ranges(lasr_comm_t* comm, float* base, const int64_t* lo
                                void* producer_stream);
 int lasr_comm_broadcast(lasr_comm_t* comm, float* buf, int64_t count, int root, void* producer_stream);
 int lasr_comm_wait(lasr_comm_t* comm, void* consumer_stream);
-/* lasr_comm_calls: collectives issued so far (a grouped _ranges call counts once) = the index the next one gets.
- * lasr_comm_wait_call: `consumer_stream` waits for collective `call_index` only (one of the last 16 issued) - the optimiser of an
- * earlier bucket's tensors can then run while a later, smaller bucket is still on the wire (Lightning's DDP waits for all buckets
- * before optimizer.step; the split changes no value, only when the first part of lasr_novograd_step may start).                   */
-int64_t lasr_comm_calls(const lasr_comm_t* comm);
-int lasr_comm_wait_call(lasr_comm_t* comm, int64_t call_index, void* consumer_stream);
 /* LASR_COMM_MAX_CHANNELS=n (> 0) makes lasr_comm_init set NCCL_MAX_NCHANNELS=n (the persistent workgroups a collective keeps resident
  * on the CUs it shares with the backward) unless that variable is already set; default 0 = RCCL's own choice (measured: the
  * interference grows with the LENGTH of the exchange, not with the CUs it holds - DESIGN 5).

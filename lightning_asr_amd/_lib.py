@@ -137,8 +137,6 @@ SIGNATURES = {
     "lasr_step_metrics": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "lasr_wav_info": (_i32, [C.c_char_p, C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lasr_wav_read_batch": (_i32, [_p, _i64, _p, C.c_double, _p, _i64, C.POINTER(_i64), _p, C.c_int32, _i32, _i32]),
-    "lasr_comm_calls": (_i64, [_p]),
-    "lasr_comm_wait_call": (_i32, [_p, _i64, _p]),
     "lasr_comm_timing": (_i32, [_p, _i32]),
     "lasr_comm_timing_collect": (_i32, [_p, _i32, _p, _p, C.POINTER(_i32), _p, C.POINTER(_i32)]),
     "lasr_comm_unique_id": (_i32, [_p, _sz]),

@@ -95,14 +95,6 @@ class Communicator:
         """the current stream waits for every collective issued so far (device-side; the host does not block)"""
         call("lasr_comm_wait", self._h, _stream())
 
-    def calls(self) -> int:
-        """collectives issued so far = the index the next one gets"""
-        return int(_lib.load().lasr_comm_calls(self._h))
-
-    def wait_call(self, call_index: int) -> None:
-        """the current stream waits for collective ``call_index`` only (one of the last 16 issued), not for later ones"""
-        call("lasr_comm_wait_call", self._h, int(call_index), _stream())
-
     # ---- timing (bench.py's `comm` record) -----------------------------------------------------------------------------------
     def timing(self, on: bool) -> None:
         """bracket every collective (side stream) and every wait (consumer stream) with events from now on; eager launches only"""

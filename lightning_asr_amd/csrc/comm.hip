@@ -82,7 +82,6 @@ using namespace lasr;
 
 // one timed collective (lasr_comm_timing): events on the side stream around the ncclAllReduce / group
 struct CommRec { hipEvent_t a, b; double bytes; };
-static constexpr int kCallRing = 16;
 // one timed lasr_comm_wait: events on the CONSUMER stream right before and right after its wait for the side stream -
 // their distance is the part of the exchange that backward did not hide (what the optimiser launch actually waited)
 struct WaitRec { hipEvent_t a, b; };
@@ -94,7 +93,6 @@ struct lasr_comm {
   hipEvent_t ev_out = nullptr;       // side stream -> consumer stream
   int world = 1, rank = 0, device = 0;
   int64_t calls = 0;
-  hipEvent_t ev_call[kCallRing] = {};   // completion of the last kCallRing collectives on the side stream (lasr_comm_wait_call)
   bool timing = false;
   std::vector<CommRec> recs;
   std::vector<WaitRec> waits;
@@ -146,7 +144,6 @@ extern "C" int lasr_comm_init(lasr_comm_t** out, const void* unique_id, size_t i
   hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming);
-  for (int i = 0; i < kCallRing && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->ev_call[i], hipEventDisableTiming);
   if (e != hipSuccess) { lasr_comm_destroy(c); return hip_fail(e, "lasr_comm_init: stream / events"); }
   *out = c;
   return 0;
@@ -158,7 +155,6 @@ extern "C" int lasr_comm_destroy(lasr_comm_t* c) {
   if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   if (c->ev_in) (void)hipEventDestroy(c->ev_in);
   if (c->ev_out) (void)hipEventDestroy(c->ev_out);
-  for (int i = 0; i < kCallRing; ++i) if (c->ev_call[i]) (void)hipEventDestroy(c->ev_call[i]);
   for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto& w : c->waits) { (void)hipEventDestroy(w.a); (void)hipEventDestroy(w.b); }
   for (auto& e : c->pool) (void)hipEventDestroy(e);
@@ -184,7 +180,6 @@ extern "C" int lasr_comm_allreduce(lasr_comm_t* c, float* buf, int64_t count, vo
   if (c->timing) { rec.a = c->timed_event(); rec.b = c->timed_event(); (void)hipEventRecord(rec.a, c->side); }
   LASR_NCCL(g_rccl.AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->comm, c->side), "ncclAllReduce");
   if (c->timing) { (void)hipEventRecord(rec.b, c->side); c->recs.push_back(rec); }
-  LASR_HIP(hipEventRecord(c->ev_call[c->calls % kCallRing], c->side), "hipEventRecord(call)");
   c->calls += 1;
   return 0;
 }
@@ -204,7 +199,6 @@ extern "C" int lasr_comm_allreduce_ranges(lasr_comm_t* c, float* base, const int
   }
   LASR_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
   if (c->timing) { (void)hipEventRecord(rec.b, c->side); c->recs.push_back(rec); }
-  LASR_HIP(hipEventRecord(c->ev_call[c->calls % kCallRing], c->side), "hipEventRecord(call)");
   c->calls += 1;
   return 0;
 }
@@ -222,21 +216,6 @@ extern "C" int lasr_comm_wait(lasr_comm_t* c, void* consumer_stream) {
   WaitRec w{nullptr, nullptr};
   if (c->timing) { w.a = c->timed_event(); w.b = c->timed_event(); (void)hipEventRecord(w.a, as_stream(consumer_stream)); }
   LASR_HIP(hipStreamWaitEvent(as_stream(consumer_stream), c->ev_out, 0), "hipStreamWaitEvent(consumer)");
-  if (c->timing) { (void)hipEventRecord(w.b, as_stream(consumer_stream)); c->waits.push_back(w); }
-  return 0;
-}
-
-// Number of collectives issued so far (all-reduces; a grouped _ranges call counts once): the index of the next one.
-extern "C" int64_t lasr_comm_calls(const lasr_comm_t* c) { return c ? c->calls : -1; }
-
-// `consumer_stream` waits for collective number `call_index` only (one of the last 16 issued), not for the ones issued after it: the
-// optimiser of an EARLIER bucket's tensors can run while a later bucket is still on the wire.
-extern "C" int lasr_comm_wait_call(lasr_comm_t* c, int64_t call_index, void* consumer_stream) {
-  LASR_CHECK_ARG(c && call_index >= 0 && call_index < c->calls && call_index >= c->calls - kCallRing, "lasr_comm_wait_call: index %lld of %lld",
-                 (long long)call_index, (long long)(c ? c->calls : 0));
-  WaitRec w{nullptr, nullptr};
-  if (c->timing) { w.a = c->timed_event(); w.b = c->timed_event(); (void)hipEventRecord(w.a, as_stream(consumer_stream)); }
-  LASR_HIP(hipStreamWaitEvent(as_stream(consumer_stream), c->ev_call[call_index % kCallRing], 0), "hipStreamWaitEvent(call)");
   if (c->timing) { (void)hipEventRecord(w.b, as_stream(consumer_stream)); c->waits.push_back(w); }
   return 0;
 }

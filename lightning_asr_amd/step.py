@@ -53,7 +53,6 @@ class TrainStep:
         self.force_staged = bool(int(os.environ.get("LASR_FORCE_OVERLAP", "0"))) and \
             (self.comm is not None or torch.distributed.is_initialized())
         self._prefetched = None    # (key, feats, pct) of the batch announced by the previous step(prefetch_wave=...)
-        self._sub_offsets = {}     # (t0, t1) -> (lo, hi, rebased device offsets) of a NovoGrad call over a run of tensors
         self._lr_state = None      # device image of the schedule (use_device_schedule)
         self._lr_epoch = None      # host schedule position the device image corresponds to
 
@@ -126,42 +125,7 @@ class TrainStep:
         _, btf, _, pct = ops.mel(wave, sample_lens, dither, aug, True, self.model.act_dtype, want_bft=False, want_btf=True)
         return btf, pct
 
-    def _novograd(self, t0: int = 0, t1: Optional[int] = None) -> None:
-        """NovoGrad over the parameter tensors [t0, t1) (default: all): every tensor's update depends on its own gradient only
-        (scheduler/novograd.py:113-137), so a contiguous run of tensors is a smaller instance of the same flat problem"""
-        m = self.model
-        n_t = self.exp_avg_sq.numel()
-        t1 = n_t if t1 is None else t1
-        if t0 == 0 and t1 == n_t:
-            ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
-                              self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
-            return
-        key = (t0, t1)
-        sub = self._sub_offsets.get(key)
-        if sub is None:
-            offs = self.offsets.cpu()
-            lo, hi = int(offs[t0]), int(offs[t1])
-            sub = self._sub_offsets[key] = (lo, hi, (offs[t0:t1 + 1] - lo).to(m.params.device))
-        lo, hi, offs_dev = sub
-        ops.novograd_step(m.params[lo:hi], m.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[t0:t1], offs_dev, self.lr_dev,
-                          self.betas[0], self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
-
-    def _split_point(self, ranges0) -> Optional[int]:
-        """tensor index t such that the FIRST bucket of the staged backward (the last layers' gradients) is exactly the tensors
-        [t, n): then their update can run while the later bucket is still being reduced.  None: no such clean cut."""
-        if len(ranges0) != 1 or int(ranges0[0][1]) != self.model.n_param or os.environ.get("LASR_OPT_SPLIT", "1") == "0":
-            return None
-        lo = int(ranges0[0][0])
-        infos = self.model.param_infos()
-        for i, t in enumerate(infos):
-            if t.offset == lo:
-                return i if lo % 4 == 0 and 0 < i < len(infos) else None
-        return None
-
-    def optimizer_step(self, first_call: Optional[int] = None, split: Optional[int] = None) -> None:
-        """first_call / split (staged data-parallel step over the library's communicator): the tensors [split, n) belong to the bucket
-        whose all-reduce has index ``first_call``; they are updated as soon as THAT collective is done, beside the wire time of the
-        last (small, fully exposed) bucket - Lightning's DDP waits for every bucket before ``optimizer.step``; same values."""
+    def optimizer_step(self) -> None:
         m = self.model
         if self.world > 1 and not getattr(self, "_reduced", False):
             # one flat 20 MB SUM all-reduce; the 1/world average is folded into the optimiser's grad scale
@@ -171,13 +135,8 @@ class TrainStep:
             else:
                 torch.distributed.all_reduce(m.grads, group=self.pg)
         self._reduced = False
-        if first_call is not None and split is not None and self.comm is not None:
-            self.comm.wait_call(first_call)
-            self._novograd(split, None)
-            self.comm.wait()
-            self._novograd(0, split)
-        else:
-            self._novograd()
+        ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
+                          self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
         if self.schedule is not None:
             if self._lr_state is not None and self.schedule.last_epoch != self._lr_epoch:
                 self.sync_device_schedule()                # the host schedule was loaded / reset since the last step
@@ -212,17 +171,8 @@ class TrainStep:
             # are still being differentiated: RCCL runs on its own stream and waits (event) only for the
             # kernels enqueued so far; the optimiser waits for all buckets.
             if self.comm is not None:       # library-owned communicator and side stream (lasr_comm_*)
-                issued = []                 # (index of the collective, its ranges), in issue order
-
-                def on_bucket(ranges):
-                    self.comm.all_reduce_ranges(m.grads, ranges)
-                    issued.append((self.comm.calls() - 1, ranges))
-                loss, nll, logp, am = m.loss_backward_staged(feats, pct, targets, tgt_lens, on_bucket, want_logp=want_logp)
-                split = self._split_point(issued[0][1]) if len(issued) >= 2 else None
-                self._reduced = True
-                if split is not None:       # the first bucket's tensors are updated while the last bucket is on the wire
-                    self.optimizer_step(first_call=issued[0][0], split=split)
-                    return loss, nll, logp, am
+                loss, nll, logp, am = m.loss_backward_staged(feats, pct, targets, tgt_lens,
+                                                             lambda ranges: self.comm.all_reduce_ranges(m.grads, ranges), want_logp=want_logp)
                 self.comm.wait()
             else:
                 works = []

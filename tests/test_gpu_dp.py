@@ -633,51 +633,3 @@ def test_replay_watchdog_times_out_instead_of_hanging(dev):
         sync_with_timeout("a stream that is stuck", timeout_s=0.2, hard_exit=False)
     assert 0.15 < time.perf_counter() - t0 < 1.0
     torch.cuda.synchronize()
-
-
-def test_optimizer_split_by_bucket_equals_one_call(dev, monkeypatch):
-    """The staged data-parallel step updates the FIRST bucket's tensors (the last layers) as soon as that bucket's all-reduce is
-    done - `lasr_comm_wait_call` - while the last, small bucket is still on the wire, and the rest after `lasr_comm_wait`.  NovoGrad
-    is per tensor (scheduler/novograd.py:113-137), so two calls over [split, n) and [0, split) must land where one call lands."""
-    from lightning_asr_amd.comm import Communicator
-    from lightning_asr_amd.engine import NativeModel
-    from lightning_asr_amd.step import TrainStep
-    m = NativeModel("plain", 28, mask=True, act="relu", dtype=torch.float32, device=dev)
-    m.init_parameters(seed=2)
-    g = torch.Generator().manual_seed(9)
-    grads = (torch.randn(m.n_param, generator=g) * 1e-2).to(dev)
-    p0 = m.params.clone()
-    out = []
-    for split_mode in (False, True):
-        m.params.copy_(p0)
-        ts = TrainStep(m, 1e-2, 1e-3)
-        ranges0 = m.bucket_schedule(2)[0][1]
-        split = ts._split_point(ranges0)
-        assert split is not None and 0 < split < len(m.param_infos())
-        assert m.param_infos()[split].name.startswith("encoder.block3.")          # first 512-channel block: the bucket cut of DESIGN 5
-        for _ in range(3):                                                        # first step initialises exp_avg_sq, later ones decay it
-            m.grads.copy_(grads)
-            if split_mode:
-                ts._novograd(split, None)
-                ts._novograd(0, split)
-            else:
-                ts._novograd()
-        torch.cuda.synchronize()
-        out.append((m.params.clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone()))
-    for a, b in zip(out[0], out[1]):
-        assert torch.equal(a, b)
-    # and through the communicator: wait_call orders the consumer behind ONE collective of several
-    monkeypatch.setenv("LASR_FORCE_OVERLAP", "1")
-    comm = Communicator.single(dev)
-    buf = torch.ones(1 << 20, device=dev)
-    n0 = comm.calls()
-    comm.all_reduce(buf)
-    comm.all_reduce_ranges(buf, [(0, 1024), (4096, 8192)])
-    assert comm.calls() == n0 + 2
-    comm.wait_call(n0)
-    comm.wait()
-    torch.cuda.synchronize()
-    assert float(buf.sum()) == float(1 << 20)
-    with pytest.raises(Exception, match="index"):
-        comm.wait_call(n0 + 5)
-    comm.close()
