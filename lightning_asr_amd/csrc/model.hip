@@ -6,6 +6,7 @@
 #include "mel.h"
 #include "fused.h"
 #include "gemm.h"
+#include "se_seqsum.h"
 #include <string>
 #include <vector>
 #include <math.h>
@@ -567,6 +568,7 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
     }
     float* stats = training ? atf(ws, u.o_stats) : nullptr;
     float* stats2 = (training && u.has_res) ? atf(ws, u.o_stats2) : nullptr;
+    bool se_sums_done = false;
     {  // main 1x1 (masked, BN sums) and, for residual blocks, the residual 1x1 (never masked) in one launch
       lasr_gemm_problem pr[2];
       pr[0] = {gin, wptr(m, params, ws, u.w_pw), at(ws, u.o_y), N, u.co, u.ci, nullptr, u.masked ? lens : nullptr, T, stats};
@@ -584,7 +586,14 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
           br[1] = {parts[1], tiles[1], params + u.bn_res.gamma, params + u.bn_res.beta, buffers + u.bn_res.rmean,
                    buffers + u.bn_res.rvar, atf(ws, u.o_coef2), atf(ws, u.o_saved2), stats2};
         ProfScope ps(LASR_PROF_BN, stream, 0.0);
-        LASR_TRY(lasr_bn_finalize_partials(br, np, u.co, N, kBnEps, kBnMom, stream));
+        // SE units: the squeeze's per-utterance sums of y do not depend on the finalize - one launch for both (se_seqsum.h)
+        int merged = 1;
+        if (u.has_se) {
+          merged = bn_finalize_partials_seqsum(br, np, u.co, N, kBnEps, kBnMom, at(ws, u.o_y), dt, B, T, atf(ws, u.o_se_sum), stream);
+          if (merged < 0 || merged > 1) return merged;
+          se_sums_done = merged == 0;
+        }
+        if (merged == 1) LASR_TRY(lasr_bn_finalize_partials(br, np, u.co, N, kBnEps, kBnMom, stream));
       } else {
         LASR_TRY(lasr_gemm_batch(pr, np, dt, dt, 0, 0, 1, scratch, p.scratch_bytes, stream));
         if (training) {   // (eval: every layer's coefficients were computed by one launch before the loop)
@@ -599,7 +608,7 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
     }
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
       ProfScope ps_se(LASR_PROF_BN, stream, (double)N * u.co * dtype_size(dt));
-      LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
+      if (!se_sums_done) LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
       LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
                            atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), stream));
     }

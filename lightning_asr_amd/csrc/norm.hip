@@ -3,6 +3,7 @@
 // Replaces models/QuartNet.py:33-37 (MaskCNN lengths, BatchNorm1d(eps=1e-3), ReLU) and :74-77
 // (residual add + ReLU), plus their autograd backward.  All statistics are f32.
 #include "common.h"
+#include "se_seqsum.h"
 #include "dropout.h"
 #include <algorithm>
 
@@ -161,6 +162,59 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(BnBranch2 br,
     if (b.stats) { b.stats[c] = (float)s; b.stats[C + c] = (float)q; }
     bn_finalize_channel((float)s, (float)q, c, b.gamma, b.beta, b.rmean, b.rvar, b.coef, b.saved, C, n, eps, momentum, 1);
   }
+}
+
+// The same finalize with the SE squeeze of the unit's y in its grid (ContextSE units, round 4): the first nf workgroups are the
+// finalize's, the rest seqsum_vec_kernel's - two launch-floor kernels of the forward chain (4.9 us each) that do not depend on each
+// other become one.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_seqsum_kernel(BnBranch2 br, int64_t C, float n, float eps, float momentum, int nfx, int nf,
+                                                                 const T* __restrict__ x, int Tt, int gx, float* __restrict__ sums) {
+  constexpr int RL = 256 / (64 / Vec<T>::kN);
+  __shared__ double s_acc[8][33];
+  __shared__ float s_red[RL][65];
+  if ((int)blockIdx.x < nf) {                              // workgroup-uniform
+    const int fx = blockIdx.x % nfx, fy = blockIdx.x / nfx;
+    const BnBranch& b = fy ? br.b[1] : br.b[0];
+    const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int64_t c = (int64_t)fx * 16 + (cl & 15);
+    s_acc[pl][cl] = c < C ? partial_lane_sum(b.partials, b.n_part, 2 * C, (int64_t)(cl >> 4) * C + c, pl) : 0.0;
+    __syncthreads();
+    if (pl == 0 && cl < 16 && c < C) {
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s += s_acc[i][cl]; q += s_acc[i][16 + cl]; }
+      if (b.stats) { b.stats[c] = (float)s; b.stats[C + c] = (float)q; }
+      bn_finalize_channel((float)s, (float)q, c, b.gamma, b.beta, b.rmean, b.rvar, b.coef, b.saved, C, n, eps, momentum, 1);
+    }
+    return;
+  }
+  const int id = blockIdx.x - nf;
+  seqsum_vec_body<T>(x, Tt, (int)C, sums, id % gx, id / gx, s_red);
+}
+
+int bn_finalize_partials_seqsum(const lasr_bn_branch* branches, int n_branches, int64_t C, int64_t n_rows, float eps, float momentum,
+                                const void* x, int dtype, int64_t B, int64_t T_, float* sums, void* stream) {
+  static const bool off = getenv("LASR_SE_SEQSUM_IN_FINALIZE") && atoi(getenv("LASR_SE_SEQSUM_IN_FINALIZE")) == 0;
+  const int v = dtype == LASR_F32 ? 4 : 8;
+  if (off || C % v != 0 || reinterpret_cast<uintptr_t>(x) % 16 != 0 || T_ >= ((int64_t)1 << 30) || C >= ((int64_t)1 << 30) || B >= 65536) return 1;
+  LASR_CHECK_ARG(branches && n_branches >= 1 && n_branches <= 2 && C > 0 && n_rows > 0 && x && sums, "bn_finalize_partials_seqsum: bad argument");
+  BnBranch2 br;
+  for (int i = 0; i < 2; ++i) {
+    const lasr_bn_branch& q = branches[i < n_branches ? i : 0];
+    LASR_CHECK_ARG(q.partials && q.n_partials > 0 && q.gamma && q.beta && q.coef, "bn_finalize_partials_seqsum: null pointer");
+    br.b[i] = {q.partials, q.n_partials, q.gamma, q.beta, q.running_mean, q.running_var, q.coef, q.saved, q.stats};
+  }
+  const int nfx = (int)cdiv(C, 16), nf = nfx * n_branches, gx = (int)cdiv(C, 64);
+  const unsigned grid = (unsigned)(nf + gx * B);
+  if (dtype == LASR_F32)
+    hipLaunchKernelGGL(bn_finalize_seqsum_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), br, C, (float)n_rows, eps, momentum, nfx, nf,
+                       (const float*)x, (int)T_, gx, sums);
+  else
+    hipLaunchKernelGGL(bn_finalize_seqsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), br, C, (float)n_rows, eps, momentum, nfx, nf,
+                       (const bf16_t*)x, (int)T_, gx, sums);
+  LASR_LAUNCH_CHECK("bn_finalize_seqsum_kernel");
+  return 0;
 }
 
 int launch_reduce_partials(const float* partials, int n_part, int64_t ncols, float* out0, int64_t split, float* out1,

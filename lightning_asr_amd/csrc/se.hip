@@ -5,6 +5,7 @@
 // squeeze needs only per-(utterance, channel) sums of the pre-BN tensor: one extra read of y in
 // forward; the excite scale is folded into lasr_bn_act_fwd / lasr_bn_act_bwd_*.
 #include "common.h"
+#include "se_seqsum.h"
 #include "dropout.h"
 
 namespace lasr {
@@ -44,39 +45,9 @@ __global__ __launch_bounds__(256) void seqsum_kernel(const T* __restrict__ x, in
 // thread and trip: 11.5 us for the 16 MB of a 512-channel unit at cfg4.
 template <typename T>
 __global__ __launch_bounds__(256) void seqsum_vec_kernel(const T* __restrict__ x, int Tt, int C, float* __restrict__ sums) {
-  constexpr int V = Vec<T>::kN, CT = 64 / V, RL = 256 / CT, RB = 8;
+  constexpr int RL = 256 / (64 / Vec<T>::kN);
   __shared__ float s_red[RL][65];
-  const int b = blockIdx.y, cl = threadIdx.x % CT, rl = threadIdx.x / CT;
-  const int c = blockIdx.x * 64 + cl * V;
-  const T* xb = x + (size_t)b * Tt * C + min(c, C - V);
-  float acc[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) acc[j] = 0.f;
-  for (int t0 = rl; t0 < Tt; t0 += RB * RL) {
-    uint4 r[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) r[i] = Vec<T>::raw(xb + (size_t)min(t0 + i * RL, Tt - 1) * C);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      float v[V];
-      Vec<T>::unpack(r[i], v);
-      const bool live = t0 + i * RL < Tt;
-#pragma unroll
-      for (int j = 0; j < V; ++j) acc[j] += live ? v[j] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < V; ++j) s_red[rl][cl * V + j] = acc[j];
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int cc = blockIdx.x * 64 + threadIdx.x;
-    if (cc < C) {
-      float s = 0.f;
-#pragma unroll
-      for (int r = 0; r < RL; ++r) s += s_red[r][threadIdx.x];
-      sums[(size_t)b * C + cc] = s;
-    }
-  }
+  seqsum_vec_body<T>(x, Tt, C, sums, blockIdx.x, blockIdx.y, s_red);
 }
 
 // ds[b][c] = sum_t dout * act'(z) * (a1*y + b1),  z = (a1*y+b1)*se + (a2*y2+b2): gradient w.r.t. the scale

@@ -90,6 +90,9 @@ def test_context_se_switches(dev):
         _close(_run(env, variant="context_se"), base, env)
     # the BiLSTM backward recurrence inside the grid of the stage's weight-gradient launch (default) against the two launches one
     # after the other: the same kernels' arithmetic on the same operands - the same numbers
+    # the SE squeeze's column sums inside the BN finalize launch (default) against the two launches: the same numbers
+    two = _run({"LASR_SE_SEQSUM_IN_FINALIZE": "0"}, variant="context_se")
+    assert two == base, (two, base)
     sep = _run({"LASR_LSTM_BESIDE_WGRAD": "0"}, variant="context_se")
     _close(sep, base, "LASR_LSTM_BESIDE_WGRAD=0")
     # the recurrence's arithmetic is the same code (lstm_body.h): the forward is untouched and the loss identical; the weight
