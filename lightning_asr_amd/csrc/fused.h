@@ -13,4 +13,12 @@ namespace lasr {
 int dwconv_fwd_bn(const void* y, const float* coef, const void* y2, const float* coef2, int act, const float* w, void* out, void* u,
                   int64_t B, int64_t T, int64_t C, int k, void* stream);
 
+// norm.hip: lasr_mask_lengths_step + lasr_cast_f32_to_bf16 in one launch (the start of every bf16 training forward); 1 = not taken
+int mask_lengths_step_cast(const float* pct, int64_t B, int64_t T_, int32_t* lens, uint64_t* step_counter, const float* in, void* out,
+                           int64_t n, void* stream);
+// norm.hip: lasr_cast_pad_f32_to_bf16 + lasr_colsum_f32's first stage + lasr_scale_sum_f32 in one launch, then the column sums' second
+// stage (the tail of the dense small-vocabulary loss head); 1 = not taken
+int head_tail(const float* gl, int64_t rows, int64_t C, void* gl_bf16, int64_t ld_out, float* bias_grad, void* workspace,
+              size_t workspace_bytes, const float* nll, int64_t n_nll, float scale, float* loss, void* stream);
+
 }  // namespace lasr

@@ -122,6 +122,7 @@ struct lasr_model {
   float drop_p = 0.f;
   uint64_t drop_seed = 0;
   uint64_t* drop_step = nullptr;
+  const float* tail_nll = nullptr; float* tail_loss = nullptr;   // the batch mean of the losses, left by forward_and_loss to the backward's first launch
   bool lean_active = false;   // the last loss ran the large-vocabulary head: d(logits) is the bf16 [N][ldc] tensor at o_d1, db is done
   int lean_tiles = 0;
   int bwd_cur = 0;       // ping-pong index of the gradient buffers between partial backward calls
@@ -490,8 +491,15 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
   const bool dropping = training && m->drop_p > 0.f;
   {
     ProfScope ps(LASR_PROF_OTHER, stream, dt == LASR_BF16 ? 6.0 * m->n_param : 0.0);
-    LASR_TRY(lasr_mask_lengths_step(pct, B, T, lens, dropping ? m->drop_step : nullptr, stream));   // (bumps the masks' step counter)
-    if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
+    int merged = 1;      // bf16: the lengths and the weights' bf16 shadow in one launch (two independent launch-floor kernels)
+    if (dt == LASR_BF16) {
+      merged = mask_lengths_step_cast(pct, B, T, lens, dropping ? m->drop_step : nullptr, params, at(ws, p.o_wbf16), m->n_param, stream);
+      if (merged < 0 || merged > 1) return merged;
+    }
+    if (merged == 1) {
+      LASR_TRY(lasr_mask_lengths_step(pct, B, T, lens, dropping ? m->drop_step : nullptr, stream));   // (bumps the masks' step counter)
+      if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
+    }
   }
   void* scratch = at(ws, p.o_scratch);
   if (!training) {   // eval: BN coefficients of all layers from the running statistics, one launch
@@ -694,18 +702,31 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   // decoder (models/QuartNet.py:275): dW = gl^T h, db = colsum(gl), dh = gl W
   const void* gl_ab = gl;
   int64_t ld_gl = C;
+  bool bias_done = false;
   if (m->lean_active) {   // lasr_ctc_loss_lean wrote the bf16 gradient (rows padded to 8) and the bias gradient
     ld_gl = lean_ldc(m);
     gl_ab = at(ws, p.o_d1);
   } else if (dt == LASR_BF16) {  // GEMM operands share a dtype: bf16 shadow of the logits gradient, rows padded to 16-byte multiples
     ld_gl = (C + 7) / 8 * 8;
     ProfScope ps(LASR_PROF_HEAD, stream, (double)N * C * 6);
-    LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
+    int merged = 1;
+    if (m->tail_loss) {      // padded copy + bias-gradient column sums + the loss mean forward_and_loss left to this launch
+      merged = head_tail(gl, N, C, at(ws, p.o_d1), ld_gl, grads + m->b_dec, scratch, sb, m->tail_nll, B, 1.0f / (float)B, m->tail_loss, stream);
+      if (merged < 0 || merged > 1) return merged;
+      if (merged == 1) LASR_TRY(lasr_scale_sum_f32(m->tail_nll, B, 1.0f / (float)B, m->tail_loss, stream));
+      m->tail_loss = nullptr; m->tail_nll = nullptr;
+      bias_done = merged == 0;
+    }
+    if (merged == 1) LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
     gl_ab = at(ws, p.o_d1);
+  }
+  if (m->tail_loss) {        // (not reached in bf16; keeps the loss defined whatever path the head takes)
+    LASR_TRY(lasr_scale_sum_f32(m->tail_nll, B, 1.0f / (float)B, m->tail_loss, stream));
+    m->tail_loss = nullptr; m->tail_nll = nullptr;
   }
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr,
                         dec_wgrad_split(C, N), scratch, sb, stream));
-  if (!m->lean_active) {
+  if (!m->lean_active && !bias_done) {
     ProfScope ps(LASR_PROF_HEAD, stream, (double)N * C * 4);
     LASR_TRY(lasr_colsum_f32(gl, grads + m->b_dec, N, C, scratch, sb, stream));
   }
@@ -934,6 +955,8 @@ static int forward_and_loss(lasr_model_t* m, const float* params, float* buffers
     LASR_TRY(lasr_ctc_loss(logp_out, targets, lens, tgt_lens, B, p.T, C, p.S_max, C - 1, nll_out, atf(ws, p.o_glogits), nullptr,
                            at(ws, p.o_ctc), p.ctc_bytes, stream));
   }
+  // dense head in bf16 with a narrow vocabulary: the batch mean rides in the launch that opens the backward (head_tail, fused.h)
+  if (!lean && m->cfg.dtype == LASR_BF16 && C <= 256) { m->tail_nll = nll_out; m->tail_loss = loss_out; return 0; }
   return lasr_scale_sum_f32(nll_out, B, 1.0f / (float)B, loss_out, stream);
 }
 

@@ -4,6 +4,7 @@
 // (residual add + ReLU), plus their autograd backward.  All statistics are f32.
 #include "common.h"
 #include "se_seqsum.h"
+#include "fused.h"
 #include "dropout.h"
 #include <algorithm>
 
@@ -42,6 +43,29 @@ __global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, fl
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < B) lens[i] = (int32_t)(Tf * pct[i]);  // f32 product, truncation toward zero (torch .int())
   if (i == 0 && step_counter) *step_counter += 1ull;   // index of this training forward: the dropout masks' counter (dropout.h)
+}
+
+// The two launches every training forward starts with - lens = int(T' * pct) (models/QuartNet.py:311) and the bf16 shadow of the
+// weights - are independent of each other: one grid (round 4; the last workgroup does the lengths).
+__global__ __launch_bounds__(256) void mask_lengths_cast_kernel(const float* __restrict__ pct, int64_t B, float Tf, int32_t* __restrict__ lens,
+                                                                unsigned long long* __restrict__ step_counter, const float* __restrict__ in,
+                                                                bf16_t* __restrict__ out, int64_t n) {
+  if (blockIdx.x == gridDim.x - 1) {                     // workgroup-uniform
+    for (int64_t i = threadIdx.x; i < B; i += 256) lens[i] = (int32_t)(Tf * pct[i]);
+    if (threadIdx.x == 0 && step_counter) *step_counter += 1ull;
+    return;
+  }
+  const int64_t n4 = n >> 2;                             // 16-byte loads, 8-byte stores (the buffers are 256-byte aligned)
+  const int64_t stride = (int64_t)(gridDim.x - 1) * 256;
+  for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n4; e += stride) {
+    const float4 v = reinterpret_cast<const float4*>(in)[e];
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    o.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    reinterpret_cast<uint2*>(out)[e] = o;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t e = (n4 << 2) + threadIdx.x; e < n; e += 256) out[e] = f32_to_bf16(in[e]);
 }
 
 // ------------------------------------------------------------------ BN finalize --------------
@@ -881,6 +905,19 @@ extern "C" int lasr_mask_lengths_step(const float* pct, int64_t B, int64_t T_, i
   LASR_LAUNCH_CHECK("mask_lengths_kernel");
   return 0;
 }
+int lasr::mask_lengths_step_cast(const float* pct, int64_t B, int64_t T_, int32_t* lens, uint64_t* step_counter, const float* in, void* out,
+                                 int64_t n, void* stream) {
+  LASR_CHECK_ARG(pct && lens && B > 0 && T_ > 0 && in && out && n > 0, "mask_lengths_step_cast: bad argument");
+  if (reinterpret_cast<uintptr_t>(in) % 16 || reinterpret_cast<uintptr_t>(out) % 8) return 1;
+  int64_t blocks = cdiv(n >> 2, 256);
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(mask_lengths_cast_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, as_stream(stream), pct, B, (float)T_, lens,
+                     reinterpret_cast<unsigned long long*>(step_counter), in, reinterpret_cast<bf16_t*>(out), n);
+  LASR_LAUNCH_CHECK("mask_lengths_cast_kernel");
+  return 0;
+}
+
 extern "C" int lasr_mask_lengths(const float* pct, int64_t B, int64_t T_, int32_t* lens, void* stream) {
   return lasr_mask_lengths_step(pct, B, T_, lens, nullptr, stream);
 }
@@ -1304,7 +1341,81 @@ __global__ __launch_bounds__(64) void scale_sum_kernel(const float* __restrict__
   s = wave_sum(s);
   if (threadIdx.x == 0) out[0] = s * scale;
 }
+// The three small launches behind the dense head's CTC gradient - the row-padded bf16 copy of d(logits) (operand of the decoder's
+// two gradient GEMMs), the slab partials of its column sums (decoder bias gradient) and the batch mean of the per-utterance losses
+// (train.py:77) - read the same two tensors and do not depend on each other: one grid, three kinds of workgroup (round 4).
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ gl, int64_t rows, int64_t C, bf16_t* __restrict__ gl_bf16,
+                                                        int64_t ld_out, int n_cast, float* __restrict__ partials, int rows_per_wg, int n_sum,
+                                                        const float* __restrict__ nll, int64_t n_nll, float scale, float* __restrict__ loss) {
+  const int id = blockIdx.x;
+  if (id < n_cast) {                                     // cast_pad_bf16_kernel
+    const int64_t total = rows * ld_out;
+    for (int64_t i = id * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)n_cast * 256) {
+      const int64_t r = i / ld_out, c = i - r * ld_out;
+      gl_bf16[i] = c < C ? f32_to_bf16(gl[r * C + c]) : (bf16_t)0;
+    }
+    return;
+  }
+  if (id < n_cast + n_sum) {                             // colsum_partial_kernel (C <= 256: one column chunk)
+    __shared__ float s_p[256];
+    const int blk = id - n_cast;
+    const int col_threads = (int)C, row_lanes = 256 / col_threads;
+    const int cl = threadIdx.x % col_threads, rl = threadIdx.x / col_threads;
+    const int64_t r0 = (int64_t)blk * rows_per_wg;
+    const int64_t r1 = r0 + rows_per_wg < rows ? r0 + rows_per_wg : rows;
+    float s = 0.f;
+    if (rl < row_lanes) {
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int64_t r = r0 + rl; r < r1; r += 8 * row_lanes) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t rr = r + (int64_t)u * row_lanes;
+          const float xv = gl[(rr < r1 ? rr : r1 - 1) * C + cl];
+          v[u] = rr < r1 ? xv : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += v[u];
+      }
+      s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    s_p[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+      float t = 0.f;
+      for (int l = 0; l < row_lanes; ++l) t += s_p[l * col_threads + cl];
+      partials[(int64_t)blk * C + cl] = t;
+    }
+    return;
+  }
+  if (threadIdx.x < 64) {                                // scale_sum_kernel: one wave, fixed order
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n_nll; i += 64) s += nll[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s * scale;
+  }
+}
 }  // namespace lasr
+
+// the dense small-vocabulary head's tail in one launch (see head_tail_kernel): gl_bf16 = row-padded bf16 copy of gl [rows][C],
+// bias_grad = column sums of gl (through `workspace`, second stage = launch_reduce_partials, fixed order), loss = scale * sum(nll).
+// Returns 1 (nothing launched) for shapes the merged grid does not take (C > 256).
+int lasr::head_tail(const float* gl, int64_t rows, int64_t C, void* gl_bf16, int64_t ld_out, float* bias_grad, void* workspace,
+                    size_t workspace_bytes, const float* nll, int64_t n_nll, float scale, float* loss, void* stream) {
+  static const bool off = getenv("LASR_HEAD_TAIL_MERGED") && atoi(getenv("LASR_HEAD_TAIL_MERGED")) == 0;
+  if (off || C > 256 || C < 1) return 1;
+  LASR_CHECK_ARG(gl && gl_bf16 && bias_grad && workspace && nll && loss && rows > 0 && ld_out >= C && n_nll > 0, "head_tail: bad argument");
+  if (workspace_bytes < lasr_colsum_workspace_bytes(rows, C)) return fail(LASR_E_WORKSPACE, "head_tail: workspace");
+  const int rpw = colsum_rows(C);
+  const int n_sum = (int)cdiv(rows, rpw);
+  int64_t n_cast = cdiv(rows * ld_out, 256);
+  if (n_cast > 256 * 16) n_cast = 256 * 16;
+  float* partials = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(lasr::head_tail_kernel, dim3((unsigned)(n_cast + n_sum + 1)), dim3(256), 0, as_stream(stream), gl, rows, C,
+                     reinterpret_cast<bf16_t*>(gl_bf16), ld_out, (int)n_cast, partials, rpw, n_sum, nll, n_nll, scale, loss);
+  LASR_LAUNCH_CHECK("head_tail_kernel");
+  return launch_reduce_partials(partials, n_sum, C, bias_grad, C, nullptr, as_stream(stream));   // f64, fixed order
+}
 
 // out[i] = sum_p partials[p*n + i] for up to 64 independent (partials, out, n, n_partials) segments in ONE launch:
 // the deferred reductions of a backward stage (split-K slabs of the 1x1 weight gradients, per-(utterance, chunk)

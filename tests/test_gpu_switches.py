@@ -75,7 +75,12 @@ def test_bn_inside_the_depthwise_forward_is_bit_identical(dev):
     a.pop("prof_brackets"); b.pop("prof_brackets")
     assert a == b
     # and at the probe's own short shape nothing is fused (T' = 201): the two builds of the step make the same launches
-    assert _run({}) == _run({"LASR_BN_DW_FUSE": "0"})
+    base = _run({})
+    assert base == _run({"LASR_BN_DW_FUSE": "0"})
+    # the dense head's tail (padded bf16 copy of d(logits), bias-gradient column sums, loss mean) in one launch or in three: same numbers
+    sep = _run({"LASR_HEAD_TAIL_MERGED": "0"})
+    sep.pop("prof_brackets"); base.pop("prof_brackets")
+    assert sep == base, (sep, base)
 
 
 def test_large_vocabulary_head_switch(dev):
