@@ -8,6 +8,7 @@
 // s-1 / s-2 (s+1 / s+2) neighbours cross lanes with one shuffle each, so a time step needs no
 // LDS and no barrier; the emission log-probs of step t+1 are fetched while step t is computed.
 #include "ctc_lattice.h"
+#include "fused.h"
 
 namespace lasr {
 
@@ -37,6 +38,36 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restric
   const float lse = logf(s);
   float* y = logp + row * C;
   for (int64_t c = lane; c < C; c += 64) y[c] = (x[c] - m) - lse;
+  if (argmax && lane == 0) argmax[row] = (int32_t)mi;
+}
+
+// The same for a narrow head (C <= 64: one class per lane) straight from the decoder GEMM's split-K slabs: logits = sum of the slabs
+// (in slab order, as gemm_split_reduce_kernel sums them) + bias, written out for the taps, then the row's log_softmax and argmax in
+// registers - the split reduction's own launch and one round trip of the logits are gone; the arithmetic is log_softmax_kernel's.
+__global__ __launch_bounds__(256) void log_softmax_split_kernel(const float* __restrict__ ws, int split, const float* __restrict__ bias,
+                                                                float* __restrict__ logits, float* __restrict__ logp,
+                                                                int32_t* __restrict__ argmax, int64_t N, int64_t C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const bool live = lane < C;
+  const int64_t i = row * C + (live ? lane : 0);
+  float v = 0.f;
+  for (int p = 0; p < split; ++p) v += ws[(int64_t)p * N * C + i];
+  if (bias) v += bias[live ? lane : 0];
+  if (live) logits[i] = v;
+  float m = live ? v : kNegInf;
+  int64_t mi = live ? (int64_t)lane : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64);
+    const int64_t oi = __shfl_xor((long long)mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  float s = live ? expf(v - m) : 0.f;
+  s = wave_sum(s);
+  const float lse = logf(s);
+  if (live) logp[i] = (v - m) - lse;
   if (argmax && lane == 0) argmax[row] = (int32_t)mi;
 }
 
@@ -172,6 +203,20 @@ extern "C" int lasr_log_softmax(const float* logits, float* logp, int32_t* argma
   LASR_CHECK_ARG(logits && logp && N > 0 && C > 0, "lasr_log_softmax: bad argument");
   hipLaunchKernelGGL(log_softmax_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, as_stream(stream), logits, logp, argmax, N, C);
   LASR_LAUNCH_CHECK("log_softmax_kernel");
+  return 0;
+}
+
+bool lasr::log_softmax_split_on(int64_t C) {
+  static const bool off = getenv("LASR_LOGSOFTMAX_SPLIT") && atoi(getenv("LASR_LOGSOFTMAX_SPLIT")) == 0;   // dev switch
+  return !off && C >= 1 && C <= 64;
+}
+
+int lasr::log_softmax_split(const float* partials, int split, const float* bias, float* logits, float* logp, int32_t* argmax, int64_t N,
+                            int64_t C, void* stream) {
+  LASR_CHECK_ARG(partials && logits && logp && N > 0 && split >= 1 && C >= 1 && C <= 64, "log_softmax_split: bad argument");
+  hipLaunchKernelGGL(log_softmax_split_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, as_stream(stream), partials, split, bias, logits, logp,
+                     argmax, N, C);
+  LASR_LAUNCH_CHECK("log_softmax_split_kernel");
   return 0;
 }
 

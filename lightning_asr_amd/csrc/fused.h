@@ -21,4 +21,9 @@ int mask_lengths_step_cast(const float* pct, int64_t B, int64_t T_, int32_t* len
 int head_tail(const float* gl, int64_t rows, int64_t C, void* gl_bf16, int64_t ld_out, float* bias_grad, void* workspace,
               size_t workspace_bytes, const float* nll, int64_t n_nll, float scale, float* loss, void* stream);
 
+// ctc.hip: the decoder GEMM's split-K reduction (+ bias) and lasr_log_softmax in one launch, for C <= 64 (log_softmax_split_on)
+bool log_softmax_split_on(int64_t C);
+int log_softmax_split(const float* partials, int split, const float* bias, float* logits, float* logp, int32_t* argmax, int64_t N, int64_t C,
+                      void* stream);
+
 }  // namespace lasr

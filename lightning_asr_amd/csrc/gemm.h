@@ -29,6 +29,9 @@ namespace lstm { struct BwdArgs; }
 // lstm_job (optional): the BiLSTM backward recurrences of lstm_utts utterances run in the same grid, ahead of the tiles (lstm_body.h)
 int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job = nullptr,
                            int lstm_utts = 0);
+// gemm.hip: lasr_gemm(split_k > 1, f32 result) without its final sum: the slabs stay at the head of `workspace`, [*splits][M*N] f32
+int gemm_split_partials_one(const void* A, const void* B, int dtype_ab, int64_t M, int64_t N, int64_t K, int transA, int transB, int split_k,
+                            void* workspace, size_t workspace_bytes, int* splits, void* stream);
 // lasr_gemm_multi_split_partials with the context branch's lasr_bilstm_bwd recurrence in its grid (and that call's dW_hh reduction
 // behind it); returns 1 without launching anything when the shapes do not take the combined grid (the caller then makes both calls)
 int gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits,

@@ -264,7 +264,9 @@ struct StatOut { const float* partials; int tiles; };
 static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dtype_c, int64_t M, int64_t N, int64_t K,
                      int transA, int transB, const float* bias, const void* addend, const int32_t* row_lens,
                      int64_t rows_per_seq, float* stats, int split_k, void* workspace, size_t workspace_bytes,
-                     void* stream, StatOut* stat_out, int64_t lda = 0, int64_t ldb = 0, int64_t ldc = 0) {
+                     void* stream, StatOut* stat_out, int64_t lda = 0, int64_t ldb = 0, int64_t ldc = 0, int* split_left_out = nullptr) {
+  // split_left_out != null (split_k > 1): the split-K slabs stay unreduced at the head of the workspace ([*split_left_out][M*N] f32,
+  // no bias) for a consumer that sums them itself (gemm_split_partials_one)
   LASR_CHECK_ARG(A && B && C, "lasr_gemm: null pointer");
   LASR_CHECK_ARG((dtype_ab == LASR_F32 || dtype_ab == LASR_BF16) && (dtype_c == LASR_F32 || dtype_c == LASR_BF16), "lasr_gemm: bad dtype");
   LASR_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && split_k >= 1 && split_k <= 1024, "lasr_gemm: M=%lld N=%lld K=%lld split=%d",
@@ -310,7 +312,9 @@ static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dt
   else rc = dtype_c == LASR_F32 ? launch_f32<bf16_t, float>(g, transA, transB, grid, st) : launch_f32<bf16_t, bf16_t>(g, transA, transB, grid, st);
   prof_end(tok, st);
   if (rc) return rc;
-  if (g.split_ws) {
+  if (g.split_ws && split_left_out) {
+    *split_left_out = split_k;
+  } else if (g.split_ws) {
     const int64_t mn = M * N;
     if (dtype_c == LASR_F32)
       hipLaunchKernelGGL(gemm_split_reduce_kernel<float>, dim3((unsigned)cdiv(mn, 256)), dim3(256), 0, st, g.split_ws, split_k, M, N, g.ldc, bias, (const float*)addend, (float*)C);
@@ -324,6 +328,14 @@ static int gemm_impl(const void* A, const void* B, void* C, int dtype_ab, int dt
     LASR_TRY(launch_reduce_partials(g.stat_partials, grid_m, 2 * N, stats, 2 * N, nullptr, st));
   }
   return 0;
+}
+
+// one split-K problem, slabs left unreduced: partials = workspace, [*splits][M*N] f32 (the bias is NOT added)
+int lasr::gemm_split_partials_one(const void* A, const void* B, int dtype_ab, int64_t M, int64_t N, int64_t K, int transA, int transB,
+                                  int split_k, void* workspace, size_t workspace_bytes, int* splits, void* stream) {
+  LASR_CHECK_ARG(splits && split_k > 1 && workspace, "gemm_split_partials_one: bad argument");
+  return gemm_impl(A, B, workspace /* unused: nothing is reduced into C */, dtype_ab, LASR_F32, M, N, K, transA, transB, nullptr, nullptr, nullptr,
+                   0, nullptr, split_k, workspace, workspace_bytes, stream, nullptr, 0, 0, 0, splits);
 }
 
 extern "C" int lasr_gemm_ld(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int dtype_ab, int dtype_c,

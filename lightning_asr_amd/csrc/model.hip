@@ -643,6 +643,14 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
                              &m->lean_tiles, stream);
   }
   const int dec_split = (dt == LASR_BF16 && C <= 128) ? dec_split_k() : 1;
+  if (dec_split > 1 && log_softmax_split_on(C)) {      // narrow head: the split-K slabs are summed by the log_softmax launch itself (fused.h)
+    int splits = 0;
+    LASR_TRY(gemm_split_partials_one(x, wptr(m, params, ws, m->w_dec), dt, N, C, 1024, 0, 0, dec_split, scratch, p.scratch_bytes, &splits, stream));
+    ProfScope ps(LASR_PROF_HEAD, stream, (2.0 + splits) * N * C * sizeof(float));
+    const int rc = log_softmax_split(reinterpret_cast<const float*>(scratch), splits, params + m->b_dec, atf(ws, p.o_logits), logp_out, argmax_out,
+                                     N, C, stream);
+    return rc;
+  }
   LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->w_dec), atf(ws, p.o_logits), dt, LASR_F32, N, C, 1024, 0, 0, params + m->b_dec,
                      nullptr, nullptr, 0, nullptr, dec_split, scratch, p.scratch_bytes, stream));
   ProfScope ps(LASR_PROF_HEAD, stream, 2.0 * N * C * sizeof(float));
