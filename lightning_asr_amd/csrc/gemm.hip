@@ -528,8 +528,10 @@ int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* pro
   float* pwhh = reinterpret_cast<float*>(workspace);
   const lstm::BwdArgs a = {dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved, dg_f, dg_r, pwhh};
   LASR_TRY(multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, &a, (int)B));
-  // pwhh is [B][2][G*H]: sum over b (lstm.hip)
-  return launch_reduce_partials(pwhh, (int)B, (int64_t)2 * lstm::G * lstm::H, dwhh_f, (int64_t)lstm::G * lstm::H, dwhh_r, as_stream(stream));
+  // dW_hh from the stored gate gradients (lstm.hip): pwhh is [B * kDwZ][2][G*H], summed over the first index
+  LASR_TRY(lstm::launch_dwhh_partials(a, B, as_stream(stream)));
+  return launch_reduce_partials(pwhh, (int)B * lstm::kDwZ, (int64_t)2 * lstm::G * lstm::H, dwhh_f, (int64_t)lstm::G * lstm::H, dwhh_r,
+                                as_stream(stream));
 }
 
 static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,

@@ -861,9 +861,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_lstm_kernel(Bf16Mu
     const int slot = threadIdx.x / 192;
     if (slot >= 2) return;                                // (a finished wave is not waited for by s_barrier)
     const int b = blockIdx.x, dir = slot;
-    int len = job.a.lens[b];
-    if (len > job.a.Tt) len = (int)job.a.Tt;
-    lstm::bilstm_bwd_body<bf16_t, true, KP, true>(job.a, b, dir, (int)threadIdx.x - slot * 192, 192, sm[slot], [] { lds_barrier(); }, len);
+    lstm::bilstm_bwd_body<bf16_t, true, KP>(job.a, b, dir, (int)threadIdx.x - slot * 192, 192, sm[slot], [] { lds_barrier(); });
     return;
   }
   const int lid_all = xcd_remap((int)blockIdx.x - job.n_wg, gm.total);

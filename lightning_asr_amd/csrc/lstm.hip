@@ -54,46 +54,58 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* _
     const int k = (int)(i - t * H);
     Elem<T>::st(out + ((int64_t)b * Tt + t) * ldo + col0 + dir * H + k, 0.f);
   }
-  float ring[kPre];
-#pragma unroll
-  for (int k = 0; k < kPre; ++k) ring[k] = k < len ? gx[(int64_t)(dir ? len - 1 - k : k) * G + j] : 0.f;
   float c = 0.f;
   __syncthreads();
-  for (int s0 = 0; s0 < len; s0 += kPre) {
+  auto step = [&](int s, float gxv) {
+    const int t = dir ? len - 1 - s : s;
+    float a0 = gxv + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* hp = s_h[s & 1];
+#pragma unroll
+    for (int k4 = 0; k4 < H; k4 += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(hp + k4);
+      a0 = fmaf(w[k4], hv.x, a0); a1 = fmaf(w[k4 + 1], hv.y, a1); a2 = fmaf(w[k4 + 2], hv.z, a2); a3 = fmaf(w[k4 + 3], hv.w, a3);
+    }
+    const float pre = (a0 + a1) + (a2 + a3);
+    // one exp + one rcp for either non-linearity, no divergent branch: tanh(x) = 2 sigmoid(2x) - 1
+    const float sg = sigmoid_fast(q == 2 ? 2.f * pre : pre);
+    const float a = q == 2 ? fmaf(2.f, sg, -1.f) : sg;
+    float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
+    sv[j] = a;
+    const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
+    c = fmaf(fg, c, ig * gg);
+    const float h = og * tanh_fast(c);
+    if (q == 0) {
+      s_h[(s + 1) & 1][u] = h;
+      sv[G + u] = c;
+      sv[G + H + u] = h;
+      Elem<T>::st(out + ((int64_t)b * Tt + t) * ldo + col0 + dir * H + u, h);
+    }
+    lds_barrier();
+  };
+  // The first len % kPre steps fetch their own operand (and wait for it); the rest is a whole number of kPre-step rounds whose loop
+  // body is ONE basic block - with the `s < len` tests of a ragged last round inside it, the compiler's wait-count bookkeeping gave
+  // up at the loop header and drained every outstanding load and store once per round (round 4, read off the ISA).
+  const int odd = len % kPre;
+  for (int s = 0; s < odd; ++s) step(s, gx[(int64_t)(dir ? len - 1 - s : s) * G + j]);
+  float ring[kPre];
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) {
+    const int sn = min(odd + k, max(len - 1, 0));
+    ring[k] = gx[(int64_t)(dir ? max(len - 1 - sn, 0) : sn) * G + j];
+  }
+#pragma unroll
+  for (int k = 0; k < kPre; ++k) asm volatile("" : "+v"(ring[k]));   // the priming loads land here (see lstm_body.h: the loop's waits are priced on its own round-to-round distances)
+  for (int s0 = odd; s0 < len; s0 += kPre) {
 #pragma unroll
     for (int k = 0; k < kPre; ++k) {
       const int s = s0 + k;
-      if (s < len) {   // workgroup-uniform
-        const int t = dir ? len - 1 - s : s;
-        float a0 = ring[k] + bias, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        {   // unconditional (clamped) refill: a load inside a branch is followed by s_waitcnt vmcnt(0) at the join - the whole
-            // HBM round trip on the step's critical path (0.65 us per step measured), which is what the ring is there to hide
-          const int sn = min(s + kPre, len - 1);
-          ring[k] = gx[(int64_t)(dir ? len - 1 - sn : sn) * G + j];
-        }
-        const float* hp = s_h[s & 1];
-#pragma unroll
-        for (int k4 = 0; k4 < H; k4 += 4) {
-          const float4 hv = *reinterpret_cast<const float4*>(hp + k4);
-          a0 = fmaf(w[k4], hv.x, a0); a1 = fmaf(w[k4 + 1], hv.y, a1); a2 = fmaf(w[k4 + 2], hv.z, a2); a3 = fmaf(w[k4 + 3], hv.w, a3);
-        }
-        const float pre = (a0 + a1) + (a2 + a3);
-        // one exp + one rcp for either non-linearity, no divergent branch: tanh(x) = 2 sigmoid(2x) - 1
-        const float sg = sigmoid_fast(q == 2 ? 2.f * pre : pre);
-        const float a = q == 2 ? fmaf(2.f, sg, -1.f) : sg;
-        float* sv = saved + (((int64_t)b * Tt + t) * 2 + dir) * (G + 2 * H);
-        sv[j] = a;
-        const float ig = quad_bcast<0>(a), fg = quad_bcast<1>(a), gg = quad_bcast<2>(a), og = quad_bcast<3>(a);
-        c = fmaf(fg, c, ig * gg);
-        const float h = og * tanh_fast(c);
-        if (q == 0) {
-          s_h[(s + 1) & 1][u] = h;
-          sv[G + u] = c;
-          sv[G + H + u] = h;
-          Elem<T>::st(out + ((int64_t)b * Tt + t) * ldo + col0 + dir * H + u, h);
-        }
-        lds_barrier();
-      }
+      float gxv;                                 // the slot's old value moves out before the refill is issued (lstm_body.h)
+      asm volatile("v_mov_b32 %0, %1" : "=v"(gxv) : "v"(ring[k]));
+      // unconditional (clamped) refill: a load inside a branch is followed by s_waitcnt vmcnt(0) at the join - the whole HBM round
+      // trip on the step's critical path (0.65 us per step measured), which is what the ring is there to hide
+      const int sn = min(s + kPre, len - 1);
+      ring[k] = gx[(int64_t)(dir ? len - 1 - sn : sn) * G + j];
+      step(s, gxv);
     }
   }
 }
@@ -102,9 +114,66 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_fwd_kernel(const float* _
 template <typename T>
 __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(lstm::BwdArgs a) {
   __shared__ lstm::BwdSmem sm;
-  int len = a.lens[blockIdx.x];
-  if (len > a.Tt) len = (int)a.Tt;
-  lstm::bilstm_bwd_body<T, false, kPre, true>(a, blockIdx.x, blockIdx.y, threadIdx.x, kLstmThreads, sm, [] { lds_barrier(); }, len);
+  lstm::bilstm_bwd_body<T, false, kPre>(a, blockIdx.x, blockIdx.y, threadIdx.x, kLstmThreads, sm, [] { lds_barrier(); });
+}
+
+// dW_hh[j][k] = sum_{b,t} dg[b,t,j] h_prev[b,t,k] (h_prev = the direction's previous hidden state, nothing at its first step) from
+// the stored gate gradients and the forward pass's saved states - off the recurrence's chain since round 4.  Workgroup = one
+// (utterance, direction, quarter of the time axis), four 192-thread slots that each walk a sixteenth of the steps: thread j keeps row
+// j of dW_hh in 40 registers, the step's hidden vector arrives through wave-uniform addresses.  The slots' sums meet in LDS (two
+// rounds over a [2][G*H] image); pwhh [B * kDwZ][2][G*H] partials go to launch_reduce_partials.
+static constexpr int kDwSlices = 4, kDwSlot = 192;
+__global__ __launch_bounds__(kDwSlices * kDwSlot) void bilstm_dwhh_kernel(lstm::BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_acc[2][G * H];
+  const int b = blockIdx.x, dir = blockIdx.y, z = blockIdx.z;
+  const int slice = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kDwSlot);
+  const int tid_in = (int)threadIdx.x - slice * kDwSlot;
+  const bool live = tid_in < G;
+  const int j = min(tid_in, G - 1);
+  const int64_t Tt = a.Tt;
+  int len = a.lens[b];
+  if (len > Tt) len = (int)Tt;
+  // steps that have a previous hidden state: forward t = 1 .. len-1 with h(t-1), reverse t = 0 .. len-2 with h(t+1)
+  const int n = max(len - 1, 0), parts = lstm::kDwZ * kDwSlices;
+  const int per = (n + parts - 1) / parts, part = z * kDwSlices + slice;
+  const int i0 = min(part * per, n), i1 = min(i0 + per, n);
+  const float* dg = (dir ? a.dg_r : a.dg_f) + (int64_t)b * Tt * G + j;
+  const float* hbase = a.saved + ((int64_t)b * Tt * 2 + dir) * (G + 2 * H) + G + H;
+  float dw[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) dw[k] = 0.f;
+#pragma unroll 2
+  for (int i = i0; i < i1; ++i) {
+    const int t = dir ? i : i + 1, tp = dir ? t + 1 : t - 1;
+    const float my = dg[(int64_t)t * G];
+    const float* hp = hbase + (int64_t)tp * 2 * (G + 2 * H);
+#pragma unroll
+    for (int k = 0; k < H; ++k) dw[k] = fmaf(my, hp[k], dw[k]);
+  }
+  // slots 0, 1 lay their rows down, slots 2, 3 add theirs on top, then the two images are summed on the way out
+  float* mine = s_acc[slice & 1] + j * H;
+  if (live && slice < 2) {
+#pragma unroll
+    for (int k = 0; k < H; k += 4) *reinterpret_cast<float4*>(mine + k) = make_float4(dw[k], dw[k + 1], dw[k + 2], dw[k + 3]);
+  }
+  __syncthreads();
+  if (live && slice >= 2) {
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      float4 v = *reinterpret_cast<float4*>(mine + k);
+      v.x += dw[k]; v.y += dw[k + 1]; v.z += dw[k + 2]; v.w += dw[k + 3];
+      *reinterpret_cast<float4*>(mine + k) = v;
+    }
+  }
+  __syncthreads();
+  float* out = a.pwhh + (((int64_t)b * lstm::kDwZ + z) * 2 + dir) * (G * H);
+  for (int e = threadIdx.x; e < G * H; e += kDwSlices * kDwSlot) out[e] = s_acc[0][e] + s_acc[1][e];
+}
+
+int lstm::launch_dwhh_partials(const lstm::BwdArgs& a, int64_t B, hipStream_t st) {
+  hipLaunchKernelGGL(bilstm_dwhh_kernel, dim3((unsigned)B, 2, lstm::kDwZ), dim3(kDwSlices * kDwSlot), 0, st, a);
+  LASR_LAUNCH_CHECK("bilstm_dwhh_kernel");
+  return 0;
 }
 
 // dst[n][dcol0 + c] = src[n][scol0 + c] for c < ncols (optionally += ), with dtype conversion
@@ -143,7 +212,7 @@ extern "C" int lasr_bilstm_fwd(const float* gx_f, const float* gx_r, const float
   return 0;
 }
 
-extern "C" size_t lasr_bilstm_bwd_workspace_bytes(int64_t B) { return (size_t)B * 2 * G * H * sizeof(float); }
+extern "C" size_t lasr_bilstm_bwd_workspace_bytes(int64_t B) { return (size_t)B * lstm::kDwZ * 2 * G * H * sizeof(float); }
 
 extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f, const float* whh_r,
                                const int32_t* lens, int64_t B, int64_t T_, const float* saved, float* dg_f, float* dg_r, float* dwhh_f,
@@ -159,8 +228,9 @@ extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int
   if (dtype == LASR_F32) hipLaunchKernelGGL(bilstm_bwd_kernel<float>, grid, dim3(kLstmThreads), 0, st, a);
   else hipLaunchKernelGGL(bilstm_bwd_kernel<bf16_t>, grid, dim3(kLstmThreads), 0, st, a);
   LASR_LAUNCH_CHECK("bilstm_bwd_kernel");
-  // pwhh is [B][2][G*H]: sum over b with a stride of 2*G*H -> view as B partials of 2*G*H columns, split at G*H
-  return launch_reduce_partials(pwhh, (int)B, (int64_t)2 * G * H, dwhh_f, (int64_t)G * H, dwhh_r, st);
+  LASR_TRY(lstm::launch_dwhh_partials(a, B, st));
+  // pwhh is [B * kDwZ][2][G*H]: sum over the first index -> B * kDwZ partials of 2*G*H columns, split at G*H
+  return launch_reduce_partials(pwhh, (int)B * lstm::kDwZ, (int64_t)2 * G * H, dwhh_f, (int64_t)G * H, dwhh_r, st);
 }
 
 extern "C" int lasr_copy_cols(const void* src, int src_dtype, int64_t ld_src, int64_t scol0, void* dst, int dst_dtype, int64_t ld_dst,
