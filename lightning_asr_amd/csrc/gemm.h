@@ -26,18 +26,19 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
 // up to 32 split-K weight-gradient problems (transA = transB = 1, f32 slabs in g[i].split_ws), one launch
 int launch_gemm_bf16_dual(const GemmArgs& g, const void* A2, int64_t lda2, int64_t K1, const float* bias, int act, hipStream_t st);
 namespace lstm { struct BwdArgs; }
-// lstm_job (optional): the BiLSTM backward recurrences of lstm_utts utterances run in the same grid, ahead of the tiles (lstm_body.h)
+// lstm_job (optional): the BiLSTM backward recurrences run in the same grid as lstm_wgs workgroups, ahead of the tiles (lstm_body.h)
 int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job = nullptr,
-                           int lstm_utts = 0);
+                           int lstm_wgs = 0);
 // gemm.hip: lasr_gemm(split_k > 1, f32 result) without its final sum: the slabs stay at the head of `workspace`, [*splits][M*N] f32
 int gemm_split_partials_one(const void* A, const void* B, int dtype_ab, int64_t M, int64_t N, int64_t K, int transA, int transB, int split_k,
                             void* workspace, size_t workspace_bytes, int* splits, void* stream);
-// lasr_gemm_multi_split_partials with the context branch's lasr_bilstm_bwd recurrence in its grid (and that call's dW_hh reduction
-// behind it); returns 1 without launching anything when the shapes do not take the combined grid (the caller then makes both calls)
-int gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits,
-                                              const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f,
-                                              const float* whh_r, const int32_t* lens, int64_t B, int64_t T_, const float* saved, float* dg_f,
-                                              float* dg_r, float* dwhh_f, float* dwhh_r, void* workspace, size_t workspace_bytes, void* stream);
+// lasr_gemm_multi_split_partials with the context branch's BiLSTM backward recurrences (lstm_body.h) in its grid, and the dW_hh /
+// bias-gradient partial sums (rec.pwhh [2][B * kDwZ][G*H], rec.pbias [2][B * kDwZ][G]: the caller reduces them) behind it; returns 1
+// without launching anything when the shapes do not take the combined grid (the caller then makes the separate calls).
+// Only the first *n_taken problems are launched (as many tiles as finish, in one round of workgroups, about when the recurrences do):
+// the caller keeps the rest for its next batched launch.
+int gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int* n_taken, int split_k, float* const* slabs, int* splits,
+                                              const lstm::BwdArgs& rec, int dtype, int64_t B, void* stream);
 int launch_gemm_bf16_rowstat(const GemmArgs& g, float* row_stat, int32_t* row_arg, int* n_col_tiles, hipStream_t st);
 
 }  // namespace lasr

@@ -502,40 +502,51 @@ extern "C" int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, in
 }
 
 static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,
-                            const lstm::BwdArgs* lstm_job, int lstm_utts);
+                            const lstm::BwdArgs* lstm_job, int lstm_wgs);
 
 extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs,
                                               int* splits, void* stream) {
   return multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, nullptr, 0);
 }
 
-int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits,
-                                                    const void* dout, int dtype, int64_t ld_dout, int64_t col0, const float* whh_f,
-                                                    const float* whh_r, const int32_t* lens, int64_t B, int64_t T_, const float* saved,
-                                                    float* dg_f, float* dg_r, float* dwhh_f, float* dwhh_r, void* workspace,
-                                                    size_t workspace_bytes, void* stream) {
+int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int* n_taken, int split_k, float* const* slabs, int* splits,
+                                                    const lstm::BwdArgs& rec, int dtype, int64_t B, void* stream) {
+  const int64_t T_ = rec.Tt;
   static const bool off = getenv("LASR_LSTM_BESIDE_WGRAD") && atoi(getenv("LASR_LSTM_BESIDE_WGRAD")) == 0;
-  if (off || dtype != LASR_BF16 || B % 8 != 0 || B > 128 || n_probs < 1) return 1;
+  if (off || dtype != LASR_BF16 || B % 8 != 0 || B > 128 || n_probs < 1 || !n_taken) return 1;
+  // How many slices the tiles should be cut into so that they are through when the recurrences are (measured on the MI355X, round 4:
+  // 0.36 us per recurrence step; a 256 x 256 tile 1.7 us per 64 rows of K + ~15 us around them), and how many tiles of that length
+  // fit in ONE round beside the B recurrence workgroups.  The problems past that budget stay with the caller: the stage's closing
+  // launch has room for them (cfg4: 64 of the tiles here in 3 slices beside 2 B = 64 recurrence workgroups: the launch takes 216 us, the
+  // closing launch 73 instead of 48).  LASR_LSTM_WGRAD_BUDGET=0: all of them, as before.
+  static const bool budgeted = !(getenv("LASR_LSTM_WGRAD_BUDGET") && atoi(getenv("LASR_LSTM_WGRAD_BUDGET")) == 0);
+  const double rec_us = 0.36 * (double)T_;
+  int want = 1;
+  while (want < std::min(split_k, 16) && (double)cdiv(cdiv(probs[0].K, want), 64) * 1.7 + 15.0 > rec_us) ++want;
+  static const bool pair = getenv("LASR_LSTM_PAIR") && atoi(getenv("LASR_LSTM_PAIR")) == 1;   // (gemm_bf16.hip: the two directions of an utterance in one workgroup)
+  const int64_t lstm_wgs = pair ? B : 2 * B;
+  const int64_t budget = budgeted ? std::max<int64_t>((256 - lstm_wgs) / want, 1) : 256 - lstm_wgs;
   int64_t tiles_big = 0;
+  int take = 0;
   for (int i = 0; i < n_probs; ++i) {
     const lasr_gemm_problem& q = probs[i];
     if (q.M % 8 || q.N % 8 || reinterpret_cast<uintptr_t>(q.A) % 16 || reinterpret_cast<uintptr_t>(q.B) % 16 || q.K < 1024) return 1;
-    tiles_big += cdiv(q.M, 256) * cdiv(q.N, 256);
+    const int64_t t = cdiv(q.M, 256) * cdiv(q.N, 256);
+    if (tiles_big + t > budget) break;
+    tiles_big += t;
+    take = i + 1;
   }
-  if (tiles_big + B > 256) return 1;                       // the recurrences and one slice of every tile must make ONE round
-  LASR_CHECK_ARG(dout && whh_f && whh_r && lens && saved && dg_f && dg_r && dwhh_f && dwhh_r && workspace, "gemm + BiLSTM grid: null pointer");
-  if (workspace_bytes < lasr_bilstm_bwd_workspace_bytes(B)) return fail(LASR_E_WORKSPACE, "gemm + BiLSTM grid: workspace");
-  float* pwhh = reinterpret_cast<float*>(workspace);
-  const lstm::BwdArgs a = {dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved, dg_f, dg_r, pwhh};
-  LASR_TRY(multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, &a, (int)B));
-  // dW_hh from the stored gate gradients (lstm.hip): pwhh is [B * kDwZ][2][G*H], summed over the first index
-  LASR_TRY(lstm::launch_dwhh_partials(a, B, as_stream(stream)));
-  return launch_reduce_partials(pwhh, (int)B * lstm::kDwZ, (int64_t)2 * lstm::G * lstm::H, dwhh_f, (int64_t)lstm::G * lstm::H, dwhh_r,
-                                as_stream(stream));
+  if (take < 1 || tiles_big + lstm_wgs > 256) return 1;           // the recurrences and one slice of every tile must make ONE round
+  n_probs = take;
+  *n_taken = take;
+  LASR_CHECK_ARG(rec.dout && rec.whh_f && rec.whh_r && rec.lens && rec.saved && rec.dg_f && rec.dg_r && rec.pwhh, "gemm + BiLSTM grid: null pointer");
+  LASR_TRY(multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, &rec, (int)lstm_wgs));
+  // dW_hh (and the bias gradients' column sums) from the stored gate gradients (lstm.hip); the caller sums the partials
+  return lstm::launch_dwhh_partials(rec, B, as_stream(stream));
 }
 
 static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,
-                            const lstm::BwdArgs* lstm_job, int lstm_utts) {
+                            const lstm::BwdArgs* lstm_job, int lstm_wgs) {
   LASR_CHECK_ARG(probs && slabs && splits && n_probs >= 1 && n_probs <= 32 && split_k >= 1 && split_k <= 1024,
                  "lasr_gemm_multi_split_partials: bad argument");
   GemmArgs g[32];
@@ -561,7 +572,7 @@ static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int spl
     // one round of workgroups, as many CUs as the slice count reaches (measured on the 71-tile stage of the plain model:
     // 3 slices / 213 workgroups 175 us, 5 / 355 180 us, 7 / 497 194 us, 10 / 710 198 us: a second round costs its
     // prologue and another 256 KB slab per tile)
-    split = (int)std::min<int64_t>(std::max<int64_t>((256 - lstm_utts) / std::max<int64_t>(tiles_big, 1), 1), std::min(split_k, 16));   // (CUs the recurrences take)
+    split = (int)std::min<int64_t>(std::max<int64_t>((256 - lstm_wgs) / std::max<int64_t>(tiles_big, 1), 1), std::min(split_k, 16));   // (CUs the recurrences take)
   } else {
     split = (int)std::min<int64_t>(std::max<int64_t>(cdiv(1536, tiles_small), 1), split_k);
   }
@@ -587,7 +598,7 @@ static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int spl
   }
   const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
   if (lstm_job && !big_tile) { prof_end(tok, st); return fail(LASR_E_SHAPE, "gemm + BiLSTM grid needs the 256-row tile form"); }
-  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st, lstm_job, lstm_utts);
+  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st, lstm_job, lstm_wgs);
   prof_end(tok, st);
   return rc;
 }

@@ -854,13 +854,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi g
 // per frame whatever else runs, the weight gradients of the units above block3 do not depend on it: 437 us on 64 small workgroups
 // with 190 CUs idle becomes ~500 us with the stage's biggest launch inside it (cfg4 step 3.751 -> 3.646 ms).
 struct LstmJob { lstm::BwdArgs a; int n_wg; int n_utt; };
-template <bool NTL, int KP>
+template <bool NTL, int KP, bool PAIR>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_lstm_kernel(Bf16Multi gm, LstmJob job) {
   if ((int)blockIdx.x < job.n_wg) {                       // workgroup-uniform
     __shared__ lstm::BwdSmem sm[2];
     const int slot = threadIdx.x / 192;
-    if (slot >= 2) return;                                // (a finished wave is not waited for by s_barrier)
-    const int b = blockIdx.x, dir = slot;
+    if (slot >= (PAIR ? 2 : 1)) return;                   // (a finished wave is not waited for by s_barrier)
+    const int b = PAIR ? blockIdx.x : blockIdx.x >> 1, dir = PAIR ? slot : (blockIdx.x & 1);
     lstm::bilstm_bwd_body<bf16_t, true, KP>(job.a, b, dir, (int)threadIdx.x - slot * 192, 192, sm[slot], [] { lds_barrier(); });
     return;
   }
@@ -988,7 +988,7 @@ int launch_gemm_bf16_rowstat(const GemmArgs& g, float* row_stat, int32_t* row_ar
 }
 
 // n <= 32 split-K problems with f32 slab output, both operands row-contiguous ([K][M], [K][N]: weight gradients)
-int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job, int lstm_utts) {
+int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job, int lstm_wgs) {
   if (n < 1 || n > kMaxMulti) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: 1..%d problems", kMaxMulti);
   Bf16Multi m;
   bool vec = true;
@@ -1006,11 +1006,16 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
   if (big_tile) {
     if (!vec) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: the 256-row tile needs 16-byte aligned operand rows");
     if (lstm_job) {                                        // the context branch's recurrences ride in this grid (bf16 model)
-      LstmJob job; job.a = *lstm_job; job.n_wg = (lstm_utts + 7) / 8 * 8; job.n_utt = lstm_utts;
-      if (job.n_wg != lstm_utts) return fail(LASR_E_SHAPE, "gemm + BiLSTM grid: the batch must be a multiple of 8 utterances");
-      // look-ahead of the recurrence's operand ring: measured in the cfg4 step, one call (profiles/r04_cfg4_lstm_beside_wgrad.txt):
-      // 8 steps 3.646 ms, 16 steps 3.662, 32 steps 3.665 (the two launches one after the other: 3.751) - the stand-alone kernel's 8
-      hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, lstm::kPre>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      // One recurrence per workgroup (2 B workgroups) or the two directions of an utterance in one (B workgroups, LASR_LSTM_PAIR=1);
+      // operand ring 16 steps ahead.  Measured in the cfg4 step after the recurrence's rewrite (profiles/r04_cfg4_lstm_pair_kp.txt):
+      // paired / 8 steps 3.411 ms, paired / 16 3.395, single / 8 3.382, single / 16 3.378 - a recurrence alone on its CU keeps the
+      // stand-alone kernel's step time (two of them share the CU's LDS pipe and issue slots), and under the GEMM tiles' traffic a load
+      // takes longer than 8 steps to arrive.
+      static const bool pair = getenv("LASR_LSTM_PAIR") && atoi(getenv("LASR_LSTM_PAIR")) == 1;
+      LstmJob job; job.a = *lstm_job; job.n_wg = lstm_wgs; job.n_utt = pair ? lstm_wgs : lstm_wgs / 2;
+      if (job.n_wg % 8) return fail(LASR_E_SHAPE, "gemm + BiLSTM grid: the batch must be a multiple of 8 utterances");
+      if (pair) hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 16, true>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
+      else hipLaunchKernelGGL((gemm_bf16_big_multi_lstm_kernel<false, 16, false>), dim3((unsigned)(total + job.n_wg)), dim3(big::NT), 0, st, m, job);
       LASR_LAUNCH_CHECK("gemm_bf16_big_multi_lstm_kernel");
       return 0;
     }

@@ -121,10 +121,11 @@ __global__ __launch_bounds__(kLstmThreads) void bilstm_bwd_kernel(lstm::BwdArgs 
 // the stored gate gradients and the forward pass's saved states - off the recurrence's chain since round 4.  Workgroup = one
 // (utterance, direction, quarter of the time axis), four 192-thread slots that each walk a sixteenth of the steps: thread j keeps row
 // j of dW_hh in 40 registers, the step's hidden vector arrives through wave-uniform addresses.  The slots' sums meet in LDS (two
-// rounds over a [2][G*H] image); pwhh [B * kDwZ][2][G*H] partials go to launch_reduce_partials.
+// rounds over a [2][G*H] image); pwhh [2][B * kDwZ][G*H] partials are summed over the middle index by the caller's reduction.
 static constexpr int kDwSlices = 4, kDwSlot = 192;
 __global__ __launch_bounds__(kDwSlices * kDwSlot) void bilstm_dwhh_kernel(lstm::BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float s_acc[2][G * H];
+  __shared__ float s_db[kDwSlices][G];
   const int b = blockIdx.x, dir = blockIdx.y, z = blockIdx.z;
   const int slice = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kDwSlot);
   const int tid_in = (int)threadIdx.x - slice * kDwSlot;
@@ -142,16 +143,20 @@ __global__ __launch_bounds__(kDwSlices * kDwSlot) void bilstm_dwhh_kernel(lstm::
   float dw[H];
 #pragma unroll
   for (int k = 0; k < H; ++k) dw[k] = 0.f;
+  // the column sum of dg (bias gradient) rides along: every step of the chunk, and the one step without a previous state once
+  float db = (part == 0 && len > 0) ? dg[(int64_t)(dir ? len - 1 : 0) * G] : 0.f;
 #pragma unroll 2
   for (int i = i0; i < i1; ++i) {
     const int t = dir ? i : i + 1, tp = dir ? t + 1 : t - 1;
     const float my = dg[(int64_t)t * G];
     const float* hp = hbase + (int64_t)tp * 2 * (G + 2 * H);
+    db += my;
 #pragma unroll
     for (int k = 0; k < H; ++k) dw[k] = fmaf(my, hp[k], dw[k]);
   }
   // slots 0, 1 lay their rows down, slots 2, 3 add theirs on top, then the two images are summed on the way out
   float* mine = s_acc[slice & 1] + j * H;
+  if (live) s_db[slice][j] = db;
   if (live && slice < 2) {
 #pragma unroll
     for (int k = 0; k < H; k += 4) *reinterpret_cast<float4*>(mine + k) = make_float4(dw[k], dw[k + 1], dw[k + 2], dw[k + 3]);
@@ -166,8 +171,10 @@ __global__ __launch_bounds__(kDwSlices * kDwSlot) void bilstm_dwhh_kernel(lstm::
     }
   }
   __syncthreads();
-  float* out = a.pwhh + (((int64_t)b * lstm::kDwZ + z) * 2 + dir) * (G * H);
+  const int64_t row = ((int64_t)dir * gridDim.x + b) * lstm::kDwZ + z;
+  float* out = a.pwhh + row * (G * H);
   for (int e = threadIdx.x; e < G * H; e += kDwSlices * kDwSlot) out[e] = s_acc[0][e] + s_acc[1][e];
+  if (a.pbias && threadIdx.x < G) a.pbias[row * G + threadIdx.x] = (s_db[0][threadIdx.x] + s_db[1][threadIdx.x]) + (s_db[2][threadIdx.x] + s_db[3][threadIdx.x]);
 }
 
 int lstm::launch_dwhh_partials(const lstm::BwdArgs& a, int64_t B, hipStream_t st) {
@@ -224,13 +231,15 @@ extern "C" int lasr_bilstm_bwd(const void* dout, int dtype, int64_t ld_dout, int
   float* pwhh = reinterpret_cast<float*>(workspace);
   dim3 grid((unsigned)B, 2);
   hipStream_t st = as_stream(stream);
-  const lstm::BwdArgs a = {dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved, dg_f, dg_r, pwhh};
+  const lstm::BwdArgs a = {dout, ld_dout, col0, whh_f, whh_r, lens, T_, saved, dg_f, dg_r, pwhh, nullptr, nullptr, nullptr};
   if (dtype == LASR_F32) hipLaunchKernelGGL(bilstm_bwd_kernel<float>, grid, dim3(kLstmThreads), 0, st, a);
   else hipLaunchKernelGGL(bilstm_bwd_kernel<bf16_t>, grid, dim3(kLstmThreads), 0, st, a);
   LASR_LAUNCH_CHECK("bilstm_bwd_kernel");
   LASR_TRY(lstm::launch_dwhh_partials(a, B, st));
-  // pwhh is [B * kDwZ][2][G*H]: sum over the first index -> B * kDwZ partials of 2*G*H columns, split at G*H
-  return launch_reduce_partials(pwhh, (int)B * lstm::kDwZ, (int64_t)2 * G * H, dwhh_f, (int64_t)G * H, dwhh_r, st);
+  // pwhh is [2][B * kDwZ][G*H]: per direction, B * kDwZ partials of G*H columns
+  const int np = (int)B * lstm::kDwZ;
+  LASR_TRY(launch_reduce_partials(pwhh, np, (int64_t)G * H, dwhh_f, (int64_t)G * H, nullptr, st));
+  return launch_reduce_partials(pwhh + (int64_t)np * G * H, np, (int64_t)G * H, dwhh_r, (int64_t)G * H, nullptr, st);
 }
 
 extern "C" int lasr_copy_cols(const void* src, int src_dtype, int64_t ld_src, int64_t scol0, void* dst, int dst_dtype, int64_t ld_dst,

@@ -24,6 +24,9 @@ struct BwdArgs {
   const void* dout; int64_t ldd, col0;
   const float* whh_f; const float* whh_r; const int32_t* lens; int64_t Tt; const float* saved;
   float* dg_f; float* dg_r; float* pwhh;
+  // optional (null: not written): bf16 copies of dg for the GEMMs behind the recurrence (dW_ih, dx), and per-workgroup column sums of
+  // dg (the bias gradients) next to the dW_hh partials
+  bf16_t* dgb_f; bf16_t* dgb_r; float* pbias;
 };
 struct BwdSmem {
   __attribute__((aligned(16))) float s_dg[2][G];          // the step's gate gradients, double-buffered: ONE barrier per step
@@ -55,6 +58,8 @@ __device__ __forceinline__ void bilstm_bwd_body(const BwdArgs& a, int b, int dir
   const int u = tid >> 2, q = tid & 3, j = q * H + u;
   const float* whh = dir ? a.whh_r : a.whh_f;
   float* dg = (dir ? a.dg_r : a.dg_f) + (int64_t)b * Tt * G;
+  bf16_t* dgb = dir ? a.dgb_r : a.dgb_f;                  // (slot-uniform)
+  if (dgb) dgb += (int64_t)b * Tt * G;
   const float* saved = a.saved;
   int len = a.lens[b];
   if (len > Tt) len = (int)Tt;
@@ -62,6 +67,8 @@ __device__ __forceinline__ void bilstm_bwd_body(const BwdArgs& a, int b, int dir
 #pragma unroll
   for (int qq = 0; qq < H; ++qq) wt[qq] = whh[(q * H + qq) * H + u];
   for (int64_t i = (int64_t)len * G + tid_in; i < Tt * G; i += nthr) dg[i] = 0.f;
+  if (dgb)
+    for (int64_t i = (int64_t)len * G + tid_in; i < Tt * G; i += nthr) dgb[i] = 0;
   // per-step operands, KP steps ahead, kept RAW in the ring (any arithmetic on a loaded value - a select, the bf16 widening - at
   // fetch time makes the step wait for the load it has just issued: s_waitcnt vmcnt(0) on the chain, found in the ISA in round 4):
   // every lane its own gate (ra), lane q of a quad c (q = 0) or c_prev (q = 1) of unit u (rs), and the unit's d(out) (rd)
@@ -94,6 +101,7 @@ __device__ __forceinline__ void bilstm_bwd_body(const BwdArgs& a, int b, int dir
     if (live) {
       sm.s_dg[buf][j] = mine;
       dg[(int64_t)t * G + j] = mine;
+      if (dgb) dgb[(int64_t)t * G + j] = f32_to_bf16(mine);
     }
     barrier();
     const float* sd = sm.s_dg[buf] + q * H;
@@ -145,8 +153,8 @@ __device__ __forceinline__ void bilstm_bwd_body(const BwdArgs& a, int b, int dir
   }
 }
 
-// lstm.hip: dW_hh partials from the stored gate gradients and the saved hidden states - pwhh [B * kDwZ][2][G*H], to be summed over
-// the first index (launch_reduce_partials)
+// lstm.hip: dW_hh partials from the stored gate gradients and the saved hidden states - pwhh [2][B * kDwZ][G*H], to be summed over
+// the middle index (a.pbias, when set: [2][B * kDwZ][G] column sums of dg, the bias gradients' partials)
 int launch_dwhh_partials(const BwdArgs& a, int64_t B, hipStream_t st);
 
 }  // namespace lstm

@@ -6,6 +6,7 @@
 #include "mel.h"
 #include "fused.h"
 #include "gemm.h"
+#include "lstm_body.h"
 #include "se_seqsum.h"
 #include <string>
 #include <vector>
@@ -100,6 +101,7 @@ struct Plan {
   size_t o_lens = 0, o_logits = 0, o_glogits = 0, o_nll = 0, o_scratch = 0, o_g[2] = {0, 0}, o_d1 = 0, o_d2 = 0, o_du = 0, o_dxr = 0;
   size_t o_sums = 0, o_sums2 = 0, o_ctc = 0, o_wbf16 = 0;
   size_t o_cat = 0, o_gx[2] = {0, 0}, o_lstm_saved = 0, o_dg[2] = {0, 0};   // context: [N][336] | [N][160] f32 x2 | saved | [N][160] f32 x2
+  size_t o_dgb[2] = {0, 0}, o_lstm_part = 0, o_lstm_bpart = 0, o_lstm_wgp = 0, lstm_wgp_bytes = 0;   // bf16 mode: dg as bf16 x2 | dW_hh partials | bias partials | dW_ih slabs
   size_t scratch_bytes = 0, ctc_bytes = 0;
   size_t o_rowstat = 0, o_lean = 0, lean_bytes = 0;   // large-vocabulary head: softmax row statistics, lasr_ctc_loss_lean workspace
 };
@@ -281,6 +283,13 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
     scratch = std::max(scratch, lasr_bilstm_bwd_workspace_bytes(B));
     scratch = std::max(scratch, lasr_gemm_workspace_bytes(160, 256, 16, 0));
     scratch = std::max(scratch, lasr_colsum_workspace_bytes(N, 160));
+    if (m->cfg.dtype == LASR_BF16) {   // what the recurrences' launch leaves for the stage's closing launch / reduction (backward_from_glogits)
+      for (int d = 0; d < 2; ++d) p.o_dgb[d] = take(cur, (size_t)N * 160 * sizeof(bf16_t));
+      p.o_lstm_part = take(cur, (size_t)2 * B * lstm::kDwZ * lstm::G * lstm::H * sizeof(float));
+      p.o_lstm_bpart = take(cur, (size_t)2 * B * lstm::kDwZ * lstm::G * sizeof(float));
+      p.lstm_wgp_bytes = lasr_gemm_workspace_bytes(160, 256, wgrad_split(), 0);
+      p.o_lstm_wgp = take(cur, 2 * p.lstm_wgp_bytes);
+    }
   }
   // f32 logits (dense head) or bf16 logits with rows padded to 8 classes (large-vocabulary head) - and, in the SAME bytes, the dense
   // head's d(loss)/d(logits): log_softmax has consumed the logits before the CTC gradient kernel writes, and backward reads only the
@@ -542,9 +551,11 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
     }
     if (u.ctx_before) {
       // context branch: gates' input projection as two GEMMs (f32 out), the recurrence, then cat(x, lstm) -> [N][336]
-      for (int d = 0; d < 2; ++d)
-        LASR_TRY(lasr_gemm(x, wptr(m, params, ws, m->lstm.w_ih[d]), atf(ws, p.o_gx[d]), dt, LASR_F32, N, 160, 256, 0, 0, nullptr, nullptr,
-                           nullptr, 0, nullptr, 1, scratch, p.scratch_bytes, stream));
+      {
+        lasr_gemm_problem pr[2];
+        for (int d = 0; d < 2; ++d) pr[d] = {x, wptr(m, params, ws, m->lstm.w_ih[d]), atf(ws, p.o_gx[d]), N, 160, 256, nullptr, nullptr, 0, nullptr};
+        LASR_TRY(lasr_gemm_batch(pr, 2, dt, LASR_F32, 0, 0, 1, scratch, p.scratch_bytes, stream));   // (one launch)
+      }
       LASR_TRY(lasr_copy_cols(x, dt, 256, 0, at(ws, p.o_cat), dt, 336, 0, N, 256, 0, stream));
       LASR_TRY(lasr_bilstm_fwd(atf(ws, p.o_gx[0]), atf(ws, p.o_gx[1]), params + m->lstm.w_hh[0], params + m->lstm.w_hh[1],
                                params + m->lstm.b_ih[0], params + m->lstm.b_hh[0], params + m->lstm.b_ih[1], params + m->lstm.b_hh[1],
@@ -861,21 +872,48 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       // gemm_bf16_big_multi_lstm_kernel; LASR_LSTM_BESIDE_WGRAD=0: the two launches one after the other).  `scratch` holds the
       // recurrence's dW_hh partials; the GEMM part writes only its slabs.
       int beside = 1;
-      if (!wprobs.empty() && wprobs.size() <= 32) {
-        int splits[32];
-        beside = gemm_multi_split_partials_with_bilstm_bwd(wprobs.data(), (int)wprobs.size(), wgrad_split(), wslabs.data(), splits,
-                                                           at(ws, p.o_g[cur]), dt, 336, 256, params + m->lstm.w_hh[0], params + m->lstm.w_hh[1],
-                                                           lens, B, T, atf(ws, p.o_lstm_saved), atf(ws, p.o_dg[0]), atf(ws, p.o_dg[1]),
-                                                           grads + m->lstm.w_hh[0], grads + m->lstm.w_hh[1], scratch, sb, stream);
+      if (!wprobs.empty() && wprobs.size() <= 32 && dt == LASR_BF16 && defer) {
+        int splits[32], taken = 0;
+        const lstm::BwdArgs rec = {at(ws, p.o_g[cur]), 336, 256, params + m->lstm.w_hh[0], params + m->lstm.w_hh[1], lens, T, atf(ws, p.o_lstm_saved),
+                                   atf(ws, p.o_dg[0]), atf(ws, p.o_dg[1]), atf(ws, p.o_lstm_part),
+                                   reinterpret_cast<bf16_t*>(at(ws, p.o_dgb[0])), reinterpret_cast<bf16_t*>(at(ws, p.o_dgb[1])), atf(ws, p.o_lstm_bpart)};
+        beside = gemm_multi_split_partials_with_bilstm_bwd(wprobs.data(), (int)wprobs.size(), &taken, wgrad_split(), wslabs.data(), splits, rec, dt, B,
+                                                           stream);
         if (beside < 0 || beside > 1) return beside;
-        if (beside == 0) {
-          for (size_t i = 0; i < wprobs.size(); ++i)
+        if (beside == 0) {                                  // the first `taken` problems rode along; the rest wait for the stage's closing launch
+          for (int i = 0; i < taken; ++i)
             pending.push_back({wslabs[i], reinterpret_cast<float*>(wprobs[i].C), wprobs[i].M * wprobs[i].N, splits[i]});
-          wprobs.clear();
-          wslabs.clear();
+          wprobs.erase(wprobs.begin(), wprobs.begin() + taken);
+          wslabs.erase(wslabs.begin(), wslabs.begin() + taken);
         }
       }
-      if (beside == 1)
+      if (beside == 0) {
+        // The recurrences' launch left dg as f32 and bf16, and per-workgroup partial sums of dW_hh and of dg's columns.  Their sums
+        // (dW_hh, and the bias gradients - b_ih and b_hh enter the gates as a sum: one gradient, stored twice) join the stage's closing
+        // reduction; dW_ih = dG^T x23 joins the stage's closing weight-gradient launch; only the data gradient
+        // d(block23 out) = d(cat)[:, :256] + dG_f W_ih_f + dG_r W_ih_r is needed now.   (7 small launches fewer than the separate form)
+        const int np = (int)B * lstm::kDwZ;
+        const int64_t gh = (int64_t)lstm::G * lstm::H;
+        for (int d = 0; d < 2; ++d) {
+          pending.push_back({atf(ws, p.o_lstm_part) + (int64_t)d * np * gh, grads + m->lstm.w_hh[d], gh, np});
+          pending.push_back({atf(ws, p.o_lstm_bpart) + (int64_t)d * np * lstm::G, grads + m->lstm.b_ih[d], lstm::G, np});
+          pending.push_back({atf(ws, p.o_lstm_bpart) + (int64_t)d * np * lstm::G, grads + m->lstm.b_hh[d], lstm::G, np});
+          if (wprobs.size() + 1 > 32) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
+          wprobs.push_back({at(ws, p.o_dgb[d]), x23, grads + m->lstm.w_ih[d], 160, 256, N, nullptr, nullptr, 0, nullptr});
+          wslabs.push_back(atf(ws, p.o_lstm_wgp) + (int64_t)d * (p.lstm_wgp_bytes / sizeof(float)));
+        }
+        if (pending.size() + wprobs.size() > 60) {          // (lasr_reduce_many takes 64 segments)
+          LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
+          LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));
+          pending.clear();
+        }
+        LASR_TRY(lasr_copy_cols(at(ws, p.o_g[cur]), dt, 336, 0, at(ws, p.o_g[cur ^ 1]), dt, 256, 0, N, 256, 0, stream));
+        for (int d = 0; d < 2; ++d)
+          LASR_TRY(lasr_gemm(at(ws, p.o_dgb[d]), wptr(m, params, ws, m->lstm.w_ih[d]), at(ws, p.o_g[cur ^ 1]), dt, dt, N, 256, 160, 0, 1, nullptr,
+                             at(ws, p.o_g[cur ^ 1]), nullptr, 0, nullptr, 1, scratch, sb, stream));
+        cur ^= 1;
+        continue;
+      }
       LASR_TRY(lasr_bilstm_bwd(at(ws, p.o_g[cur]), dt, 336, 256, params + m->lstm.w_hh[0], params + m->lstm.w_hh[1], lens, B, T,
                                atf(ws, p.o_lstm_saved), atf(ws, p.o_dg[0]), atf(ws, p.o_dg[1]), grads + m->lstm.w_hh[0],
                                grads + m->lstm.w_hh[1], scratch, sb, stream));
