@@ -1,6 +1,7 @@
 // Shared helpers for liblasr (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -218,6 +219,17 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
   if (act == LASR_ACT_RELU) return fmaxf(x, 0.f);
   if (act == LASR_ACT_SWISH) return x / (1.f + __expf(-x));
   return x;
+}
+
+// A runtime activation code as a compile-time constant inside f: f(std::integral_constant<int, ACT>).  With `act` a plain kernel
+// argument, act_fwd / act_grad compile to two or three scalar compare-and-branch pairs PER ELEMENT in the BN passes' inner loops
+// (128 branches in the statistics pass's loop body, read off the ISA in round 4) - every element its own basic block, nothing
+// scheduled across them.  One uniform branch per kernel instead.
+template <typename F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
+  if (act == LASR_ACT_RELU) f(std::integral_constant<int, LASR_ACT_RELU>{});
+  else if (act == LASR_ACT_SWISH) f(std::integral_constant<int, LASR_ACT_SWISH>{});
+  else f(std::integral_constant<int, LASR_ACT_NONE>{});
 }
 
 }  // namespace lasr

@@ -585,6 +585,8 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
           if (bn.y2) lr[r][h] = Vec<bf16_t>::raw(bn.y2 + off);
         }
       }
+      with_act(bn.act, [&](auto act_c) {                // (the activation code as a constant: no branches per element)
+      constexpr int act = decltype(act_c)::value;
 #pragma unroll
       for (int r = 0; r < kRounds; ++r) {
 #pragma unroll
@@ -604,13 +606,14 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
             for (int j = 0; j < 8; ++j) o[j] += fmaf(rv[j], ca2[j], cb2[j]);
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = act_fwd(o[j], bn.act);
+          for (int j = 0; j < 8; ++j) o[j] = act_fwd(o[j], act);
           const uint4 pk = Vec<bf16_t>::pack(o);
           if (ok && t >= tA && t < tA + TTS) *reinterpret_cast<uint4*>(bn.out + ub + (size_t)t * C + cc) = pk;
           const uint32_t mk = ok ? 0xffffffffu : 0u;
           v[r][h] = make_uint4(pk.x & mk, pk.y & mk, pk.z & mk, pk.w & mk);
         }
       }
+      });
     }
     // the addend of the data gradient (same [frame][channel] tile as the output) is requested now, behind the tile's own
     // loads, and used in phase 3: its latency rides under the staging and the MFMAs (it was exposed once per half: ~3 us)

@@ -325,7 +325,7 @@ template <typename T, bool HAS2, bool SE, bool DROP>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ coef,
                                                          const T* __restrict__ y2, const float* __restrict__ coef2,
                                                          const float* __restrict__ se, T* __restrict__ out,
-                                                         int rows, int Tt, int C, int act, DropArgs drop) {
+                                                         int rows, int Tt, int C, int act_rt, DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) float s_tab[];
   constexpr int V = Vec<T>::kN;
   const unsigned long long drop_step = DROP ? *drop.step : 0ull;
@@ -338,6 +338,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   const int cv = C / V;
   const int r0 = blockIdx.x * kFwdSlabRows;
   const int n_items = (min(r0 + kFwdSlabRows, rows) - r0) * cv;
+  with_act(act_rt, [&](auto act_c) {
+  constexpr int act = decltype(act_c)::value;
   for (int it0 = threadIdx.x; it0 < n_items; it0 += 512) {
     uint4 rv[2], rw[2];
     uint32_t off[2];
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       if (it0 + 256 * u < n_items) Vec<T>::store(out + off[u], o);
     }
   }
+  });
 }
 
 // pass 1: per-block partial sums -> partials[blk][4][C]  (s1, s2 of branch 1; s1', s2' of branch 2).
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
                                                                   const float* __restrict__ coef, const float* __restrict__ saved,
                                                                   const bf16_t* __restrict__ y2, const float* __restrict__ coef2,
                                                                   const float* __restrict__ saved2, const float* __restrict__ se,
-                                                                  float* __restrict__ partials, int rows, int C, int act, int rpc) {
+                                                                  float* __restrict__ partials, int rows, int C, int act_rt, int rpc) {
   __shared__ float s_red[8][4][kSlCh];
   constexpr int V = 8, RB = 4;
   const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3, lane = tid & 63, wid = tid >> 6;
@@ -658,6 +661,9 @@ __global__ __launch_bounds__(512) void bn_bwd_stats_sliced_kernel(const bf16_t* 
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[k][j] = 0.f;
+  // (act stays a runtime value here: as a constant the loop body is one basic block, the scheduler overlaps the four rows further and
+  //  the 256-register budget spills - measured equal, 12.0 us either way: the pass waits on memory)
+  const int act = act_rt;
   for (int rb = r0 + rl; rb < r1; rb += RB * kSlLanes) {
     uint4 rd[RB], ry[RB], rr[RB];
 #pragma unroll
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(512, WPE) void bn_bwd_apply_sliced_kernel(const bf1
                                                                   float inv_n, const int32_t* __restrict__ row_lens, bf16_t* __restrict__ dy,
                                                                   bf16_t* __restrict__ dy2, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                   float* __restrict__ dgamma2, float* __restrict__ dbeta2, int rows, int Tt,
-                                                                  int C, int act, int rpc) {
+                                                                  int C, int act_rt, int rpc) {
   __shared__ double s_sum[4][kSlCh];
   __shared__ __attribute__((aligned(16))) float s_tab[10][kSlCh];
   constexpr int V = 8;
@@ -781,6 +787,8 @@ __global__ __launch_bounds__(512, WPE) void bn_bwd_apply_sliced_kernel(const bf1
   const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, rows);
   float sev[V], sgv[V];
   if (SE) { lds_vec8(se + (size_t)blockIdx.y * C + c, sev); lds_vec8(seg + (size_t)blockIdx.y * C + c, sgv); }
+  with_act(act_rt, [&](auto act_c) {
+  constexpr int act = decltype(act_c)::value;
   for (int rb = r0 + rl; rb < r1; rb += RB * kSlLanes) {
     uint4 rd[RB], ry[RB], rr2[RB];
     uint32_t off[RB];
@@ -828,6 +836,7 @@ __global__ __launch_bounds__(512, WPE) void bn_bwd_apply_sliced_kernel(const bf1
       }
     }
   }
+  });
 }
 
 // rows per chunk of the sliced pair for this shape (0: take the row-major kernels).  One 512-thread workgroup per CU (the
