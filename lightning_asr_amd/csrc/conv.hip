@@ -525,8 +525,11 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
       const bool cok = c0 + ch < C;
       const int q0 = min(max(j0, 0), k - 1), q1 = min(max(j1, 0), k - 1);
       const float a0 = wc[flip ? k - 1 - q0 : q0], a1 = wc[flip ? k - 1 - q1 : q1];
-      f0[it] = (cok && j0 >= 0 && j0 < k) ? a0 : 0.f;
-      f1[it] = (cok && j1 >= 0 && j1 < k) ? a1 : 0.f;
+      // masked with bit operations, not `cond ? a : 0.f`: the compiler turns a select whose operand is a load into a branch
+      // around the load (and waits for it at the join) - in the 32-channel backward kernel that was 17 memory round trips one
+      // after the other before the first tile load was issued (round 4, read off the ISA)
+      f0[it] = __uint_as_float(__float_as_uint(a0) & ((cok && j0 >= 0 && j0 < k) ? 0xffffffffu : 0u));
+      f1[it] = __uint_as_float(__float_as_uint(a1) & ((cok && j1 >= 0 && j1 < k) ? 0xffffffffu : 0u));
     }
 #pragma unroll
     for (int it = 0; it < kIt; ++it) wsm[tid + 512 * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
@@ -1132,8 +1135,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
       const bool cok = c0 + ch < C;
       const int q0 = min(max(j0, 0), k - 1), q1 = min(max(j1, 0), k - 1);
       const float a0 = wc[k - 1 - q0], a1 = wc[k - 1 - q1];
-      f0[it] = (cok && j0 >= 0 && j0 < k) ? a0 : 0.f;
-      f1[it] = (cok && j1 >= 0 && j1 < k) ? a1 : 0.f;
+      // masked with bit operations, not `cond ? a : 0.f`: the compiler turns a select whose operand is a load into a branch
+      // around the load (and waits for it at the join) - in the 32-channel backward kernel that was 17 memory round trips one
+      // after the other before the first tile load was issued (round 4, read off the ISA)
+      f0[it] = __uint_as_float(__float_as_uint(a0) & ((cok && j0 >= 0 && j0 < k) ? 0xffffffffu : 0u));
+      f1[it] = __uint_as_float(__float_as_uint(a1) & ((cok && j1 >= 0 && j1 < k) ? 0xffffffffu : 0u));
     }
 #pragma unroll
     for (int it = 0; it < kIt; ++it) wsm[tid + NT * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
