@@ -1120,31 +1120,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
   const bf16_t* addend = a.addend;
   typedef __attribute__((address_space(3))) dw_s16x4 lds_s4;
 
-  // the workgroup's taps, reversed (data gradient), as packed bf16 pair tables: W[i] = w'[i - 24], TE[i] = (W[2i], W[2i+1]),
-  // TO[i] = (W[2i+1], W[2i+2]); loads unconditional (clamped index, masked value), all issued before the first conversion
-  {
-    constexpr int kIt = CB * WROW / NT;
-    float f0[kIt], f1[kIt];
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int i = tid + NT * it;
-      const int ch = i / WROW, idx = i - ch * WROW;
-      const int i0 = idx < HALF ? 2 * idx : 2 * (idx - HALF) + 1;
-      const int j0 = i0 - 24, j1 = i0 - 23;
-      const float* wc = a.w + (size_t)min(c0 + ch, C - 1) * k;
-      const bool cok = c0 + ch < C;
-      const int q0 = min(max(j0, 0), k - 1), q1 = min(max(j1, 0), k - 1);
-      const float a0 = wc[k - 1 - q0], a1 = wc[k - 1 - q1];
-      // masked with bit operations, not `cond ? a : 0.f`: the compiler turns a select whose operand is a load into a branch
-      // around the load (and waits for it at the join) - in the 32-channel backward kernel that was 17 memory round trips one
-      // after the other before the first tile load was issued (round 4, read off the ISA)
-      f0[it] = __uint_as_float(__float_as_uint(a0) & ((cok && j0 >= 0 && j0 < k) ? 0xffffffffu : 0u));
-      f1[it] = __uint_as_float(__float_as_uint(a1) & ((cok && j1 >= 0 && j1 < k) ? 0xffffffffu : 0u));
-    }
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) wsm[tid + NT * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
-  }
-
   dw_f32x4 accw[8];
 #pragma unroll
   for (int ch = 0; ch < 8; ++ch) accw[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1182,8 +1157,33 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
     }
   };
 
+  issue_loads(bz);                                       // the first tile's loads travel while the tap tables are built
+  // the workgroup's taps, reversed (data gradient), as packed bf16 pair tables: W[i] = w'[i - 24], TE[i] = (W[2i], W[2i+1]),
+  // TO[i] = (W[2i+1], W[2i+2]); loads unconditional (clamped index, masked value), all issued before the first conversion
+  {
+    constexpr int kIt = CB * WROW / NT;
+    float f0[kIt], f1[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int i = tid + NT * it;
+      const int ch = i / WROW, idx = i - ch * WROW;
+      const int i0 = idx < HALF ? 2 * idx : 2 * (idx - HALF) + 1;
+      const int j0 = i0 - 24, j1 = i0 - 23;
+      const float* wc = a.w + (size_t)min(c0 + ch, C - 1) * k;
+      const bool cok = c0 + ch < C;
+      const int q0 = min(max(j0, 0), k - 1), q1 = min(max(j1, 0), k - 1);
+      const float a0 = wc[k - 1 - q0], a1 = wc[k - 1 - q1];
+      // masked with bit operations, not `cond ? a : 0.f`: the compiler turns a select whose operand is a load into a branch
+      // around the load (and waits for it at the join) - in the 32-channel backward kernel that was 17 memory round trips one
+      // after the other before the first tile load was issued (round 4, read off the ISA)
+      f0[it] = __uint_as_float(__float_as_uint(a0) & ((cok && j0 >= 0 && j0 < k) ? 0xffffffffu : 0u));
+      f1[it] = __uint_as_float(__float_as_uint(a1) & ((cok && j1 >= 0 && j1 < k) ? 0xffffffffu : 0u));
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) wsm[tid + NT * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
+  }
+
   DW_STAMP(0);
-  issue_loads(bz);
   for (int q = bz; q < n_tiles; q += gz) {
     const int tA = q * TT;
     const bool last = q == n_tiles - 1;

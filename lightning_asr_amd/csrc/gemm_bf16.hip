@@ -17,6 +17,22 @@
 
 namespace lasr {
 
+// The lane's bias values for its 2 x 4 accumulator quads (columns nbase + ni*32 + 8*j + e), fetched in ONE batch and masked with bit
+// operations.  Written as `col < N ? bias[col] : 0.f` inside the epilogue loops, every value became a branch around its load with a
+// wait behind it: 32 memory round trips one after the other per tile (and per mi), read off the ISA in round 4.
+__device__ __forceinline__ void load_bias_quads(const float* __restrict__ bias, int nbase, int N, float (&bv)[2][4][4]) {
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = nbase + ni * 32 + 8 * j + e;
+        bv[ni][j][e] = __uint_as_float(__float_as_uint(bias[min(n, N - 1)]) & (n < N ? 0xffffffffu : 0u));
+      }
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -292,6 +308,9 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
     const int ldw = g.split_ws ? g.N : g.ldc;
     const bool vec4 = (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
     const bool plain = g.split_ws != nullptr;                 // slabs: no bias, no mask
+    const bool has_bias = !plain && g.bias != nullptr;      // workgroup-uniform
+    float bv[2][4][4];
+    if (has_bias) load_bias_quads(g.bias, n0 + wn * 64 + 4 * half, g.N, bv);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int lr = wm * 64 + mi * 32 + l31;
@@ -308,7 +327,7 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[e] = acc[mi][ni][4 * j + e];
-              if (!plain) v[e] = (v[e] + ((g.bias && n + e < g.N) ? g.bias[min(n + e, g.N - 1)] : 0.f)) * kf;
+              if (!plain) v[e] = (v[e] + (has_bias ? bv[ni][j][e] : 0.f)) * kf;
             }
             if (vec4 && n + 3 < g.N) {
               *reinterpret_cast<float4*>(wrow + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -342,6 +361,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
     __syncthreads();  // every wave is done reading the operand images
     char* epi = smem + wid * (64 * EPI_LD);
     const bool has_bias = g.bias != nullptr;
+    float bv[2][4][4];
+    if (has_bias) load_bias_quads(g.bias, n0 + wn * 64 + 4 * half, g.N, bv);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const uint32_t km = s_keep[wm * 64 + mi * 32 + l31] != 0.f ? 0xffffffffu : 0u;
@@ -358,9 +379,8 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
             v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
           }
           if (has_bias) {
-            const int n = n0 + wn * 64 + ni * 32 + 8 * j + 4 * half;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (n + e < g.N) ? g.bias[min(n + e, g.N - 1)] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] += bv[ni][j][e];
           }
           uint2 pk;
           pk.x = pack_bf16x2(v[0], v[1]) & km;
@@ -686,6 +706,8 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   {
     char* img = smem + (wm * (32 * MI) + l31) * EPB + (wn * 64 + 4 * half) * 2;
     const bool has_bias = g.bias != nullptr;               // workgroup-uniform
+    float bv[2][4][4];
+    if (has_bias) load_bias_quads(g.bias, nb + 4 * half, g.N, bv);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const uint32_t km = s_keep[wm * (32 * MI) + mi * 32 + l31] != 0.f ? 0xffffffffu : 0u;   // MaskCNN / M edge: the row is stored as zeros
@@ -697,9 +719,8 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * j + e];
           if (has_bias) {
-            const int col = nb + ni * 32 + 8 * j + 4 * half;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (col + e < g.N) ? g.bias[min(col + e, g.N - 1)] : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] += bv[ni][j][e];
           }
           if constexpr (DUAL) {                             // folded eval form: activation in the epilogue
 #pragma unroll
