@@ -591,14 +591,18 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   const int kend = min(kbeg + g.k_per_split, g.K);
   const int nk = (kend - kbeg + TK - 1) / TK;
 
-  if (tid < BTM) {
-    const int m = m0 + tid;
-    bool keep = m < g.M;
-    if (!DUAL && keep && g.row_lens) {   // (folded eval form: the mask is on the first A operand's rows instead)
-      const int b = m / g.rows_per_seq;
-      keep = (m - b * g.rows_per_seq) < g.row_lens[b];
-    }
-    s_keep[tid] = keep ? 1.f : 0.f;
+  // MaskCNN row mask of the epilogue: the utterance's length word is REQUESTED here, in front of the first tile loads, and consumed
+  // behind them (below).  Written in one piece here, the load sat in a divergent branch with a wait at its join: one memory round trip
+  // before the first operand load of every masked launch (round 4, read off the ISA).  Unconditional load from an address that is
+  // valid either way; the folded eval form masks the first A operand's rows instead.
+  const bool row_masked = !DUAL && g.row_lens != nullptr;   // workgroup-uniform
+  int keep_pos, keep_len;
+  {
+    const int m = min(m0 + (tid & (BTM - 1)), g.M - 1);
+    const int b = m / g.rows_per_seq;
+    keep_pos = m - b * g.rows_per_seq;
+    const int32_t* lp = row_masked ? g.row_lens + b : reinterpret_cast<const int32_t*>(g.B);
+    keep_len = *lp;
   }
 
   f32x16 acc[MI][2];
@@ -628,6 +632,7 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   load_vec<TRANS_B, BTN, NT, CF::NCB, NTL>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
   store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
   store_vec<TRANS_B, BTN, NT, LD_KC, CF::LDRB, CF::NCB>(smem + OPER, rb, kbeg, kend);
+  if (tid < BTM) s_keep[tid] = (m0 + tid < g.M && (!row_masked || keep_pos < keep_len)) ? 1.f : 0.f;   // (the length word arrived before the tile did)
   if (nk > 1) {
     if constexpr (DUAL) {
 #pragma unroll
