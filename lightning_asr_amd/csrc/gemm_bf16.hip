@@ -754,11 +754,16 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   float cs[8], cq[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cs[i] = 0.f; cq[i] = 0.f; }
+  // all of the lane's row chunks are read back first: the loop below has uniform branches (statistics or not, row statistics or not),
+  // i.e. basic blocks, and with the read inside it every row paid its own LDS round trip before its store was issued
+  uint4 vv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) vv[it] = *reinterpret_cast<const uint4*>(smem + (wid * 32 + it * RPI + lrow) * EPB + lc * 16);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int lr = wid * 32 + it * RPI + lrow;   // (orders that put a block's waves on adjacent rows at the same time measured 1.8x slower)
     const int m = m0 + lr;
-    const uint4 v = *reinterpret_cast<const uint4*>(smem + lr * EPB + lc * 16);
+    const uint4 v = vv[it];
     if (want_rowstat) {
       // this row's 8 stored values per lane -> (max, first argmax, sum exp(x - max)) over the tile's valid columns: the LPR lanes
       // of a row are contiguous, so xor-shuffles below LPR stay inside the row
