@@ -250,9 +250,32 @@ class FusedLoop:
             self.acc.zero_()
         return out
 
+    def _reserve_workspace(self) -> None:
+        """Size the model workspace ONCE, for the longest clip and transcript of the training set.  The workspace only ever grows,
+        but with ragged batches (length buckets, random crops) it grew in as many steps as the batch order happened to offer longer
+        clips - each a multi-GB allocation with the GPU idle behind it: the same cfg5 run took 3.2 or 4.2 ms per step depending on
+        that order (round 4; the kernels' time was 3.0 ms either way)."""
+        if getattr(self, "_ws_reserved", False):
+            return
+        self._ws_reserved = True
+        items = getattr(getattr(self.dm, "train_datasets", None), "datasets", None)
+        if not items:
+            return
+        try:
+            max_dur = max(float(d["duration"]) for d in items)
+            s_max = max(len(d["text"]) for d in items)
+        except (KeyError, TypeError, ValueError):
+            return
+        cap = getattr(self.dm, "train_max_duration", None)
+        if cap:
+            max_dur = min(max_dur, float(cap))
+        t_in = ops.mel_num_frames(int(max_dur * 16000 + 0.5) + 1)
+        self.native.workspace(int(getattr(self.dm, "train_bs", 32)), t_in, max(s_max, 1))
+
     # ---- one epoch -----------------------------------------------------------------------------------------------------
     def run_epoch(self, loader, n_batches: int, on_step=None) -> None:
         tr, dm = self.trainer, self.dm
+        self._reserve_workspace()
         src = make_source(dm, loader, self.native.device, True, n_batches, getattr(dm, "train_max_duration", 16.7) or 16.7,
                           getattr(dm, "train_bs", 32), crop=getattr(dm, "train_crop", True))
         self.source_kind = type(src).__name__
