@@ -531,6 +531,8 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
       f0[it] = __uint_as_float(__float_as_uint(a0) & ((cok && j0 >= 0 && j0 < k) ? 0xffffffffu : 0u));
       f1[it] = __uint_as_float(__float_as_uint(a1) & ((cok && j1 >= 0 && j1 < k) ? 0xffffffffu : 0u));
     }
+    __builtin_amdgcn_sched_barrier(0);                // every load above leaves before the first conversion below waits for one (left to
+                                                      // itself the scheduler interleaves them: five batches, five round trips)
 #pragma unroll
     for (int it = 0; it < kIt; ++it) wsm[tid + 512 * it] = (uint32_t)f32_to_bf16(f0[it]) | ((uint32_t)f32_to_bf16(f1[it]) << 16);
   }
