@@ -8,6 +8,24 @@
 
 namespace lasr {
 
+// ---- the step's precomputed depthwise tap tables (fused.h) ---------------------------------------------------------------------
+static thread_local const DwTapCtx* g_dw_tap_ctx = nullptr;
+void dw_taps_set_ctx(const DwTapCtx* ctx) { g_dw_tap_ctx = ctx; }
+bool dw_taps_enabled() {
+  static const bool on = !(getenv("LASR_DW_TAPS") && atoi(getenv("LASR_DW_TAPS")) == 0);
+  return on;
+}
+// the layer's table ([2][C][kDwTapRow]) when the model call in progress on this thread registered one for `w`; the kernels copy whole
+// 64-channel row blocks, so the layer's width must be a multiple of 64
+const uint32_t* dw_taps_for(const float* w, int flip, int64_t C) {
+  (void)flip;
+  const DwTapCtx* c = g_dw_tap_ctx;
+  if (!c || C % 64 != 0) return nullptr;
+  for (int i = 0; i < c->n; ++i)
+    if (c->w[i] == w && c->C[i] == (int)C) return c->t[i];
+  return nullptr;
+}
+
 static constexpr int kCB = 64;    // channels per workgroup (16 lanes x 4 channels)
 static constexpr int kTT = 128;   // output frames per workgroup (16 lanes x 8 outputs)
 static constexpr int kR = 8;      // outputs per thread
@@ -502,7 +520,7 @@ template <int NKS, int NSET, bool FUSE = false>
 __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                     const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
                                                     int Tlen, int C, int k, int flip, int bx, int by, int bz, int gz,
-                                                    char* smem_raw, const DwBnIn bn = DwBnIn{}) {
+                                                    char* smem_raw, const uint32_t* __restrict__ taps, const DwBnIn bn = DwBnIn{}) {
   using namespace dwm;
   char* img = smem_raw;                               // [64 channels][LDI]: frame tau at byte 2*tau
   char* stage = smem_raw + IMG_BYTES;                 // [RS frames][LDST]
@@ -512,7 +530,15 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
   // the block's taps -> LDS once, as packed bf16 pair tables (reversed for the data gradient); a Toeplitz
   // fragment W[s .. s+7] is 4 consecutive dwords of TE (s even) or TO (s odd): no per-channel work in phase 2.
   // Loads are unconditional (clamped index, masked value) and all issued before the first conversion.
-  {   // (kept in front of the tile's loads: issued behind them it cost 4 us more)
+  if (taps) {   // workgroup-uniform: the step's precomputed tables (fused.h) - the workgroup's 64 rows are one contiguous 40 KB block
+    static_assert(WROW == kDwTapRow, "tap table row");
+    const uint4* src = reinterpret_cast<const uint4*>(taps + ((size_t)flip * C + c0) * WROW);
+    uint4 tv[kCB * WROW / 4 / 512];
+#pragma unroll
+    for (int it = 0; it < kCB * WROW / 4 / 512; ++it) tv[it] = src[tid + 512 * it];
+#pragma unroll
+    for (int it = 0; it < kCB * WROW / 4 / 512; ++it) reinterpret_cast<uint4*>(wsm)[tid + 512 * it] = tv[it];
+  } else {   // (kept in front of the tile's loads: issued behind them it cost 4 us more)
     constexpr int kIt = kCB * WROW / 512;             // 20
     float f0[kIt], f1[kIt];
 #pragma unroll
@@ -758,17 +784,17 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
 template <int NKS, int NSET>
 __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                 const bf16_t* __restrict__ addend, bf16_t* __restrict__ y,
-                                                                int Tlen, int C, int k, int flip) {
+                                                                int Tlen, int C, int k, int flip, const uint32_t* __restrict__ taps) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  dwconv_s1_mfma_body<NKS, NSET>(x, w, addend, y, Tlen, C, k, flip, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw);
+  dwconv_s1_mfma_body<NKS, NSET>(x, w, addend, y, Tlen, C, k, flip, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw, taps);
 }
 
 // forward with the BN + add + activation of the unit below made in the staging loop (DwBnIn)
 template <int NKS, int NSET>
 __global__ __launch_bounds__(512, 1) void dwconv_s1_mfma_bn_kernel(DwBnIn bn, const float* __restrict__ w, bf16_t* __restrict__ y, int Tlen,
-                                                                   int C, int k) {
+                                                                   int C, int k, const uint32_t* __restrict__ taps) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  dwconv_s1_mfma_body<NKS, NSET, true>(nullptr, w, nullptr, y, Tlen, C, k, 0, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw, bn);
+  dwconv_s1_mfma_body<NKS, NSET, true>(nullptr, w, nullptr, y, Tlen, C, k, 0, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z, smem_raw, taps, bn);
 }
 
 // Weight gradient, stride 1.  Lane = 4 channels x 8 consecutive taps (group jg) x one time split;
@@ -1055,7 +1081,7 @@ __global__ __launch_bounds__(512, 1) void dwconv_bwd_s1_mfma_kernel(DwBwd a) {
   } else {
     id -= a.n_w;
     const int bx = id % a.gx, by = (id / a.gx) % a.B, bz = id / (a.gx * a.B);
-    dwconv_s1_mfma_body<NKS, NSET>(a.dy, a.w, a.addend, a.dx, a.Tlen, a.C, a.k, 1, bx, by, bz, a.gz_d, smem_raw);
+    dwconv_s1_mfma_body<NKS, NSET>(a.dy, a.w, a.addend, a.dx, a.Tlen, a.C, a.k, 1, bx, by, bz, a.gz_d, smem_raw, nullptr);
   }
 }
 
@@ -1091,6 +1117,7 @@ struct Cfg {
 struct DwUni {
   const bf16_t* x; const bf16_t* dy; const float* w; const bf16_t* addend; bf16_t* dx; float* partials;
   int Tlen, C, k, gx, B, gz, total;
+  const uint32_t* taps;   // the step's precomputed reversed-tap table of the layer ([C][kDwTapRow], fused.h) or null
 };
 
 template <int NKS, int NW, bool NTL = false>
@@ -1162,7 +1189,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
   issue_loads(bz);                                       // the first tile's loads travel while the tap tables are built
   // the workgroup's taps, reversed (data gradient), as packed bf16 pair tables: W[i] = w'[i - 24], TE[i] = (W[2i], W[2i+1]),
   // TO[i] = (W[2i+1], W[2i+2]); loads unconditional (clamped index, masked value), all issued before the first conversion
-  {
+  if (a.taps) {   // workgroup-uniform: rows of the step's precomputed table (TE | TO of 80 each there, HALF each here)
+    constexpr int kV = CB * WROW / 4 / NT;               // 16-byte groups per thread
+    static_assert(CB * WROW / 4 % NT == 0 && HALF % 4 == 0 && HALF <= kDwTapRow / 2, "tap table copy");
+    uint4 tv[kV];
+#pragma unroll
+    for (int it = 0; it < kV; ++it) {
+      const int i4 = tid + NT * it;
+      const int ch = i4 / (WROW / 4), idx = (i4 - ch * (WROW / 4)) * 4;
+      tv[it] = *reinterpret_cast<const uint4*>(a.taps + (size_t)(c0 + ch) * kDwTapRow + (idx < HALF ? idx : kDwTapRow / 2 + idx - HALF));
+    }
+#pragma unroll
+    for (int it = 0; it < kV; ++it) reinterpret_cast<uint4*>(wsm)[tid + NT * it] = tv[it];
+  } else {
     constexpr int kIt = CB * WROW / NT;
     float f0[kIt], f1[kIt];
 #pragma unroll
@@ -1377,11 +1416,12 @@ extern "C" int lasr_dwconv_fwd(const void* x, const float* w, const void* addend
         static const bool no_half = getenv("LASR_DWCONV_NO_HALF") != nullptr;
         const bool half = !no_half && Tin > 256 && cdiv(C, kCB) * B * cdiv(Tin, (int64_t)512) < 200;
         const dim3 gridm((unsigned)cdiv(C, kCB), (unsigned)B, half ? (unsigned)std::min<int64_t>(cdiv(Tin, (int64_t)256), 8) : 1u);
+        const uint32_t* taps = dw_taps_for(w, flip, C);   // the step's precomputed tap tables, when the model call in progress made them
 #define LASR_DWM2(N_, S_)                                                                                                    \
   do {                                                                                                                       \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_mfma_kernel<N_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((dwconv_s1_mfma_kernel<N_, S_>), gridm, dim3(512), dwm::SMEM, as_stream(stream), (const bf16_t*)x, w,  \
-                       (const bf16_t*)addend, (bf16_t*)y, (int)Tin, (int)C, k, flip);                                        \
+                       (const bf16_t*)addend, (bf16_t*)y, (int)Tin, (int)C, k, flip, taps);                                  \
   } while (0)
 #define LASR_DWM(N_) do { if (half) LASR_DWM2(N_, 1); else LASR_DWM2(N_, 2); } while (0)
         if (nks == 1) LASR_DWM(1); else if (nks == 2) LASR_DWM(2); else if (nks == 3) LASR_DWM(3); else LASR_DWM(4);
@@ -1437,10 +1477,11 @@ int lasr::dwconv_fwd_bn(const void* y, const float* coef, const void* y2, const 
   DwBnIn bn;
   bn.y = (const bf16_t*)y; bn.y2 = (const bf16_t*)y2; bn.coef = coef; bn.coef2 = coef2; bn.out = (bf16_t*)out; bn.act = act;
   const int tok = prof_begin(LASR_PROF_DWCONV, as_stream(stream), 2.0 * (double)B * T * C * k, (double)B * T * C * (y2 ? 4 : 3) * 2);
+  const uint32_t* taps = dw_taps_for(w, 0, C);
 #define LASR_DWMB2(N_, S_)                                                                                                  \
   do {                                                                                                                      \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_s1_mfma_bn_kernel<N_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((dwconv_s1_mfma_bn_kernel<N_, S_>), gridm, dim3(512), dwm::SMEM, as_stream(stream), bn, w, (bf16_t*)u, (int)T, (int)C, k); \
+    hipLaunchKernelGGL((dwconv_s1_mfma_bn_kernel<N_, S_>), gridm, dim3(512), dwm::SMEM, as_stream(stream), bn, w, (bf16_t*)u, (int)T, (int)C, k, taps); \
   } while (0)
 #define LASR_DWMB(N_) do { if (half) LASR_DWMB2(N_, 1); else LASR_DWMB2(N_, 2); } while (0)
   if (nks == 1) LASR_DWMB(1); else if (nks == 2) LASR_DWMB(2); else if (nks == 3) LASR_DWMB(3); else LASR_DWMB(4);
@@ -1569,6 +1610,10 @@ extern "C" int lasr_dwconv_bwd_fused(const void* x, const void* dy, const float*
       u.x = (const bf16_t*)x; u.dy = (const bf16_t*)dy; u.w = w; u.addend = (const bf16_t*)addend; u.dx = (bf16_t*)dx;
       u.partials = reinterpret_cast<float*>(workspace);
       u.Tlen = (int)T; u.C = (int)C; u.k = k; u.B = (int)B;
+      {
+        const uint32_t* tp = dw_taps_for(w, 1, C);        // reversed taps: the second half of the layer's table
+        u.taps = tp ? tp + (size_t)C * kDwTapRow : nullptr;
+      }
       const int cb = u32 ? 32 : 64;
       u.gx = (int)cdiv(C, cb);
       const int n_tiles = (int)cdiv(T, (int64_t)dwu::TT);

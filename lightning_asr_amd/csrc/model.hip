@@ -90,6 +90,7 @@ struct Unit {
   size_t o_se_sum = 0, o_se_pool = 0, o_se_hid = 0, o_se_scale = 0, o_se_grad = 0;   // SE: [B][co] (hid: [B][co/8]) f32
   size_t o_wfold = 0, o_bfold = 0;   // eval: folded [a W | a2 Wr] bf16 and b + b2 (residual units)
   size_t o_wgp = 0, wgp_bytes = 0, o_dwp = 0, dwp_bytes = 0, o_dy = 0, o_dy2 = 0;   // deferred reductions: split-K slabs of dW / dWr, depthwise-dW partials
+  size_t o_taps = 0;     // bf16, stride-1 depthwise layers of 64 k channels: the step's tap tables [2][ci][kDwTapRow] (fused.h); 0 = none
 };
 
 // BiLSTM context branch (Context / ContextSE): parameter offsets per direction
@@ -128,6 +129,7 @@ struct lasr_model {
   bool lean_active = false;   // the last loss ran the large-vocabulary head: d(logits) is the bf16 [N][ldc] tensor at o_d1, db is done
   int lean_tiles = 0;
   int bwd_cur = 0;       // ping-pong index of the gradient buffers between partial backward calls
+  bool taps_valid = false;   // the workspace holds this step's depthwise tap tables (made by the last training forward)
   int bwd_next = -1;     // next unit a lasr_model_backward_continue call would process (-1: nothing pending)
   // one-shot feature prefetch consumed by the next loss_backward call (lasr_model_set_prefetch)
   struct Prefetch {
@@ -314,6 +316,9 @@ static void make_plan(lasr_model* m, int64_t B, int64_t T_in, int64_t S_max) {
     if (u.has_dw) {
       u.dwp_bytes = lasr_dwconv_wgrad_workspace_bytes(B, p.T, u.ci, u.k);
       u.o_dwp = take(cur, u.dwp_bytes);
+      u.o_taps = 0;
+      if (m->cfg.dtype == LASR_BF16 && u.stride == 1 && u.ci % 64 == 0 && dw_taps_enabled())
+        u.o_taps = take(cur, (size_t)2 * u.ci * kDwTapRow * sizeof(uint32_t));
     }
   }
   p.scratch_bytes = scratch;
@@ -468,6 +473,26 @@ static inline const void* wptr(const lasr_model* m, const float* params, void* w
   return params + off;
 }
 
+// The step's depthwise tap tables (fused.h): made by the training forward's first launch, looked up by the depthwise host
+// functions while a model call is in progress on this thread.
+struct DwTapScope {
+  DwTapCtx ctx;
+  bool on = false;
+  DwTapScope(const lasr_model* m, const float* params, void* ws, bool valid) {
+    ctx.n = 0;
+    if (!valid) return;
+    for (const Unit& u : m->units)
+      if (u.o_taps && ctx.n < 16) {
+        ctx.w[ctx.n] = params + u.w_dw; ctx.t[ctx.n] = reinterpret_cast<const uint32_t*>(at(ws, u.o_taps)); ctx.C[ctx.n] = u.ci;
+        ++ctx.n;
+      }
+    if (ctx.n) { dw_taps_set_ctx(&ctx); on = true; }
+  }
+  ~DwTapScope() { if (on) dw_taps_set_ctx(nullptr); }
+  DwTapScope(const DwTapScope&) = delete;
+  DwTapScope& operator=(const DwTapScope&) = delete;
+};
+
 // eval-mode folding (LASR_NO_EVAL_FOLD=1: the unfolded eval path, for A/B runs and the parity test)
 static bool eval_fold(int dtype) {
   static const bool off = getenv("LASR_NO_EVAL_FOLD") != nullptr;
@@ -501,15 +526,28 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
   {
     ProfScope ps(LASR_PROF_OTHER, stream, dt == LASR_BF16 ? 6.0 * m->n_param : 0.0);
     int merged = 1;      // bf16: the lengths and the weights' bf16 shadow in one launch (two independent launch-floor kernels)
+    m->taps_valid = false;
     if (dt == LASR_BF16) {
-      merged = mask_lengths_step_cast(pct, B, T, lens, dropping ? m->drop_step : nullptr, params, at(ws, p.o_wbf16), m->n_param, stream);
+      DwTapJobs jobs;                                       // training: the depthwise tap tables ride in the same launch
+      jobs.n = 0; jobs.blk0[0] = 0;
+      if (training)
+        for (const Unit& u : m->units)
+          if (u.o_taps && jobs.n < 16) {
+            jobs.w[jobs.n] = params + u.w_dw; jobs.out[jobs.n] = reinterpret_cast<uint32_t*>(at(ws, u.o_taps)); jobs.C[jobs.n] = u.ci; jobs.k[jobs.n] = u.k;
+            jobs.blk0[jobs.n + 1] = jobs.blk0[jobs.n] + (int)cdiv((int64_t)2 * u.ci * kDwTapRow, 256);
+            ++jobs.n;
+          }
+      merged = mask_lengths_step_cast(pct, B, T, lens, dropping ? m->drop_step : nullptr, params, at(ws, p.o_wbf16), m->n_param,
+                                      jobs.n ? &jobs : nullptr, stream);
       if (merged < 0 || merged > 1) return merged;
+      m->taps_valid = merged == 0 && jobs.n > 0;
     }
     if (merged == 1) {
       LASR_TRY(lasr_mask_lengths_step(pct, B, T, lens, dropping ? m->drop_step : nullptr, stream));   // (bumps the masks' step counter)
       if (dt == LASR_BF16) LASR_TRY(lasr_cast_f32_to_bf16(params, at(ws, p.o_wbf16), m->n_param, stream));
     }
   }
+  DwTapScope tap_scope(m, params, ws, m->taps_valid);
   void* scratch = at(ws, p.o_scratch);
   if (!training) {   // eval: BN coefficients of all layers from the running statistics, one launch
     std::vector<lasr_bn_eval_desc> descs;
@@ -710,6 +748,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   const Plan& p = m->plan;
   const int dt = m->cfg.dtype;
   const int64_t T = p.T, N = B * T, C = m->cfg.n_class;
+  DwTapScope tap_scope(m, params, ws, m->taps_valid);     // (the tables of this step's forward: the parameters have not moved since)
   void* scratch = at(ws, p.o_scratch);
   const size_t sb = p.scratch_bytes;
   const int32_t* lens = reinterpret_cast<const int32_t*>(at(ws, p.o_lens));

@@ -7,6 +7,7 @@
 #include "fused.h"
 #include "dropout.h"
 #include <algorithm>
+#include <string.h>
 
 namespace lasr {
 
@@ -47,16 +48,25 @@ __global__ void mask_lengths_kernel(const float* __restrict__ pct, int64_t B, fl
 
 // The two launches every training forward starts with - lens = int(T' * pct) (models/QuartNet.py:311) and the bf16 shadow of the
 // weights - are independent of each other: one grid (round 4; the last workgroup does the lengths).
+// grid: [cast_blocks of the weight shadow | the depthwise tap tables' blocks (fused.h), one 256-entry block each | the lengths]
 __global__ __launch_bounds__(256) void mask_lengths_cast_kernel(const float* __restrict__ pct, int64_t B, float Tf, int32_t* __restrict__ lens,
                                                                 unsigned long long* __restrict__ step_counter, const float* __restrict__ in,
-                                                                bf16_t* __restrict__ out, int64_t n) {
+                                                                bf16_t* __restrict__ out, int64_t n, int cast_blocks, DwTapJobs jobs) {
   if (blockIdx.x == gridDim.x - 1) {                     // workgroup-uniform
     for (int64_t i = threadIdx.x; i < B; i += 256) lens[i] = (int32_t)(Tf * pct[i]);
     if (threadIdx.x == 0 && step_counter) *step_counter += 1ull;
     return;
   }
+  if ((int)blockIdx.x >= cast_blocks) {                  // workgroup-uniform: one block of one layer's tap tables
+    const int tb = (int)blockIdx.x - cast_blocks;
+    int l = 0;
+    while (l + 1 < jobs.n && jobs.blk0[l + 1] <= tb) ++l;
+    const int e = (tb - jobs.blk0[l]) * 256 + (int)threadIdx.x;
+    if (e < 2 * jobs.C[l] * kDwTapRow) jobs.out[l][e] = dw_tap_entry(jobs.w[l], jobs.C[l], jobs.k[l], e);
+    return;
+  }
   const int64_t n4 = n >> 2;                             // 16-byte loads, 8-byte stores (the buffers are 256-byte aligned)
-  const int64_t stride = (int64_t)(gridDim.x - 1) * 256;
+  const int64_t stride = (int64_t)cast_blocks * 256;
   for (int64_t e = blockIdx.x * (int64_t)256 + threadIdx.x; e < n4; e += stride) {
     const float4 v = reinterpret_cast<const float4*>(in)[e];
     uint2 o;
@@ -915,14 +925,21 @@ extern "C" int lasr_mask_lengths_step(const float* pct, int64_t B, int64_t T_, i
   return 0;
 }
 int lasr::mask_lengths_step_cast(const float* pct, int64_t B, int64_t T_, int32_t* lens, uint64_t* step_counter, const float* in, void* out,
-                                 int64_t n, void* stream) {
+                                 int64_t n, const DwTapJobs* jobs, void* stream) {
   LASR_CHECK_ARG(pct && lens && B > 0 && T_ > 0 && in && out && n > 0, "mask_lengths_step_cast: bad argument");
   if (reinterpret_cast<uintptr_t>(in) % 16 || reinterpret_cast<uintptr_t>(out) % 8) return 1;
   int64_t blocks = cdiv(n >> 2, 256);
   if (blocks > 256 * 8) blocks = 256 * 8;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mask_lengths_cast_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, as_stream(stream), pct, B, (float)T_, lens,
-                     reinterpret_cast<unsigned long long*>(step_counter), in, reinterpret_cast<bf16_t*>(out), n);
+  DwTapJobs j;
+  memset(&j, 0, sizeof(j));
+  int tap_blocks = 0;
+  if (jobs) {
+    j = *jobs;
+    tap_blocks = j.blk0[j.n];
+  }
+  hipLaunchKernelGGL(mask_lengths_cast_kernel, dim3((unsigned)(blocks + tap_blocks + 1)), dim3(256), 0, as_stream(stream), pct, B, (float)T_, lens,
+                     reinterpret_cast<unsigned long long*>(step_counter), in, reinterpret_cast<bf16_t*>(out), n, (int)blocks, j);
   LASR_LAUNCH_CHECK("mask_lengths_cast_kernel");
   return 0;
 }

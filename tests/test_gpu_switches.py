@@ -81,6 +81,10 @@ def test_bn_inside_the_depthwise_forward_is_bit_identical(dev):
     sep = _run({"LASR_HEAD_TAIL_MERGED": "0"})
     sep.pop("prof_brackets"); base.pop("prof_brackets")
     assert sep == base, (sep, base)
+    # the depthwise kernels' tap tables copied from the step's precomputed tables or built by every workgroup: the same bf16 pairs
+    own = _run({"LASR_DW_TAPS": "0"})
+    own.pop("prof_brackets")
+    assert own == base, (own, base)
     # the decoder's split-K slabs summed inside the log_softmax launch or by the GEMM's own reduction: the same sums in the same order
     sep = _run({"LASR_LOGSOFTMAX_SPLIT": "0"})
     sep.pop("prof_brackets")
