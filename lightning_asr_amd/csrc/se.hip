@@ -158,13 +158,31 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__
   float* s_w2 = sm;
   float* s_hid = sm + kSeCh * (H + 1);
   const int c0 = blockIdx.x * kSeCh, b0 = blockIdx.y * kSeUtt;
-  for (int i = threadIdx.x; i < kSeCh * H; i += 256) {
-    const int cl = i / H, h = i - cl * H;
-    s_w2[cl * (H + 1) + h] = c0 + cl < C ? W2[(size_t)c0 * H + i] : 0.f;
+  // (clamped addresses, values masked by bit operations, eight loads in flight: as `row < C ? W2[i] : 0.f` every element was a
+  //  branch around its load with a wait behind it - eight memory round trips in a row in a 5.7 us kernel; round 4)
+  const size_t w2_last = (size_t)C * H - 1, hid_last = (size_t)B * H - 1;
+  for (int base = 0; base < kSeCh * H; base += 8 * 256) {          // all of a round's loads first, then its LDS writes
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = W2[min((size_t)c0 * H + base + u * 256 + threadIdx.x, w2_last)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + (int)threadIdx.x;
+      if (i < kSeCh * H) {
+        const int cl = i / H, h = i - cl * H;
+        s_w2[cl * (H + 1) + h] = __uint_as_float(__float_as_uint(wv[u]) & (c0 + cl < C ? 0xffffffffu : 0u));
+      }
+    }
   }
-  for (int i = threadIdx.x; i < kSeUtt * H; i += 256) {
-    const int bl = i / H;
-    s_hid[i] = b0 + bl < B ? hidden[(size_t)b0 * H + i] : 0.f;
+  for (int base = 0; base < kSeUtt * H; base += 2 * 256) {
+    float hv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) hv[u] = hidden[min((size_t)b0 * H + base + u * 256 + threadIdx.x, hid_last)];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = base + u * 256 + (int)threadIdx.x;
+      if (i < kSeUtt * H) s_hid[i] = __uint_as_float(__float_as_uint(hv[u]) & (b0 + i / H < B ? 0xffffffffu : 0u));
+    }
   }
   __syncthreads();
   const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
@@ -200,11 +218,20 @@ __global__ __launch_bounds__(256) void se_bwd_hidden_kernel(const float* __restr
   float* s_hid = s_d2 + kSeUtt * kSeC1;
   float* s_w2 = s_hid + kSeUtt * H;
   const int c0 = blockIdx.x * kSeC1, b0 = blockIdx.y * kSeUtt;
-  for (int i = threadIdx.x; i < kSeUtt * H; i += 256) s_hid[i] = b0 + i / H < B ? hidden[(size_t)b0 * H + i] : 0.f;
+  {
+    const size_t hid_last = (size_t)B * H - 1;             // (clamped address + bit mask: no branch around the load)
+#pragma unroll 2
+    for (int i = threadIdx.x; i < kSeUtt * H; i += 256)
+      s_hid[i] = __uint_as_float(__float_as_uint(hidden[min((size_t)b0 * H + i, hid_last)]) & (b0 + i / H < B ? 0xffffffffu : 0u));
+  }
+#pragma unroll 8
   for (int i = threadIdx.x; i < kSeC1 * H; i += 256) s_w2[i] = W2[(size_t)c0 * H + i];      // C % 32 == 0: whole chunks only
   {
     const int bl = threadIdx.x >> 5, b = min(b0 + bl, B - 1), c = c0 + (threadIdx.x & 31);
     float dsv;
+    // (the three per-channel / per-utterance operands of the tail are requested with the slabs' loads, not one after the other behind them)
+    const float gm = partials ? gamma[c] : 0.f, bt = partials ? beta[c] : 0.f;
+    const float s = scale[(size_t)b * C + c];
     if (partials) {
       double a[4] = {0.0, 0.0, 0.0, 0.0};
       const float* p = partials + (size_t)b * nslab * 4 * C + c;
@@ -217,11 +244,10 @@ __global__ __launch_bounds__(256) void se_bwd_hidden_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) P[((size_t)b * 4 + k) * C + c] = (float)a[k];
       }
-      dsv = (float)((double)gamma[c] * a[1] + (double)beta[c] * a[0]);
+      dsv = (float)((double)gm * a[1] + (double)bt * a[0]);
     } else {
       dsv = ds[(size_t)b * C + c];
     }
-    const float s = scale[(size_t)b * C + c];
     s_d2[threadIdx.x] = b0 + bl < B ? dsv * s * (1.f - s) : 0.f;      // utterances past the batch contribute nothing
   }
   __syncthreads();
@@ -261,19 +287,101 @@ __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restric
   float* s_seg = s_pool + (size_t)B * kSeC2;
   const int c0 = blockIdx.x * kSeC2;
   const float inv_T = 1.f / (float)Tt;
-  for (int i = threadIdx.x; i < B * H; i += 512) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < nchunk; ++k) acc += dh_part[(size_t)k * B * H + i];
-    s_dh[i] = hidden[i] > 0.f ? acc : 0.f;
+  // The first round of every array this phase stages (W1's 16 columns, the pooled values, the groups' dW2 shares) is requested
+  // before anything is waited for - with the d(hidden) shares below, ONE memory round trip for the usual shapes (C <= 512, B <= 32)
+  // where each staging loop used to be its own.
+  const int n_w1 = H * kSeC2, n_pl = B * kSeC2;
+  float r_w1[2], r_pl, r_g[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = min(u * 512 + (int)threadIdx.x, n_w1 - 1);
+    r_w1[u] = W1[(size_t)(i >> 4) * C + c0 + (i & 15)];
   }
-  for (int i = threadIdx.x; i < H * kSeC2; i += 512) s_w1[i] = W1[(size_t)(i >> 4) * C + c0 + (i & 15)];
-  for (int i = threadIdx.x; i < B * kSeC2; i += 512) s_pool[i] = pooled[(size_t)(i >> 4) * C + c0 + (i & 15)];
+  {
+    const int i = min((int)threadIdx.x, n_pl - 1);
+    r_pl = pooled[(size_t)(i >> 4) * C + c0 + (i & 15)];
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t row = ((size_t)min(u, ngroup - 1) * C + c0) * H;
+    const uint32_t mk = u < ngroup ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) r_g[e][u] = __uint_as_float(__float_as_uint(dW2_part[row + min(e * 512 + (int)threadIdx.x, n_w1 - 1)]) & mk);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // d(hidden) = relu'(hidden) * sum over the channel chunks' shares, chunks in index order.  Four elements per thread and eight chunks
+  // per round are in flight together (clamped indices, values masked by bit operations): written as one element after the other, every
+  // element waited for its own 16 loads - four to eight memory round trips in a row at the head of a 11 us kernel (round 4)
+  {
+    const int n_e = B * H;
+    for (int i0 = 0; i0 < n_e; i0 += 4 * 512) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      int ie[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ie[e] = min(i0 + e * 512 + (int)threadIdx.x, n_e - 1);
+      float hv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = hidden[ie[e]];     // (with the first round's loads, not one by one behind them)
+      for (int k0 = 0; k0 < nchunk; k0 += 8) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const size_t row = (size_t)min(k0 + u, nchunk - 1) * n_e;
+          const uint32_t mk = k0 + u < nchunk ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e][u] = __uint_as_float(__float_as_uint(dh_part[row + ie[e]]) & mk);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += v[e][u];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + e * 512 + (int)threadIdx.x;
+        if (i < n_e) s_dh[i] = hv[e] > 0.f ? acc[e] : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (u * 512 + (int)threadIdx.x < n_w1) s_w1[u * 512 + threadIdx.x] = r_w1[u];
+  for (int i = 2 * 512 + threadIdx.x; i < n_w1; i += 512) s_w1[i] = W1[(size_t)(i >> 4) * C + c0 + (i & 15)];
+  if ((int)threadIdx.x < n_pl) s_pool[threadIdx.x] = r_pl;
+  for (int i = 512 + threadIdx.x; i < n_pl; i += 512) s_pool[i] = pooled[(size_t)(i >> 4) * C + c0 + (i & 15)];
   // dW2 rows of the chunk ([16][H], contiguous): the utterance groups' partials in a fixed order
-  for (int i = threadIdx.x; i < kSeC2 * H; i += 512) {
-    float acc = 0.f;
-    for (int g = 0; g < ngroup; ++g) acc += dW2_part[((size_t)g * C + c0) * H + i];
-    dW2[(size_t)c0 * H + i] = acc;
+  for (int i0 = 0; i0 < kSeC2 * H; i0 += 2 * 512) {         // (two elements x four groups in flight, groups in index order)
+    const int n_w = kSeC2 * H;
+    float acc[2] = {0.f, 0.f};
+    int ie[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) ie[e] = min(i0 + e * 512 + (int)threadIdx.x, n_w - 1);
+    for (int g0 = 0; g0 < ngroup; g0 += 4) {
+      float v[2][4];
+      if (i0 == 0 && g0 == 0) {                           // workgroup-uniform: requested at the top of the kernel
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) v[e][u] = r_g[e][u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t row = ((size_t)min(g0 + u, ngroup - 1) * C + c0) * H;
+          const uint32_t mk = g0 + u < ngroup ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) v[e][u] = __uint_as_float(__float_as_uint(dW2_part[row + ie[e]]) & mk);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) acc[e] += v[e][u];
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = i0 + e * 512 + (int)threadIdx.x;
+      if (i < n_w) dW2[(size_t)c0 * H + i] = acc[e];
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < B * kSeC2; i += 512) {
