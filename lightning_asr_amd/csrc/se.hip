@@ -308,6 +308,16 @@ __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restric
 #pragma unroll
     for (int e = 0; e < 2; ++e) r_g[e][u] = __uint_as_float(__float_as_uint(dW2_part[row + min(e * 512 + (int)threadIdx.x, n_w1 - 1)]) & mk);
   }
+  // ... and so are the per-(utterance, channel) operands of the LAST phase (fused form): they depend on nothing this kernel computes
+  const int pf_cl = threadIdx.x & 15, pf_b = min((int)(threadIdx.x >> 4), B - 1), pf_c = c0 + pf_cl;
+  float pf_p[4] = {0.f, 0.f, 0.f, 0.f}, pf_sc = 0.f, pf_ys = 0.f, pf_mean = 0.f, pf_rstd = 0.f;
+  if (bn.tab) {                                                 // workgroup-uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pf_p[k] = P[((size_t)pf_b * 4 + k) * C + pf_c];
+    pf_sc = scale[(size_t)pf_b * C + pf_c];
+    pf_ys = bn.ysum[(size_t)pf_b * C + pf_c];
+    pf_mean = bn.saved[pf_c]; pf_rstd = bn.saved[C + pf_c];
+  }
   __builtin_amdgcn_sched_barrier(0);
   // d(hidden) = relu'(hidden) * sum over the channel chunks' shares, chunks in index order.  Four elements per thread and eight chunks
   // per round are in flight together (clamped indices, values masked by bit operations): written as one element after the other, every
@@ -405,16 +415,17 @@ __global__ __launch_bounds__(512) void se_bwd_pool_kernel(const float* __restric
   red_off = (red_off + 7) & ~(size_t)7;
   double* s_red = reinterpret_cast<double*>(reinterpret_cast<char*>(sm) + red_off);   // [4][32][16] | [4][16]
   const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4, c = c0 + cl;
-  const float mean = bn.saved[c], rstd = bn.saved[C + c];
+  const float mean = pf_mean, rstd = pf_rstd;
   double s1 = 0.0, s2 = 0.0, q1 = 0.0, q2 = 0.0;
   for (int b = bl; b < B; b += 32) {
-    const float p0 = P[((size_t)b * 4 + 0) * C + c], p1 = P[((size_t)b * 4 + 1) * C + c];
-    const float sc = scale[(size_t)b * C + c], sg = s_seg[b * kSeC2 + cl];
-    const float x1 = (bn.ysum[(size_t)b * C + c] - (float)Tt * mean) * rstd;
+    const bool first = b == bl;                                 // (requested at the top of the kernel)
+    const float p0 = first ? pf_p[0] : P[((size_t)b * 4 + 0) * C + c], p1 = first ? pf_p[1] : P[((size_t)b * 4 + 1) * C + c];
+    const float sc = first ? pf_sc : scale[(size_t)b * C + c], sg = s_seg[b * kSeC2 + cl];
+    const float x1 = ((first ? pf_ys : bn.ysum[(size_t)b * C + c]) - (float)Tt * mean) * rstd;
     s1 += (double)sc * p0 + (double)Tt * sg;
     s2 += (double)sc * p1 + (double)sg * x1;
-    q1 += (double)P[((size_t)b * 4 + 2) * C + c];
-    q2 += (double)P[((size_t)b * 4 + 3) * C + c];
+    q1 += (double)(first ? pf_p[2] : P[((size_t)b * 4 + 2) * C + c]);
+    q2 += (double)(first ? pf_p[3] : P[((size_t)b * 4 + 3) * C + c]);
   }
   s_red[(0 * 32 + bl) * kSeC2 + cl] = s1; s_red[(1 * 32 + bl) * kSeC2 + cl] = s2;
   s_red[(2 * 32 + bl) * kSeC2 + cl] = q1; s_red[(3 * 32 + bl) * kSeC2 + cl] = q2;
