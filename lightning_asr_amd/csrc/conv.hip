@@ -1164,16 +1164,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int ch = tid + NT * h;
-        const int tau = r * RS + ch / NW;
-        const int t = tA - P + tau;
+        const int t = tA - P + r * RS + ch / NW;
         const int cc = c0 + (ch % NW) * 8;
-        const bool ok = t >= 0 && t < Tlen && cc < C;
         const size_t off = (size_t)min(max(t, 0), Tlen - 1) * C + min(cc, C - 8);
-        const uint4 l0 = *reinterpret_cast<const uint4*>(db + off);
-        const uint4 l1 = Vec<bf16_t>::raw_if_nt<NTL>(xb + off);      // the unit's forward input: written ~1.5 ms and > 2 GB of traffic ago
-        const uint32_t mk = ok ? 0xffffffffu : 0u;
-        vd[r][h] = make_uint4(l0.x & mk, l0.y & mk, l0.z & mk, l0.w & mk);
-        vx[r][h] = make_uint4(l1.x & mk, l1.y & mk, l1.z & mk, l1.w & mk);
+        // kept RAW: the out-of-range mask is applied when the chunk is staged (phase 1).  Masked here, the next tile's loads - issued
+        // before the MFMA phases to travel under them - were waited for on the spot (round 4, read off the ISA: vmcnt(11) ... (0)
+        // right behind the sixteen loads)
+        vd[r][h] = *reinterpret_cast<const uint4*>(db + off);
+        vx[r][h] = Vec<bf16_t>::raw_if_nt<NTL>(xb + off);            // the unit's forward input: written ~1.5 ms and > 2 GB of traffic ago
       }
     }
     if (addend) {                                        // workgroup-uniform
@@ -1237,7 +1235,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int ch = tid + NT * h;
-        *reinterpret_cast<uint4*>(stage + (ch / NW) * LDST + ((ch % NW) << 4)) = isx ? vx[r][h] : vd[r][h];
+        const int t = tA - P + r * RS + ch / NW;
+        const uint32_t mk = (t >= 0 && t < Tlen && c0 + (ch % NW) * 8 < C) ? 0xffffffffu : 0u;   // frames / channels outside the tensor: zeros
+        const uint4 v = isx ? vx[r][h] : vd[r][h];
+        *reinterpret_cast<uint4*>(stage + (ch / NW) * LDST + ((ch % NW) << 4)) = make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
       }
       __syncthreads();
       char* img = isx ? ximg : dimg;
