@@ -511,8 +511,13 @@ __device__ __forceinline__ uint4 load_chunk_dual(const Bf16Args& g, int m0, int 
   const bf16_t* X = first ? g.A : g.A2;
   const int ld = first ? g.lda : g.lda2;
   const int kk = (first ? k0 : k0 - g.K1) + ((c & 7) << 3);
-  const uint4 v = *reinterpret_cast<const uint4*>(X + (uint32_t)min(m0 + (c >> 3), g.M - 1) * (uint32_t)ld + (uint32_t)kk);
-  const uint32_t mk = first ? kma[p] : 0xffffffffu;
+  (void)kma;   // RAW: the row mask is applied when the chunk is staged (dual_row_mask) - masked here, the load issued for the step
+               // after next was waited for on the spot instead of under a K step of MFMAs (round 4)
+  return *reinterpret_cast<const uint4*>(X + (uint32_t)min(m0 + (c >> 3), g.M - 1) * (uint32_t)ld + (uint32_t)kk);
+}
+// the folded eval form's row mask for chunk p of the K step that starts at k0 (first operand only)
+__device__ __forceinline__ uint4 dual_row_mask(const Bf16Args& g, uint4 v, int k0, int p, const uint32_t (&kma)[4]) {
+  const uint32_t mk = k0 < g.K1 ? kma[p] : 0xffffffffu;   // workgroup-uniform choice
   return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
 }
 
@@ -548,7 +553,8 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
       // 8-byte row-major LDS writes (the natural order left 2-byte writes: 128 ds_write_b16 per lane, 9 us per launch)
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cur][ni], a[cur][mi], acc[mi][ni], 0, 0, 0);
     if constexpr (STORE) {
-      store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
+      if constexpr (DUAL) store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, dual_row_mask(g, ra[ks], k_store, ks, kma), k_store, kend, ks);
+      else store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
       if constexpr (CF::NCB == 4) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks], k_store, kend, ks);
       else if (ks < CF::NCB) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks < CF::NCB ? ks : 0], k_store, kend, ks);
     }
@@ -630,6 +636,10 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     load_vec<TRANS_A, BTM, NT, 4, NTL>(g.A, g.lda, g.M, m0, kbeg, kend, ra);
   }
   load_vec<TRANS_B, BTN, NT, CF::NCB, NTL>(g.B, g.ldb, g.N, n0, kbeg, kend, rb);
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ra[p] = dual_row_mask(g, ra[p], kbeg, p, kma);
+  }
   store_vec<TRANS_A, BTM, NT, LD_KC, LDR>(smem, ra, kbeg, kend);
   store_vec<TRANS_B, BTN, NT, LD_KC, CF::LDRB, CF::NCB>(smem + OPER, rb, kbeg, kend);
   if (tid < BTM) s_keep[tid] = (m0 + tid < g.M && (!row_masked || keep_pos < keep_len)) ? 1.f : 0.f;   // (the length word arrived before the tile did)
