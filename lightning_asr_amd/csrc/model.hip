@@ -528,15 +528,16 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
     int merged = 1;      // bf16: the lengths and the weights' bf16 shadow in one launch (two independent launch-floor kernels)
     m->taps_valid = false;
     if (dt == LASR_BF16) {
-      DwTapJobs jobs;                                       // training: the depthwise tap tables ride in the same launch
+      DwTapJobs jobs;                                       // the depthwise tap tables ride in the same launch (training and eval forwards)
       jobs.n = 0; jobs.blk0[0] = 0;
-      if (training)
+      {
         for (const Unit& u : m->units)
           if (u.o_taps && jobs.n < 16) {
             jobs.w[jobs.n] = params + u.w_dw; jobs.out[jobs.n] = reinterpret_cast<uint32_t*>(at(ws, u.o_taps)); jobs.C[jobs.n] = u.ci; jobs.k[jobs.n] = u.k;
             jobs.blk0[jobs.n + 1] = jobs.blk0[jobs.n] + (int)cdiv((int64_t)2 * u.ci * kDwTapRow, 256);
             ++jobs.n;
           }
+      }
       merged = mask_lengths_step_cast(pct, B, T, lens, dropping ? m->drop_step : nullptr, params, at(ws, p.o_wbf16), m->n_param,
                                       jobs.n ? &jobs : nullptr, stream);
       if (merged < 0 || merged > 1) return merged;
