@@ -174,22 +174,42 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
       }
     }
     __syncthreads();
-    for (int t = 0; t < kWT; ++t) {
-      const float4 dv = *reinterpret_cast<const float4*>(s_d + (size_t)t * kCB + cl * 4);
+    // The tap-group count as a compile-time constant and every LDS read of two frames issued before their FMAs (clamped row: rows
+    // past the staged window belong to taps >= k, discarded below).  With `if (q < nq) if (row < in_rows)` around each read, every
+    // one of the 64 x nq reads was its own LDS round trip: 20 us for the 34 M MACs of the one stride-2 layer (round 4).
+    auto inner = [&](auto nq_c) {
+      constexpr int NQ = decltype(nq_c)::value;
+#pragma unroll 2
+      for (int t = 0; t < kWT; t += 2) {
+        float4 dv[2], xv[2][NQ];
 #pragma unroll
-      for (int q = 0; q < kQ; ++q) {
-        if (q < nq) {
-          const int j = jl + 16 * q;  // rows past k-1 read the next frames' data: harmless, discarded below
-          const int row = t * stride + j;
-          if (row < in_rows) {
-            const float4 xv = *reinterpret_cast<const float4*>(s_x + (size_t)row * kCB + cl * 4);
-            acc[q][0] = fmaf(dv.x, xv.x, acc[q][0]);
-            acc[q][1] = fmaf(dv.y, xv.y, acc[q][1]);
-            acc[q][2] = fmaf(dv.z, xv.z, acc[q][2]);
-            acc[q][3] = fmaf(dv.w, xv.w, acc[q][3]);
-          }
+        for (int u = 0; u < 2; ++u) {
+          dv[u] = *reinterpret_cast<const float4*>(s_d + (size_t)(t + u) * kCB + cl * 4);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            xv[u][q] = *reinterpret_cast<const float4*>(s_x + (size_t)min((t + u) * stride + jl + 16 * q, in_rows - 1) * kCB + cl * 4);
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            acc[q][0] = fmaf(dv[u].x, xv[u][q].x, acc[q][0]);
+            acc[q][1] = fmaf(dv[u].y, xv[u][q].y, acc[q][1]);
+            acc[q][2] = fmaf(dv[u].z, xv[u][q].z, acc[q][2]);
+            acc[q][3] = fmaf(dv[u].w, xv[u][q].w, acc[q][3]);
+          }
       }
+    };
+    static_assert(kWT % 2 == 0 && kQ == 8, "dwconv_wgrad_kernel: tap groups");
+    switch (nq) {                                          // workgroup-uniform
+      case 1: inner(std::integral_constant<int, 1>{}); break;
+      case 2: inner(std::integral_constant<int, 2>{}); break;
+      case 3: inner(std::integral_constant<int, 3>{}); break;
+      case 4: inner(std::integral_constant<int, 4>{}); break;
+      case 5: inner(std::integral_constant<int, 5>{}); break;
+      case 6: inner(std::integral_constant<int, 6>{}); break;
+      case 7: inner(std::integral_constant<int, 7>{}); break;
+      default: inner(std::integral_constant<int, 8>{}); break;
     }
   }
   if (!c_ok) return;
