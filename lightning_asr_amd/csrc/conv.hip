@@ -52,11 +52,24 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
   const T* xb = x + (int64_t)b * Tin * C;
 
   // taps -> LDS [j][channel]
-  for (int i = threadIdx.x; i < k * kCB; i += 256) {
-    const int ch = i / k, j = i - ch * k;
-    float v = 0.f;
-    if (c0 + ch < C) v = w[(c0 + ch) * k + (flip ? (k - 1 - j) : j)];
-    s_w[j * kCB + ch] = v;
+  // (rounds of eight unconditional loads - clamped channel, value masked by bit operations - then their LDS writes: a guarded load per
+  //  element was a memory round trip per element, nine in a row for k = 33; round 4)
+  for (int i0 = 0; i0 < k * kCB; i0 += 8 * 256) {
+    float tv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = min(i0 + u * 256 + (int)threadIdx.x, k * kCB - 1);
+      const int ch = i / k, j = i - ch * k;
+      tv[u] = w[min(c0 + ch, C - 1) * k + (flip ? (k - 1 - j) : j)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256 + (int)threadIdx.x;
+      if (i < k * kCB) {
+        const int ch = i / k, j = i - ch * k;
+        s_w[j * kCB + ch] = __uint_as_float(__float_as_uint(tv[u]) & (c0 + ch < C ? 0xffffffffu : 0u));
+      }
+    }
   }
   // input rows t0*stride - pad ... (+in_rows), zero outside [0, Tin)
   const int64_t in0 = t0 * stride - pad;
