@@ -405,3 +405,22 @@ def test_native_ingest_probes_the_manifest_before_it_takes_over(tmp_path):
     assert ingest.fast_ingest_ok(MyAudioDataset([manifest("good.json", good)], labels))
     assert not ingest.fast_ingest_ok(MyAudioDataset([manifest("mixed.json", good[:2] + [str(flac)] + good[2:])], labels, ), probe=8)
     assert not ingest.fast_ingest_ok(MyAudioDataset([manifest("last.json", good + [str(flac)])], labels))
+
+
+def test_fit_reserves_the_workspace_for_the_longest_clip():
+    """FusedLoop sizes the model workspace once, for the longest clip (capped by train_max_duration) and transcript of the training
+    set: growing it batch by batch stalled the GPU behind multi-GB allocations."""
+    from types import SimpleNamespace
+    from lightning_asr_amd import ops
+    from lightning_asr_amd.fused_fit import FusedLoop
+    calls = []
+    items = [{"duration": 3.2, "text": "abc"}, {"duration": 12.5, "text": "a" * 41}, {"duration": 30.0, "text": "zz"}]
+    me = SimpleNamespace(dm=SimpleNamespace(train_datasets=SimpleNamespace(datasets=items), train_max_duration=16.7, train_bs=24),
+                         native=SimpleNamespace(workspace=lambda B, T, S: calls.append((B, T, S))))
+    FusedLoop._reserve_workspace(me)
+    assert calls == [(24, ops.mel_num_frames(int(16.7 * 16000 + 0.5) + 1), 41)]
+    FusedLoop._reserve_workspace(me)                       # once per loop
+    assert len(calls) == 1
+    me2 = SimpleNamespace(dm=SimpleNamespace(train_datasets=SimpleNamespace(datasets=[]), train_bs=8), native=me.native)
+    FusedLoop._reserve_workspace(me2)                      # nothing to size from: no call
+    assert len(calls) == 1
