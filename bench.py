@@ -19,7 +19,10 @@ step i+1's waveforms inside its CTC launch (one batch of features per step eithe
 synthetic wav corpus + manifest): wav decode by the library's host threads, int16 H2D, the training-time random crop and SpecAugment
 draws, and the per-step greedy decode + WER logging are then INSIDE the timed region (stated in config.included).
 
-N>1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
+N>1: ``python bench.py --gpus N`` starts its own N per-GPU worker processes (as the reference's Lightning DDP does from a plain
+``python train.py``); under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (the driver's form) every
+rank supervises one worker.  Either way a failed attempt is retried in fresh processes one rung down (graph + lasr_comm -> eager +
+lasr_comm -> eager + torch.distributed; lightning_asr_amd/launch.py) and the line's `launcher` record says which rung ran.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -386,6 +389,13 @@ def main():
                     help="skip the `trainer` sub-record (25 + 30 steps through Trainer.fit) of the default one-GPU line")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    # N > 1 from the plain command (`python bench.py --gpus N`, no outer launcher) or under torch.distributed.run: a supervisor that
+    # never touches the GPU starts FRESH worker processes, one per GPU, relays rank 0's JSON line (plus a `launcher` record: which
+    # rung of graph + lasr_comm -> eager + lasr_comm -> eager + torch.distributed ran) and exits with their code - launch.py
+    from lightning_asr_amd import launch
+    rc = launch.maybe_launch(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
     if args.path == "trainer":
         return trainer_path(args, cfg)
 
@@ -639,9 +649,10 @@ def main():
         except Exception as e:      # the headline number above stands on its own; say why the sub-record is missing
             trainer_rec = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    if dist is not None:
+        dist.destroy_process_group()        # (rank 0 goes on alone from here: nobody waits in a collective for its CPU baseline)
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
     metric = "audio-seconds/sec training (asr13x1, bs=32, 10 s clips)" if args.config == "cfg2" else \
         "audio-seconds/sec training (%s)" % args.config
@@ -664,13 +675,14 @@ def main():
     }
     if comm_rec is not None:
         out["comm"] = comm_rec
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
+        # rank 0 only; at N > 1 AFTER the process group is gone and the other ranks have left the GPU box's cores alone
         out["cpu_baseline"] = cpu_baseline(args.config, V)
+    if launch.rung_info() is not None:
+        out["config"]["launch_rung"] = launch.rung_info()["rung_index"]
     if trainer_rec is not None:
         out["trainer"] = trainer_rec
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -157,9 +157,11 @@ class Trainer:
         self.device = torch.device(device) if device else torch.device("cuda", self.local_rank)
         n_gpus = len(gpus) if isinstance(gpus, (list, tuple)) else (int(gpus) if isinstance(gpus, (int, str)) and str(gpus).lstrip("-").isdigit() else None)
         if n_gpus is not None and n_gpus > 1 and self.world == 1:
-            raise RuntimeError("gpus=%s asks for %d data-parallel ranks but WORLD_SIZE is 1: this host runs one process per GPU, "
-                               "launch with `python -m torch.distributed.run --nproc-per-node %d -m lightning_asr_amd.train ...`"
-                               % (gpus, n_gpus, n_gpus))
+            raise RuntimeError("gpus=%s asks for %d data-parallel ranks but WORLD_SIZE is 1: this host runs one process per GPU.  "
+                               "`python -m lightning_asr_amd.train train.gpus=%d` starts them itself (lightning_asr_amd/launch.py, before "
+                               "anything touches the GPU); a script that builds its own Trainer calls launch.maybe_launch(n, argv) first or "
+                               "runs under `python -m torch.distributed.run --nproc-per-node %d`"
+                               % (gpus, n_gpus, n_gpus, n_gpus))
         self.history: List[Dict[str, Any]] = []
         self._epoch_metrics: Dict[str, List[float]] = {}
         self._best: List[tuple] = []

@@ -139,6 +139,16 @@ class LightingModule(LightningModule):
         logger.info("保存一个checkpoint epoch={:d}".format(self.current_epoch))
 
 
+def _n_gpus(gpus) -> int:
+    """Lightning's `gpus` argument (int, "N", or a list of device ids) as a rank count"""
+    if isinstance(gpus, (list, tuple)):
+        return len(gpus)
+    try:
+        return max(1, int(gpus))
+    except (TypeError, ValueError):
+        return 1
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     conf_dir = os.environ.get("LASR_CONF_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "conf"))
@@ -151,6 +161,15 @@ def main(argv=None):
         labels = [c.strip() for c in open(labels, "r", encoding="utf-8").readlines()]
         use_cer = True
     dtype = model_cfg.get("dtype", "bf16" if tran_cfg.get("precision") == 16 else "f32")
+    # `gpus: N` + `accelerator: ddp` from the plain command (conf/conf.yaml:21,30; Lightning's DDP plugin starts its per-GPU children
+    # itself, train.py:233-252): decided HERE, before anything touches the GPU - this process becomes the supervisor of N fresh worker
+    # processes (launch.py: RANK / LOCAL_RANK / MASTER_PORT in their environment, a fallback ladder around them) and returns their code
+    from . import launch
+    rc = launch.maybe_launch(_n_gpus(tran_cfg.get("gpus")), [sys.executable, "-m", "lightning_asr_amd.train"] + argv, hold_json=False)
+    if rc is not None:
+        if rc != 0:
+            raise SystemExit(rc)
+        return None
     # one process per GPU (torch.distributed.run sets LOCAL_RANK): select this rank's device BEFORE anything allocates, and
     # hand the indexed device to every component that owns GPU memory (the flat parameter buffers, the mel workspaces)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
