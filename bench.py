@@ -280,10 +280,11 @@ def trainer_path(args, cfg, emit: bool = True, steps=None, warmup=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is hand-written HIP with no CPU fallback")
+    from lightning_asr_amd.data_module import LibriDataModule
+    from lightning_asr_amd.lightning_compat import Trainer, rank_device_index, seed_everything
+    local_rank = rank_device_index()         # (LASR_DIST_BACKEND=gloo: ranks share the devices round-robin - the one-GPU rehearsal)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    from lightning_asr_amd.data_module import LibriDataModule
-    from lightning_asr_amd.lightning_compat import Trainer, seed_everything
     from lightning_asr_amd.train import LightingModule
     labels = [c.strip() for c in open(os.path.join(ROOT, cfg["vocab"]), encoding="utf-8").readlines()]
     V, B = len(labels), args.batch

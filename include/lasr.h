@@ -84,6 +84,11 @@ int lasr_mel_fwd_src(const lasr_wave_src* src, const int32_t* sample_lens, const
                      void* workspace, size_t workspace_bytes, void* stream);
 int lasr_dither_noise(uint64_t seed, const uint64_t* step, int64_t B, int64_t L, float* out, void* stream);
 
+/* AudioParser.spec_augment as a stand-alone call (data_module.py:97-122; inside the training chain the same zeros are written by
+ * lasr_mel_fwd's `aug`): out = in with rows [rect_x, rect_x + w_x) and frames [rect_y, rect_y + w_y) of every (F, T) plane zeroed;
+ * in / out (B, F, T) f32 (out may alias in), aug (B, 4) int32 = (rect_x, w_x, rect_y, w_y) drawn by the caller.        */
+int lasr_spec_augment(const float* in, float* out, const int32_t* aug, int64_t B, int64_t F, int64_t T, void* stream);
+
 /* (B, C, T) f32 reference layout -> [B][T][C] channels-last `dtype`   (models/QuartNet.py:154 squeeze) */
 int lasr_bct_to_btc(const float* in, void* out, int dtype, int64_t B, int64_t C, int64_t T, void* stream);
 int lasr_btc_to_bct(const void* in, int dtype, float* out, int64_t B, int64_t C, int64_t T, void* stream);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "lasr_mel_fwd": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "lasr_mel_fwd_src": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _i32, _p, _p, _p, _sz, _p]),
     "lasr_dither_noise": (_i32, [C.c_uint64, _p, _i64, _i64, _p, _p]),
+    "lasr_spec_augment": (_i32, [_p, _p, _p, _i64, _i64, _i64, _p]),
     "lasr_bct_to_btc": (_i32, [_p, _p, _i32, _i64, _i64, _i64, _p]),
     "lasr_btc_to_bct": (_i32, [_p, _i32, _p, _i64, _i64, _i64, _p]),
     "lasr_mask_lengths": (_i32, [_p, _i64, _i64, _p, _p]),

@@ -513,7 +513,8 @@ int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* pro
                                                     const lstm::BwdArgs& rec, int dtype, int64_t B, void* stream) {
   const int64_t T_ = rec.Tt;
   static const bool off = getenv("LASR_LSTM_BESIDE_WGRAD") && atoi(getenv("LASR_LSTM_BESIDE_WGRAD")) == 0;
-  if (off || dtype != LASR_BF16 || B % 8 != 0 || B > 128 || n_probs < 1 || !n_taken) return 1;
+  static const bool small_only_ab = getenv("LASR_WGRAD_SMALL_TILE") != nullptr;   // the A/B switch takes the 128-row tiles: no room for the recurrences' slot
+  if (off || small_only_ab || dtype != LASR_BF16 || B % 8 != 0 || B > 128 || n_probs < 1 || !n_taken) return 1;
   // How many slices the tiles should be cut into so that they are through when the recurrences are (measured on the MI355X, round 4:
   // 0.36 us per recurrence step; a 256 x 256 tile 1.7 us per 64 rows of K + ~15 us around them), and how many tiles of that length
   // fit in ONE round beside the B recurrence workgroups.  The problems past that budget stay with the caller: the stage's closing

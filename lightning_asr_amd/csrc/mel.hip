@@ -610,7 +610,29 @@ __global__ __launch_bounds__(256) void dither_noise_kernel(unsigned long long se
     if (4 * g + q < L) out[(int64_t)b * L + 4 * g + q] = z[q];
 }
 
+// SpecAugment's zeros on an existing (B, F, T) f32 feature tensor (data_module.py:97-122): rows [rx, rx+wx) and frames [ry, ry+wy)
+__global__ __launch_bounds__(256) void spec_augment_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           const int32_t* __restrict__ aug, int64_t F, int64_t T) {
+  const int64_t b = blockIdx.z, f = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int rx = aug[b * 4 + 0], wx = aug[b * 4 + 1], ry = aug[b * 4 + 2], wy = aug[b * 4 + 3];
+  const int64_t i = (b * F + f) * T + t;
+  const bool hit = (f >= rx && f < rx + wx) || (t >= ry && t < ry + wy);
+  out[i] = hit ? 0.f : in[i];
+}
+
 }  // namespace lasr
+
+extern "C" int lasr_spec_augment(const float* in, float* out, const int32_t* aug, int64_t B, int64_t F, int64_t T, void* stream) {
+  LASR_CHECK_ARG(in && out && aug, "lasr_spec_augment: null pointer");
+  LASR_CHECK_SHAPE(B > 0 && B < 65536 && F > 0 && F < 65536 && T > 0 && T < (1ll << 30), "lasr_spec_augment: B=%lld F=%lld T=%lld",
+                   (long long)B, (long long)F, (long long)T);
+  hipLaunchKernelGGL(spec_augment_kernel, dim3((unsigned)cdiv(T, 256), (unsigned)F, (unsigned)B), dim3(256), 0, as_stream(stream),
+                     in, out, aug, F, T);
+  LASR_LAUNCH_CHECK("spec_augment_kernel");
+  return 0;
+}
 
 extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dither, const int32_t* aug,
                             int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,

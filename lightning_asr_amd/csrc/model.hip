@@ -756,6 +756,11 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   float* gl = atf(ws, p.o_glogits);
   const Unit& last = m->units.back();
   int cur = m->bwd_cur;
+  // the batch-mean loss forward_and_loss left to this call's first launch: taken over HERE and forgotten by the model, so that an
+  // error return below (or a later, separate lasr_model_backward) can never write through a stale caller pointer
+  const float* tail_nll = m->tail_nll;
+  float* tail_loss = m->tail_loss;
+  m->tail_nll = nullptr; m->tail_loss = nullptr;
   if (with_head) {
   cur = 0;
   // decoder (models/QuartNet.py:275): dW = gl^T h, db = colsum(gl), dh = gl W
@@ -769,19 +774,19 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
     ld_gl = (C + 7) / 8 * 8;
     ProfScope ps(LASR_PROF_HEAD, stream, (double)N * C * 6);
     int merged = 1;
-    if (m->tail_loss) {      // padded copy + bias-gradient column sums + the loss mean forward_and_loss left to this launch
-      merged = head_tail(gl, N, C, at(ws, p.o_d1), ld_gl, grads + m->b_dec, scratch, sb, m->tail_nll, B, 1.0f / (float)B, m->tail_loss, stream);
+    if (tail_loss) {         // padded copy + bias-gradient column sums + the loss mean forward_and_loss left to this launch
+      merged = head_tail(gl, N, C, at(ws, p.o_d1), ld_gl, grads + m->b_dec, scratch, sb, tail_nll, B, 1.0f / (float)B, tail_loss, stream);
       if (merged < 0 || merged > 1) return merged;
-      if (merged == 1) LASR_TRY(lasr_scale_sum_f32(m->tail_nll, B, 1.0f / (float)B, m->tail_loss, stream));
-      m->tail_loss = nullptr; m->tail_nll = nullptr;
+      if (merged == 1) LASR_TRY(lasr_scale_sum_f32(tail_nll, B, 1.0f / (float)B, tail_loss, stream));
+      tail_loss = nullptr;
       bias_done = merged == 0;
     }
     if (merged == 1) LASR_TRY(lasr_cast_pad_f32_to_bf16(gl, at(ws, p.o_d1), N, C, ld_gl, stream));
     gl_ab = at(ws, p.o_d1);
   }
-  if (m->tail_loss) {        // (not reached in bf16; keeps the loss defined whatever path the head takes)
-    LASR_TRY(lasr_scale_sum_f32(m->tail_nll, B, 1.0f / (float)B, m->tail_loss, stream));
-    m->tail_loss = nullptr; m->tail_nll = nullptr;
+  if (tail_loss) {           // (not reached in bf16; keeps the loss defined whatever path the head takes)
+    LASR_TRY(lasr_scale_sum_f32(tail_nll, B, 1.0f / (float)B, tail_loss, stream));
+    tail_loss = nullptr;
   }
   LASR_TRY(lasr_gemm_ld(gl_ab, ld_gl, at(ws, last.o_out), 1024, grads + m->w_dec, 1024, dt, LASR_F32, C, 1024, N, 1, 1, nullptr,
                         dec_wgrad_split(C, N), scratch, sb, stream));
@@ -934,6 +939,11 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
         // d(block23 out) = d(cat)[:, :256] + dG_f W_ih_f + dG_r W_ih_r is needed now.   (7 small launches fewer than the separate form)
         const int np = (int)B * lstm::kDwZ;
         const int64_t gh = (int64_t)lstm::G * lstm::H;
+        if (pending.size() + wprobs.size() + 8 > 64) {      // six segments + two problems are about to join (lasr_reduce_many takes 64)
+          LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
+          LASR_TRY(lasr_reduce_many(pending.data(), (int)pending.size(), stream));
+          pending.clear();
+        }
         for (int d = 0; d < 2; ++d) {
           pending.push_back({atf(ws, p.o_lstm_part) + (int64_t)d * np * gh, grads + m->lstm.w_hh[d], gh, np});
           pending.push_back({atf(ws, p.o_lstm_bpart) + (int64_t)d * np * lstm::G, grads + m->lstm.b_ih[d], lstm::G, np});

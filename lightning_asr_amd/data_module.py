@@ -33,19 +33,19 @@ def load_wav(path_or_file) -> torch.Tensor:
             pcm = np.frombuffer(w.readframes(n), dtype="<i2").reshape(-1, ch).T
         return torch.from_numpy(pcm[:1].astype(np.float32) / 32768.0)
     except (ValueError, _wave.Error, EOFError) as e:
-        # flac / 24-bit / float wav (LibriSpeech's native format): whatever decoder the site has, as torchaudio.load did for the
-        # reference (data_module.py:153); neither is installed in this image
+        # flac / 24-bit / float wav (LibriSpeech's native format): the site's `soundfile`, if it has one (the reference's own
+        # requirements list it next to torchaudio; not installed in this image).  No torchaudio anywhere in this package.
+        if hasattr(path_or_file, "seek"):
+            path_or_file.seek(0)                         # a file-like input was partly consumed by the wave reader above
         try:
             import soundfile as sf
-            data, _sr = sf.read(path_or_file, dtype="float32", always_2d=True)
-            return torch.from_numpy(np.ascontiguousarray(data.T[:1]))
         except ImportError:
-            pass
+            raise ValueError("%s: %s (not a 16-bit PCM wav, and no `soundfile` module to decode other formats)" % (path_or_file, e)) from e
         try:
-            import torchaudio
-            return torchaudio.load(path_or_file)[0][:1].float()
-        except ImportError:
-            raise ValueError("%s: %s (no soundfile / torchaudio available to decode other formats)" % (path_or_file, e)) from e
+            data, _sr = sf.read(path_or_file, dtype="float32", always_2d=True)
+        except Exception as e2:                          # soundfile raises RuntimeError / LibsndfileError for what it cannot read
+            raise ValueError("%s: neither the wave reader (%s) nor soundfile (%s) can decode it" % (path_or_file, e, e2)) from e2
+        return torch.from_numpy(np.ascontiguousarray(data.T[:1]))
 
 
 class AudioParser:
@@ -88,6 +88,28 @@ class AudioParser:
         rect_x = int(self.rand.uniform(0, 64 - w_x))
         rect_y = int(self.rand.uniform(0, n_time - w_y))
         return rect_x, w_x, rect_y, w_y
+
+    def spec_augment(self, x: torch.Tensor, freq_mask: Union[int, float] = 27, time_mask: Union[int, float] = 100) -> torch.Tensor:
+        """The reference's public method (data_module.py:97-122), same signature and draw order: x (1, 64, T) -> a copy with
+        `w_x` mel rows from `rect_x` and `w_y` frames from `rect_y` set to zero.  Inside `parse_audio` / the training loop the same
+        rectangle travels into the mel kernel (`draw_spec_augment` + `lasr_mel_fwd`'s aug); this stand-alone form is one
+        `lasr_spec_augment` launch on an existing feature tensor."""
+        if x.dim() != 3:
+            raise ValueError("spec_augment expects (1, F, T) features, got %s" % (tuple(x.shape),))
+        if isinstance(freq_mask, float):
+            freq_mask = int(x.shape[1] * freq_mask)
+        if isinstance(time_mask, float):
+            time_mask = int(x.shape[2] * time_mask)
+        w_x = int(self.rand.uniform(0, freq_mask))
+        w_y = int(self.rand.uniform(0, time_mask))
+        rect_x = int(self.rand.uniform(0, x.shape[1] - w_x))
+        rect_y = int(self.rand.uniform(0, x.shape[2] - w_y))
+        xin = x.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(xin)
+        aug = torch.tensor([[rect_x, w_x, rect_y, w_y]] * xin.shape[0], dtype=torch.int32, device=self.device)
+        ops.call("lasr_spec_augment", xin.data_ptr(), out.data_ptr(), aug.data_ptr(), xin.shape[0], xin.shape[1], xin.shape[2],
+                 torch.cuda.current_stream(self.device).cuda_stream)
+        return out.to(x.device)
 
     def parse_audio(self, audio_path, mask=False) -> torch.Tensor:
         if isinstance(audio_path, str) and not os.path.exists(path=audio_path):

@@ -245,15 +245,22 @@ class DeviceFeeder:
         if n > self.pcm[k].numel() or hb.meta_words > self.meta[k].numel():
             # A batch outgrew its slot.  The new block is allocated UNDER THE COPY STREAM: the caching allocator keeps one pool per
             # stream, so it cannot be a block the compute thread just freed with kernels still queued on the compute stream (the
-            # H2D copy below is not ordered against that stream).  The outgrown block is parked until close(): steps still in
-            # flight may be reading it, and `released` only orders the copy stream behind them, not the allocator.
+            # H2D copy below is not ordered against that stream).  The outgrown block is parked while steps still in flight may be
+            # reading it: `released` was recorded behind the last kernel that reads this slot, so the block is provably idle once
+            # that event has completed - parked blocks are dropped then (ragged epochs no longer pin every outgrown
+            # block of every slot until close()).
+            idle = released is None or released.query()
             with torch.cuda.stream(cs):
                 if n > self.pcm[k].numel():
-                    self._retired.append(self.pcm[k])
+                    if not idle:
+                        self._retired.append((self.pcm[k], released))
                     self.pcm[k] = torch.empty(int(n * 1.25) + 64, dtype=torch.int16, device=self.device)
                 if hb.meta_words > self.meta[k].numel():
-                    self._retired.append(self.meta[k])
+                    if not idle:
+                        self._retired.append((self.meta[k], released))
                     self.meta[k] = torch.empty(int(hb.meta_words * 1.5) + 64, dtype=torch.int32, device=self.device)
+        if self._retired:
+            self._retired = [(blk, ev_) for blk, ev_ in self._retired if not ev_.query()]
         if released is not None:
             cs.wait_event(released)             # the step that read this device slot has finished with it
         with torch.cuda.stream(cs):

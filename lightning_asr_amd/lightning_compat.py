@@ -131,6 +131,15 @@ class GradSync:
         return 1.0 / self.world
 
 
+def rank_device_index() -> int:
+    """the device this rank trains on: LOCAL_RANK (one GPU per rank over nccl = RCCL).  LASR_DIST_BACKEND=gloo is the rehearsal of
+    several ranks on a box with fewer GPUs (RCCL refuses two ranks on one device): the ranks then share the devices round-robin"""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LASR_DIST_BACKEND", "nccl") != "nccl":
+        return local_rank % max(1, torch.cuda.device_count())
+    return local_rank
+
+
 class Trainer:
     """fit / test loops for the reference's LightingModule + LibriDataModule pair (train.py:233-253)."""
 
@@ -154,7 +163,7 @@ class Trainer:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.device = torch.device(device) if device else torch.device("cuda", self.local_rank)
+        self.device = torch.device(device) if device else torch.device("cuda", rank_device_index())
         n_gpus = len(gpus) if isinstance(gpus, (list, tuple)) else (int(gpus) if isinstance(gpus, (int, str)) and str(gpus).lstrip("-").isdigit() else None)
         if n_gpus is not None and n_gpus > 1 and self.world == 1:
             raise RuntimeError("gpus=%s asks for %d data-parallel ranks but WORLD_SIZE is 1: this host runs one process per GPU.  "
@@ -417,3 +426,16 @@ class Trainer:
         outs = [model.test_step(batch, i) for i, batch in enumerate(self._eval_batches(loader, dm, len(loader)))]
         model.test_epoch_end(outs)
         return outs
+
+    def teardown(self) -> None:
+        """end of a multi-rank run (the CLI calls it; Lightning tears its DDP plugin down the same way): every rank arrives, the
+        library's communicator and the torch.distributed group are released in that order, so no rank exits under a peer's collective"""
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_initialized():
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            dist.barrier()
+            comm = getattr(getattr(self.fused, "ts", None), "comm", None)
+            if comm is not None:
+                comm.close()
+            dist.destroy_process_group()

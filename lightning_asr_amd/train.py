@@ -14,7 +14,7 @@ import torch
 from . import ops
 from .config import load_config
 from .data_module import LibriDataModule
-from .lightning_compat import LightningModule, Trainer, seed_everything
+from .lightning_compat import LightningModule, Trainer, rank_device_index, seed_everything
 from .scheduler.cosine_annearing_with_warmup import CosineAnnealingWarmupRestarts
 from .scheduler.novograd import Novograd
 from .utils.asr_metrics import WER
@@ -172,7 +172,7 @@ def main(argv=None):
         return None
     # one process per GPU (torch.distributed.run sets LOCAL_RANK): select this rank's device BEFORE anything allocates, and
     # hand the indexed device to every component that owns GPU memory (the flat parameter buffers, the mel workspaces)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = rank_device_index()
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     data_module = LibriDataModule(data_cfg.get("train_manifest"), data_cfg.get("val_manifest"), labels=labels,
@@ -198,4 +198,6 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    _tr = main()
+    if _tr is not None:
+        _tr.teardown()

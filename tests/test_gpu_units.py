@@ -30,8 +30,14 @@ pytestmark = pytest.mark.gpu
 # Measured on MI355X (profiles/r02_unit_parity.json): bf16 act <= 8e-5, grad_act <= 4.5e-4, grad_param <= 4.5e-4;
 # f32 act <= 4e-7, grad_param <= 2e-6, grad_act <= 2e-4 (that one is d(logits): the lattice kernel evaluates lse on the
 # v_exp_f32 / v_log_f32 units, torch's CPU ctc_loss on libm - north_star's gate for the CTC loss itself is 1e-4).
+# Round 5 (VERDICT r4 "what's weak" 3): the bf16 gradient gates are per KIND OF UNIT.  Dense units (every conv unit, the BiLSTM context,
+# SE, the dense head): 1.0e-3 - the worst measured over all nine dense reports is 6.0e-4 / 4.9e-4 (profiles/r04_unit_parity_*.json), so a
+# regression that doubles any dense unit's error now fails.  The lean head's STORED-in-bf16 d(logits) alone keeps 1.5e-3 (its relative
+# L2 against the rounded oracle is the bf16 quantisation floor, measured 1.20e-3; what it is really held to is the elementwise
+# bf16-neighbour check below).
 TOL = {
-    "bf16": {"act": 3e-4, "grad_act": 1.5e-3, "grad_param": 1.5e-3, "logp_abs": 2e-5, "nll": 2e-6, "loss_e2e": 1e-3},
+    "bf16": {"act": 3e-4, "grad_act": 1.0e-3, "grad_param": 1.0e-3, "grad_act_lean_glogits": 1.5e-3, "logp_abs": 2e-5, "nll": 2e-6,
+             "loss_e2e": 1e-3},
     "f32": {"act": 5e-6, "grad_act": 6e-4, "grad_param": 2e-5, "logp_abs": 2e-5, "nll": 2e-6, "loss_e2e": 1e-5},
 }
 
@@ -105,14 +111,15 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
     report = {"config": tag, "mode": mode, "act": act, "B": B, "T_in": int(feats.shape[1]), "T": T, "C": n_class, "units": {}}
     worst = {"act": 0.0, "grad_act": 0.0, "grad_param": 0.0}
 
-    def note(unit, kind, key, val):
+    def note(unit, kind, key, val, gate=None):
         report["units"].setdefault(unit, {})[key] = val
         worst[kind] = max(worst[kind], val)
+        gate = tol[kind] if gate is None else gate
         if os.environ.get("LASR_UNITS_NOASSERT"):          # diagnosis: collect the whole report, fail at the end
-            if val >= tol[kind]:
-                report.setdefault("over_tolerance", []).append((unit, key, val, tol[kind]))
+            if val >= gate:
+                report.setdefault("over_tolerance", []).append((unit, key, val, gate))
             return
-        assert val < tol[kind], (tag, unit, key, val, tol[kind])
+        assert val < gate, (tag, unit, key, val, gate)
 
     def grad_of(name, c):
         return _bct(units[name]["g_cur"][:N * c].view(B, T, c))
@@ -224,7 +231,7 @@ def run_units_check(dev, variant, n_class, dtype, wave, sample_lens, tg, tl, tag
         # relative L2 like for like: against the oracle head in the plan's own arithmetic class (f32 lattice), as in every other unit;
         # against the f64 lattice the figure is the f32 lattice's own accuracy at T' = 801 (reported, not gated: torch's is the same)
         report["head"]["glogits_rel_l2_vs_f64_oracle_rounded"] = rel_l2(glogits_gpu, E.rb(x))
-        note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(rh["glogits"].float())))
+        note("head", "grad_act", "glogits", rel_l2(glogits_gpu, E.rb(rh["glogits"].float())), gate=tol.get("grad_act_lean_glogits"))
     else:
         note("head", "grad_act", "glogits", rel_l2(glogits_gpu, rh["glogits"]))
     note("head", "grad_act", "dx", rel_l2(_bct(units["last_cnn2"]["g_prev"][:N * 1024].view(B, T, 1024)), rh["dx"]))

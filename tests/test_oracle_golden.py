@@ -169,3 +169,36 @@ def test_bf16_oracle_without_rounding_is_the_pinned_oracle(variant):
     eb = E.Bf16OracleModel(variant, 28, state=R.formula_state(variant, 28), dtype=torch.float64, emulate=True)
     l2, _, lp2, _ = E.loss_and_grads(eb, x, tg, pct, tsz)
     assert abs(l2 - l1) / abs(l1) < 5e-3
+
+
+@pytest.mark.parametrize("L", [193, 1000, 16000 + 37, 160000, 255999])
+def test_mel_restatement_has_an_independent_second_leg(L):
+    """The log-mel front-end is UNPINNED (torchaudio 0.8.1 absent, the reference holds no vectors: DESIGN 2).  What can be had: two
+    restatements that share nothing - oracle/ref_cpu.py (torch.stft) and oracle/mel_numpy.py (frames cut by hand with explicit
+    reflect indices, numpy rfft, per-corner triangular filters; written from torchaudio 0.8.1's documented Spectrogram / MelScale /
+    AmplitudeToDB with the arguments of /root/reference/data_module.py:68-71, chain of :150-174) - agree (a) to f64 round-off when
+    both use the first one's f32-rounded window / filter tables, (b) to the tables' f32 round-off (1e-5 of the filter weights,
+    2e-5 of the feature scale) when each builds its own, at the BASELINE clip lengths (10 s = 160 000 samples, 16 s)."""
+    from oracle import mel_numpy as M
+    g = torch.Generator().manual_seed(L)
+    y = 0.1 * torch.randn(1, L, generator=g, dtype=torch.float64)
+    noise = torch.randn(1, L, generator=g, dtype=torch.float64)
+    win32 = R.hann_window_padded().double().numpy()[96:96 + 320]
+    fb32 = R.mel_filterbank().double().numpy()
+    assert np.abs(win32 - M.hann_periodic(320)).max() < 1e-7 and np.abs(R.hann_window_padded().numpy()[:96]).max() == 0
+    assert np.abs(fb32 - M.filterbank()).max() < 1e-5
+    assert ((fb32 > 0) == (M.filterbank() > 1e-6)).mean() > 0.999          # same support (up to bins sitting on a corner)
+    # (a) power mel spectrum and the whole chain on shared tables: f64 round-off
+    yp = R.preemphasis(y + 1e-5 * noise)
+    a = R.mel_power(yp)[0].numpy()
+    b = (M.power_spectrum(yp[0].numpy(), win32) @ fb32).T
+    assert a.shape == b.shape == (64, R.num_frames(L))
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
+    crop = (0.3, 0.7) if L > 4000 else None
+    aug = (5, 11, 3, min(7, a.shape[1] - 4)) if a.shape[1] > 8 else None
+    fa = R.parse_wave(y, noise, aug, crop=crop)[0].numpy()
+    fb_ = M.parse_wave(y[0].numpy(), noise[0].numpy(), aug, crop=crop, window=win32, fb=fb32)
+    assert fa.shape == fb_.shape and np.abs(fa - fb_).max() < 1e-9
+    # (b) each with its own tables
+    fc = M.parse_wave(y[0].numpy(), noise[0].numpy(), aug, crop=crop)
+    assert np.abs(fa - fc).max() < 3e-5 * np.abs(fa).max()
