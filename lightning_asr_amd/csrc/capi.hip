@@ -1,5 +1,6 @@
 // Error state and version of the C ABI (include/lasr.h).
 #include "common.h"
+#include "host_io.h"
 
 namespace lasr {
 static thread_local char g_err[512] = "";
@@ -117,17 +118,5 @@ extern "C" int lasr_prof_overhead_ms(void* stream, int n, double* ms_per_pair) {
 // ---- host-side Levenshtein distance on token-id sequences (WER/CER: utils/asr_metrics.py:54,220
 // call editdistance.eval on word / character lists; the host maps words to ids first) -------------
 extern "C" int64_t lasr_edit_distance(const int32_t* a, int64_t na, const int32_t* b, int64_t nb) {
-  if (na < 0 || nb < 0 || (na > 0 && !a) || (nb > 0 && !b)) return -1;
-  std::vector<int64_t> prev((size_t)nb + 1), cur((size_t)nb + 1);
-  for (int64_t j = 0; j <= nb; ++j) prev[(size_t)j] = j;
-  for (int64_t i = 1; i <= na; ++i) {
-    cur[0] = i;
-    for (int64_t j = 1; j <= nb; ++j) {
-      const int64_t sub = prev[(size_t)j - 1] + (a[i - 1] != b[j - 1]);
-      const int64_t del = prev[(size_t)j] + 1, ins = cur[(size_t)j - 1] + 1;
-      cur[(size_t)j] = sub < del ? (sub < ins ? sub : ins) : (del < ins ? del : ins);
-    }
-    prev.swap(cur);
-  }
-  return prev[(size_t)nb];
+  return lasr::host::edit_distance(a, na, b, nb);      // host_io.h (also built under ASan / UBSan by the CPU test tier)
 }
