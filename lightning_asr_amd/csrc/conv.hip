@@ -1130,6 +1130,19 @@ __global__ __launch_bounds__(512, 1) void dwconv_bwd_s1_mfma_kernel(DwBwd a) {
 // so dy crosses HBM and the staging once, the tap tables are built once per workgroup, and (C/CB) x B x gz workgroups make one round.
 // NW = waves per workgroup = channel octets: 8 (64 channels, whole 128-byte rows, one workgroup per CU) or 4 (32 channels,
 // two workgroups per CU).  The next tile's global loads are issued before the MFMA phases of the current one.
+// v_mov_b32 dpp row_shl:n - lane i of every 16-lane row takes the value of lane i + n of that row, lanes past the row's end read zero
+// (bound_ctrl).  n is a compile-time constant after unrolling (the DPP control is an immediate).
+__device__ __forceinline__ uint32_t dpp_row_shl(uint32_t v, int n) {
+  switch (n) {
+    case 0: return v;
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true);
+    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);
+    case 6: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x106, 0xf, 0xf, true);
+    case 8: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xf, 0xf, true);
+    default: __builtin_unreachable();
+  }
+}
+
 namespace dwu {
 static constexpr int TT = 256;            // frames per tile
 static constexpr int FR = 384;            // staged frames per image and tile
@@ -1301,6 +1314,39 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
       const uint32_t shft = (e0 & 1) * 16;
       const uint32_t* arow = reinterpret_cast<const uint32_t*>(dimg + cl * LDI) + (e0 >> 1);
       const char* brow = ximg + cl * LDI + (16 * n16 + 8 * g4) * 2;
+#ifndef LASR_DW_NO_BFRAG_DPP
+      // B[u][n] = X[u + 16 n]: the fragment of K step ks + s is the fragment of step ks moved by 2 s COLUMNS (32 u values = two 16-frame
+      // column strides), and a column is a lane of the 16-lane DPP row.  Only NC = ceil((k + sh) / 16) <= 7 of the 16 columns carry
+      // taps, so ONE 16-byte LDS read serves five K steps (columns 2 s .. 2 s + 6 <= 14), the other four as `v_mov_b32 dpp row_shl:2s`
+      // (lane i <- lane i + 2 s; lanes shifted in from outside the row read as zero - columns without taps): two B reads per channel
+      // and tile instead of nine.  The phase is bound by the LDS bandwidth of its operand reads (section 4): 36 -> 23.6 bytes per
+      // lane and MFMA.
+      const uint4 bL0 = *reinterpret_cast<const uint4*>(brow);
+      const uint4 bL5 = *reinterpret_cast<const uint4*>(brow + 64 * 5);
+#pragma unroll
+      for (int kb = 0; kb < 9; kb += 3) {
+        uint32_t wa[3][5];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) wa[j][i] = arow[16 * (kb + j) + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (kb + j < nku) {                            // workgroup-uniform
+            union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[j][i + 1], wa[j][i], shft);
+            const int ks = kb + j;
+            const uint4 base = ks < 5 ? bL0 : bL5;
+            const int sft = 2 * (ks < 5 ? ks : ks - 5);
+            bf.u[0] = dpp_row_shl(base.x, sft); bf.u[1] = dpp_row_shl(base.y, sft);
+            bf.u[2] = dpp_row_shl(base.z, sft); bf.u[3] = dpp_row_shl(base.w, sft);
+            accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
+          }
+        }
+      }
+#else
 #pragma unroll
       for (int kb = 0; kb < 9; kb += 3) {
         uint32_t wa[3][5];
@@ -1322,6 +1368,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
           }
         }
       }
+#endif
     }
     if (q == bz) DW_STAMP(3);
     // ---- phase 2b: data gradient of the tile's 256 frames, NKS K steps per channel ----------------------------------------

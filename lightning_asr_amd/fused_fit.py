@@ -96,6 +96,7 @@ class NativeSource:
         self.producer = BatchProducer(dataset, index_batches, self.ring, mask, audio_parser, n_threads=n_threads, crop=crop,
                                       feeder=self.feeder)
         self.mask = mask
+        self.n_threads = n_threads
         self.n = len(index_batches)
 
     def __iter__(self):
@@ -119,11 +120,30 @@ class NativeSource:
         self.feeder.close()
 
 
+def ingest_threads_for_rank(requested: int) -> int:
+    """host threads of this rank's wav reader: `data.num_worker` (conf/conf.yaml:14: 6 DataLoader workers PER RANK in the reference),
+    capped by this rank's share of the cores the process may run on - cores / ranks on this node, minus one for the thread that
+    enqueues the step - so that 8 ranks x (1 + num_worker) threads never oversubscribe a small host.  An explicit
+    LASR_INGEST_THREADS is taken as given.  LASR_PIN_RANKS=1 additionally pins the rank (all its threads) to its contiguous share of
+    the allowed cores - off by default: the right cores are the ones next to the rank's GPU, which only the site's topology knows."""
+    if os.environ.get("LASR_INGEST_THREADS") is not None:
+        return max(1, int(os.environ["LASR_INGEST_THREADS"]))
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    share = max(1, len(allowed) // local_world)
+    if os.environ.get("LASR_PIN_RANKS") == "1" and local_world > 1 and hasattr(os, "sched_setaffinity"):
+        lr = int(os.environ.get("LOCAL_RANK", "0")) % local_world
+        os.sched_setaffinity(0, allowed[lr * share:(lr + 1) * share])
+    return max(1, min(max(1, int(requested or 0)), max(2, share - 1)))
+
+
 def make_source(datamodule, loader, device, mask: bool, limit: int, max_seconds: float, batch_size: int, crop: Optional[bool] = None):
     ds = loader.dataset
     if fast_ingest_ok(ds) and os.environ.get("LASR_NATIVE_INGEST", "1") != "0":
-        n_threads = max(1, int(getattr(datamodule, "num_worker", 0) or 0)) if os.environ.get("LASR_INGEST_THREADS") is None \
-            else int(os.environ["LASR_INGEST_THREADS"])
+        n_threads = ingest_threads_for_rank(int(getattr(datamodule, "num_worker", 0) or 0))
         return NativeSource(ds, loader.batch_sampler, datamodule.audio_parser, device, batch_size, max_seconds, mask,
                             n_threads=max(n_threads, 1), limit=limit, crop=crop)
     return HostWaveSource(loader, device, limit)
@@ -279,6 +299,7 @@ class FusedLoop:
         src = make_source(dm, loader, self.native.device, True, n_batches, getattr(dm, "train_max_duration", 16.7) or 16.7,
                           getattr(dm, "train_bs", 32), crop=getattr(dm, "train_crop", True))
         self.source_kind = type(src).__name__
+        self.ingest_threads = getattr(src, "n_threads", None)
         self._pf = None
         window = deque()
         it = iter(src)
