@@ -1305,6 +1305,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
 
     // ---- phase 2a: weight gradient, 8 (9 on the last tile) K steps of 32 u values per channel ---------------------------
     const int nku = last ? 9 : 8;
+    (void)nku;
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
       const int cl = wid * 8 + ch;
@@ -1317,33 +1318,31 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
 #ifndef LASR_DW_NO_BFRAG_DPP
       // B[u][n] = X[u + 16 n]: the fragment of K step ks + s is the fragment of step ks moved by 2 s COLUMNS (32 u values = two 16-frame
       // column strides), and a column is a lane of the 16-lane DPP row.  Only NC = ceil((k + sh) / 16) <= 7 of the 16 columns carry
-      // taps, so ONE 16-byte LDS read serves five K steps (columns 2 s .. 2 s + 6 <= 14), the other four as `v_mov_b32 dpp row_shl:2s`
-      // (lane i <- lane i + 2 s; lanes shifted in from outside the row read as zero - columns without taps): two B reads per channel
-      // and tile instead of nine.  The phase is bound by the LDS bandwidth of its operand reads (section 4): 36 -> 23.6 bytes per
-      // lane and MFMA.
+      // taps, so ONE 16-byte LDS read serves up to five K steps (columns 2 s .. 2 s + 6 <= 14), the others as `v_mov_b32 dpp
+      // row_shl:2s` (lane i <- lane i + 2 s; lanes shifted in from outside the row read as zero - columns without taps): two B reads
+      // per channel and tile instead of eight.
+      // The eight K steps every tile has run WITHOUT a branch (the ninth - u in [tA + 256, tA + 288), the utterance's last tile only -
+      // follows behind the channel loop): a workgroup-uniform `if` inside this loop had cut it into one basic block per channel,
+      // i.e. every channel began with an exposed LDS round trip for its first fragments (round 5, read off the ISA).
       const uint4 bL0 = *reinterpret_cast<const uint4*>(brow);
-      const uint4 bL5 = *reinterpret_cast<const uint4*>(brow + 64 * 5);
+      const uint4 bL4 = *reinterpret_cast<const uint4*>(brow + 64 * 4);
 #pragma unroll
-      for (int kb = 0; kb < 9; kb += 3) {
-        uint32_t wa[3][5];
+      for (int kb = 0; kb < 8; kb += 4) {
+        uint32_t wa[4][5];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
           for (int i = 0; i < 5; ++i) wa[j][i] = arow[16 * (kb + j) + i];
         }
+        const uint4 base = kb == 0 ? bL0 : bL4;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if (kb + j < nku) {                            // workgroup-uniform
-            union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+        for (int j = 0; j < 4; ++j) {
+          union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[j][i + 1], wa[j][i], shft);
-            const int ks = kb + j;
-            const uint4 base = ks < 5 ? bL0 : bL5;
-            const int sft = 2 * (ks < 5 ? ks : ks - 5);
-            bf.u[0] = dpp_row_shl(base.x, sft); bf.u[1] = dpp_row_shl(base.y, sft);
-            bf.u[2] = dpp_row_shl(base.z, sft); bf.u[3] = dpp_row_shl(base.w, sft);
-            accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
-          }
+          for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[j][i + 1], wa[j][i], shft);
+          bf.u[0] = dpp_row_shl(base.x, 2 * j); bf.u[1] = dpp_row_shl(base.y, 2 * j);
+          bf.u[2] = dpp_row_shl(base.z, 2 * j); bf.u[3] = dpp_row_shl(base.w, 2 * j);
+          accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
         }
       }
 #else
@@ -1370,6 +1369,26 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
       }
 #endif
     }
+#ifndef LASR_DW_NO_BFRAG_DPP
+    if (last) {                                          // workgroup-uniform: the ninth K step of the utterance's last tile
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        const int cl = wid * 8 + ch;
+        const int e0 = P + 8 * g4 - n16;
+        const uint32_t shft = (e0 & 1) * 16;
+        const uint32_t* arow = reinterpret_cast<const uint32_t*>(dimg + cl * LDI) + (e0 >> 1) + 16 * 8;
+        const uint4 bb = *reinterpret_cast<const uint4*>(ximg + cl * LDI + (16 * n16 + 8 * g4) * 2 + 64 * 8);
+        uint32_t wa[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wa[i] = arow[i];
+        union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[i + 1], wa[i], shft);
+        bf.u[0] = bb.x; bf.u[1] = bb.y; bf.u[2] = bb.z; bf.u[3] = bb.w;
+        accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
+      }
+    }
+#endif
     if (q == bz) DW_STAMP(3);
     // ---- phase 2b: data gradient of the tile's 256 frames, NKS K steps per channel ----------------------------------------
     dw_f32x4 accd[8];
