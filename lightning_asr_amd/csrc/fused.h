@@ -48,6 +48,12 @@ int mask_lengths_step_cast(const float* pct, int64_t B, int64_t T_, int32_t* len
 int head_tail(const float* gl, int64_t rows, int64_t C, void* gl_bf16, int64_t ld_out, float* bias_grad, void* workspace,
               size_t workspace_bytes, const float* nll, int64_t n_nll, float scale, float* loss, void* stream);
 
+// se.hip (round 5): the excite MLP (lasr_se_fwd's two launches) inside the BN + SE + residual add + activation pass, dealt over
+// (64-channel slab x utterance) workgroups that each recompute their utterance's hidden vector; bit-identical to the three launches.
+// 0 = launched, 1 = not taken (f32, dropout, odd shapes: the caller runs lasr_se_fwd + lasr_bn_act_fwd), negative = error
+int bn_se_act_fwd(const void* y, const float* coef, const void* y2, const float* coef2, const float* sums, const float* W1, const float* W2,
+                  void* out, float* pooled, float* hidden, float* scale, int dtype, int64_t B, int64_t T_, int64_t C, int act, void* stream);
+
 // ctc.hip: the decoder GEMM's split-K reduction (+ bias) and lasr_log_softmax in one launch, for C <= 64 (log_softmax_split_on)
 bool log_softmax_split_on(int64_t C);
 int log_softmax_split(const float* partials, int split, const float* bias, float* logits, float* logp, int32_t* argmax, int64_t N, int64_t C,

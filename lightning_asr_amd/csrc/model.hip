@@ -664,11 +664,20 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
         }
       }
     }
+    bool se_applied = false;
     if (u.has_se) {  // squeeze over all T' frames of BN(y) (affine in the per-utterance sums of y), excite MLP
       ProfScope ps_se(LASR_PROF_BN, stream, (double)N * u.co * dtype_size(dt));
       if (!se_sums_done) LASR_TRY(lasr_seqsum(at(ws, u.o_y), dt, B, T, u.co, atf(ws, u.o_se_sum), stream));
-      LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
-                           atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), stream));
+      int folded = 1;
+      if (training && !dropping && !no_fuse())   // round 5: the excite MLP inside the apply pass (one launch instead of three)
+        folded = bn_se_act_fwd(at(ws, u.o_y), atf(ws, u.o_coef), u.has_res ? at(ws, u.o_y2) : nullptr, u.has_res ? atf(ws, u.o_coef2) : nullptr,
+                               atf(ws, u.o_se_sum), params + u.w_se1, params + u.w_se2, at(ws, u.o_out), atf(ws, u.o_se_pool),
+                               atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), dt, B, T, u.co, u.act ? m->cfg.act : LASR_ACT_NONE, stream);
+      if (folded < 0 || folded > 1) return folded;
+      se_applied = folded == 0;
+      if (!se_applied)
+        LASR_TRY(lasr_se_fwd(atf(ws, u.o_se_sum), atf(ws, u.o_coef), params + u.w_se1, params + u.w_se2, B, T, u.co, atf(ws, u.o_se_pool),
+                             atf(ws, u.o_se_hid), atf(ws, u.o_se_scale), stream));
     }
     // BN + residual add + activation: by the next unit's depthwise launch when that is a stride-1 bf16 depthwise conv reading this
     // unit's output directly (training; no SE scale, no dropout mask in between), otherwise here
@@ -676,7 +685,7 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
     if (bn_dw_fuse && training && !no_fuse() && dt == LASR_BF16 && !u.has_se && !dropping && nx && nx->has_dw && nx->stride == 1 &&
         !nx->ctx_before && nx->ci == u.co)
       pend = &u;
-    else
+    else if (!se_applied)
       LASR_TRY(bn_act_of(u));
     x = at(ws, u.o_out);
     Tx = T;

@@ -7,6 +7,8 @@
 #include "common.h"
 #include "se_seqsum.h"
 #include "dropout.h"
+#include "fused.h"
+#include <algorithm>
 
 namespace lasr {
 
@@ -189,6 +191,158 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__
   float acc = 0.f;
   for (int h = 0; h < H; ++h) acc = fmaf(s_w2[cl * (H + 1) + h], s_hid[bl * H + h], acc);
   if (c0 + cl < C && b0 + bl < B) scale[(size_t)(b0 + bl) * C + c0 + cl] = 1.f / (1.f + expf(-acc));
+}
+
+// ---- the whole excite path INSIDE the BN + SE + add + activation pass (round 5) -----------------------------------------------
+// The SE forward chain of a unit was four launches behind its GEMM: finalize + squeeze | hidden | scale | apply, the middle two at the
+// launch floor (5.7 + 4.8 us, 15 units: 0.16 ms of a 3.05 ms cfg4 step) because hidden needs ALL channels of an utterance and scale
+// ALL hidden units - grid-wide dependencies when the work is dealt over (outputs x utterances).  Dealt over (64-channel slab x
+// utterance) instead - the grid the apply pass wants anyway - a workgroup can close both dependencies by itself at the price of
+// redundancy: it recomputes its utterance's whole hidden vector (H x C MACs: 32 K at C = 512; W1 = 128 KB out of L2, 8 slabs x 32
+// utterances = 32 MB per launch) and then needs only its own 64 rows of W2.  Same arithmetic in the same order as se_hidden_kernel /
+// se_scale_kernel / bn_act_fwd_kernel (lane-strided fmaf chain + wave_sum; sequential fmaf over h; fmaf(y, a, b) * scale + ...), so the
+// results are bit-identical to the three launches (tests/test_gpu_switches.py, LASR_SE_FWD_FOLD=0).
+//   grid (C / 64, B, ts), block 256;  ts time lanes share an utterance when (C / 64) x B alone would leave CUs idle (C = 256).
+// Slab 0 / time lane 0 of every utterance also stores pooled, hidden (the backward reads them); every slab its 64 scales.
+template <bool HAS2>
+__global__ __launch_bounds__(256) void bn_se_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ coef,
+                                                            const bf16_t* __restrict__ y2, const float* __restrict__ coef2,
+                                                            const float* __restrict__ sums, const float* __restrict__ W1,
+                                                            const float* __restrict__ W2, bf16_t* __restrict__ out,
+                                                            float* __restrict__ pooled, float* __restrict__ hidden,
+                                                            float* __restrict__ scale, int Tt, int C, int H, float inv_T, int act_rt) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // pool[C] | hid[H] | w2[64][H + 1] | scale[64]
+  float* s_pool = sm;
+  float* s_hid = sm + C;
+  float* s_w2 = s_hid + H;
+  float* s_scale = s_w2 + 64 * (H + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int c0 = blockIdx.x * 64, b = blockIdx.y, tz = blockIdx.z, nz = gridDim.z;
+  const bool keeper = blockIdx.x == 0 && tz == 0;               // workgroup-uniform
+  // the slab's first rows are requested before anything else: they travel under the excite arithmetic
+  const int cl8 = (tid & 7) * 8, rl = tid >> 3;                  // lane's channel octet inside the slab, row lane (32 rows per pass)
+  const int tlo = (int)(((int64_t)Tt * tz) / nz), thi = (int)(((int64_t)Tt * (tz + 1)) / nz);
+  const bf16_t* yb = y + ((size_t)b * Tt) * C + c0 + cl8;
+  const bf16_t* y2b = HAS2 ? y2 + ((size_t)b * Tt) * C + c0 + cl8 : nullptr;
+  bf16_t* ob = out + ((size_t)b * Tt) * C + c0 + cl8;
+  uint4 rv[2], rw[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = min(tlo + rl + 32 * u, thi - 1);
+    rv[u] = Vec<bf16_t>::raw(yb + (size_t)t * C);
+    if (HAS2) rw[u] = Vec<bf16_t>::raw(y2b + (size_t)t * C);
+  }
+  // this slab's rows of W2 -> LDS (pitch H + 1), all loads of a round first
+  for (int base = 0; base < 64 * H; base += 8 * 256) {
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = W2[min((size_t)c0 * H + base + u * 256 + tid, (size_t)C * H - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + tid;
+      if (i < 64 * H) { const int cl = i / H, h = i - cl * H; s_w2[cl * (H + 1) + h] = wv[u]; }
+    }
+  }
+  // pooled = a * (sum_t y / T) + b for every channel of the utterance (se_hidden_kernel's expression)
+  for (int c = tid; c < C; c += 256) {
+    const float pv = fmaf(coef[c], sums[(size_t)b * C + c] * inv_T, coef[C + c]);
+    s_pool[c] = pv;
+    if (keeper) pooled[(size_t)b * C + c] = pv;
+  }
+  __syncthreads();
+  // hidden[h] = relu(W1[h] . pooled): wave w takes rows h = w, w + 4, ...; lane-strided fmaf chain, then the wave sum (four rows'
+  // loads in flight)
+  for (int h0 = wid * 4; h0 < H; h0 += 16) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < C; c += 64) {
+      const float pv = s_pool[c];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = W1[(size_t)min(h0 + u, H - 1) * C + c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fmaf(w[u], pv, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = fmaxf(wave_sum(acc[u]), 0.f);
+      if (lane == 0 && h0 + u < H) {
+        s_hid[h0 + u] = v;
+        if (keeper) hidden[(size_t)b * H + h0 + u] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {                                               // scale of the slab's channels (se_scale_kernel's chain)
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc = fmaf(s_w2[tid * (H + 1) + h], s_hid[h], acc);
+    const float sc = 1.f / (1.f + expf(-acc));
+    s_scale[tid] = sc;
+    if (tz == 0) scale[(size_t)b * C + c0 + tid] = sc;
+  }
+  __syncthreads();
+  // per-lane constants of its channel octet
+  float a[8], bb[8], a2[8], b2[8], sc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = coef[c0 + cl8 + j]; bb[j] = coef[C + c0 + cl8 + j]; sc[j] = s_scale[cl8 + j];
+    a2[j] = HAS2 ? coef2[c0 + cl8 + j] : 0.f; b2[j] = HAS2 ? coef2[C + c0 + cl8 + j] : 0.f;
+  }
+  with_act(act_rt, [&](auto act_c) {
+    constexpr int act = decltype(act_c)::value;
+    for (int t0 = tlo + rl; t0 < thi; t0 += 64) {
+      // the rows after these two are requested before these are worked on
+      uint4 nv[2], nw[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = min(t0 + 64 + 32 * u, thi - 1);
+        nv[u] = Vec<bf16_t>::raw(yb + (size_t)t * C);
+        if (HAS2) nw[u] = Vec<bf16_t>::raw(y2b + (size_t)t * C);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t0 + 32 * u;
+        float v[8], w[8], o[8];
+        Vec<bf16_t>::unpack(rv[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o[j] = fmaf(v[j], a[j], bb[j]); o[j] *= sc[j]; }
+        if (HAS2) {
+          Vec<bf16_t>::unpack(rw[u], w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += fmaf(w[j], a2[j], b2[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = act_fwd(o[j], act);
+        if (t < thi) Vec<bf16_t>::store(ob + (size_t)t * C, o);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { rv[u] = nv[u]; if (HAS2) rw[u] = nw[u]; }
+    }
+  });
+}
+
+// out = act((a y + b) * sigmoid(W2 relu(W1 (a mean_T(y) + b))) [+ a2 y2 + b2]) with pooled / hidden / scale left for the backward:
+// the excite MLP of lasr_se_fwd and lasr_bn_act_fwd(se_scale) in one launch.  0 = launched, 1 = this shape / dtype keeps the three
+// launches (nothing was launched), negative = error.
+int bn_se_act_fwd(const void* y, const float* coef, const void* y2, const float* coef2, const float* sums, const float* W1, const float* W2,
+                  void* out, float* pooled, float* hidden, float* scale, int dtype, int64_t B, int64_t T_, int64_t C, int act, void* stream) {
+  static const bool off = getenv("LASR_SE_FWD_FOLD") && atoi(getenv("LASR_SE_FWD_FOLD")) == 0;
+  const int64_t H = C / 8;
+  const size_t smem = (size_t)(C + H + 64 * (H + 1) + 64) * sizeof(float);
+  if (off || dtype != LASR_BF16 || C % 64 != 0 || C < 64 || C > 4096 || smem > 64 * 1024 || B >= 65536 || T_ < 1 || T_ >= (1 << 30) ||
+      reinterpret_cast<uintptr_t>(y) % 16 || reinterpret_cast<uintptr_t>(out) % 16 || (y2 && reinterpret_cast<uintptr_t>(y2) % 16))
+    return 1;
+  LASR_CHECK_ARG(y && coef && sums && W1 && W2 && out && pooled && hidden && scale && (!y2 || coef2), "bn_se_act_fwd: null pointer");
+  const int64_t wgs = (C / 64) * B;
+  const unsigned ts = wgs >= 256 ? 1u : (unsigned)std::min<int64_t>(std::max<int64_t>(256 / std::max<int64_t>(wgs, 1), 1), 4);
+  const dim3 grid((unsigned)(C / 64), (unsigned)B, ts);
+  if (y2)
+    hipLaunchKernelGGL(bn_se_act_fwd_kernel<true>, grid, dim3(256), smem, as_stream(stream), (const bf16_t*)y, coef, (const bf16_t*)y2, coef2, sums,
+                       W1, W2, (bf16_t*)out, pooled, hidden, scale, (int)T_, (int)C, (int)H, 1.0f / (float)T_, act);
+  else
+    hipLaunchKernelGGL(bn_se_act_fwd_kernel<false>, grid, dim3(256), smem, as_stream(stream), (const bf16_t*)y, coef, (const bf16_t*)nullptr,
+                       (const float*)nullptr, sums, W1, W2, (bf16_t*)out, pooled, hidden, scale, (int)T_, (int)C, (int)H, 1.0f / (float)T_, act);
+  LASR_LAUNCH_CHECK("bn_se_act_fwd_kernel");
+  return 0;
 }
 
 // ---- excite MLP, backward, for the whole batch -----------------------------------------------------------------------------

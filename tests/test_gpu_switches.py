@@ -106,6 +106,10 @@ def test_context_se_switches(dev):
     # the SE squeeze's column sums inside the BN finalize launch (default) against the two launches: the same numbers
     two = _run({"LASR_SE_SEQSUM_IN_FINALIZE": "0"}, variant="context_se")
     assert two == base, (two, base)
+    # round 5: the excite MLP inside the BN + SE + add + activation pass (one launch, every workgroup recomputing its utterance's hidden
+    # vector) against lasr_se_fwd's two launches + the apply pass: the same arithmetic in the same order - the same numbers
+    three = _run({"LASR_SE_FWD_FOLD": "0"}, variant="context_se")
+    assert three == base, (three, base)
     sep = _run({"LASR_LSTM_BESIDE_WGRAD": "0"}, variant="context_se")
     _close(sep, base, "LASR_LSTM_BESIDE_WGRAD=0")
     # the recurrence's arithmetic is the same code (lstm_body.h): the forward is untouched and the loss identical; the gradients
