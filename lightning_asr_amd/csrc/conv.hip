@@ -1306,46 +1306,88 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
     // ---- phase 2a: weight gradient, 8 (9 on the last tile) K steps of 32 u values per channel ---------------------------
     const int nku = last ? 9 : 8;
     (void)nku;
+#ifndef LASR_DW_NO_BFRAG_DPP
+    {
+      // Round 5, read off the phase stamps and the ISA: the phase took 4.7 us per tile whatever its LDS byte count was (36 or 24 bytes
+      // per lane and MFMA: same time) - 156 cycles per MFMA: every K step's fragments were requested right before the step that used
+      // them, i.e. every MFMA waited for an LDS round trip under the load of eight waves.  Now the 64 steps of a tile (8 channels x 8 K
+      // steps; the ninth K step of the utterance's last tile follows behind) form ONE software pipeline: the Toeplitz (A) fragments
+      // travel kDA steps ahead through a register ring, a channel pair's two B reads one pair ahead, and consecutive MFMAs alternate
+      // between the two channels of a pair (no MFMA waits for its predecessor's accumulator).
+      //   A[m][u] = dY[u - m]: elements e .. e+7 of the D image, e = P + 32 ks + 8 g4 - m (m = n16): five dwords from floor(e/2) and
+      //   a funnel shift by 16 bits for the odd lanes.
+      //   B[u][n] = X[u + 16 n]: the fragment of K step ks + s is the fragment of step ks moved by 2 s COLUMNS (32 u values = two
+      //   16-frame column strides), and a column is a lane of the 16-lane DPP row.  Only NC = ceil((k + sh) / 16) <= 7 of the 16
+      //   columns carry taps, so ONE 16-byte LDS read serves four K steps (columns 2 s .. 2 s + 6 <= 12), the others as `v_mov_b32
+      //   dpp row_shl:2s` (lane i <- lane i + 2 s; lanes shifted in from outside the row read as zero - columns without taps).
+      constexpr int kDA = 4, NST = 64;
+      const int e0 = P + 8 * g4 - n16;
+      const uint32_t shft = (e0 & 1) * 16;
+      const uint32_t* abase = reinterpret_cast<const uint32_t*>(dimg + wid * 8 * LDI) + (e0 >> 1);
+      const char* bbase = ximg + wid * 8 * LDI + (16 * n16 + 8 * g4) * 2;
+      // step i -> (channel, K step): pairs of channels, the two channels of a pair alternate
+      auto ch_of = [](int i) { return 2 * (i >> 4) + (i & 1); };
+      auto ks_of = [](int i) { return (i >> 1) & 7; };
+      uint32_t wa[kDA][5];
+      uint4 bq[2][2][2];                                   // [pair parity][channel of the pair][K steps 0-3 | 4-7]
+      auto issue_a = [&](int i, uint32_t (&dst)[5]) {
+        const uint32_t* ar = abase + ch_of(i) * (LDI / 4) + 16 * ks_of(i);
+#pragma unroll
+        for (int d = 0; d < 5; ++d) dst[d] = ar[d];
+      };
+      auto issue_b = [&](int pair, uint4 (&dst)[2][2]) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const char* br = bbase + (2 * pair + c2) * LDI;
+          dst[c2][0] = *reinterpret_cast<const uint4*>(br);
+          dst[c2][1] = *reinterpret_cast<const uint4*>(br + 64 * 4);
+        }
+      };
+      // (Also built: the NEXT tile's sixteen global loads - a 1.4 us burst in front of this phase, the CU's address path takes a
+      //  16-byte-per-lane load at 64 B per clock - dealt over this sequence, one every four steps.  The compiler would not have it: with
+      //  the loads' register arrays written from inside the unrolled sequence it either ran out of registers (16 address registers
+      //  kept alive across the sequence: 256 + spills) or demoted the arrays to scratch.  Not measured; the burst stays.)
+      issue_b(0, bq[0]);
+#pragma unroll
+      for (int i = 0; i < kDA; ++i) issue_a(i, wa[i]);
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        const int ch = ch_of(i), ks = ks_of(i), pair = i >> 4;
+        if ((i & 15) == 0 && pair + 1 < 4) issue_b(pair + 1, bq[(pair + 1) & 1]);
+        union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) af.u[d] = __builtin_amdgcn_alignbit(wa[i % kDA][d + 1], wa[i % kDA][d], shft);
+        if (i + kDA < NST) issue_a(i + kDA, wa[i % kDA]);
+        const uint4 base = bq[pair & 1][i & 1][ks >> 2];
+        const int sft = 2 * (ks & 3);
+        bf.u[0] = dpp_row_shl(base.x, sft); bf.u[1] = dpp_row_shl(base.y, sft);
+        bf.u[2] = dpp_row_shl(base.z, sft); bf.u[3] = dpp_row_shl(base.w, sft);
+        accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
+      }
+      if (last) {                                          // workgroup-uniform: the ninth K step of the utterance's last tile
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+          const uint32_t* ar = abase + ch * (LDI / 4) + 16 * 8;
+          const uint4 bb = *reinterpret_cast<const uint4*>(bbase + ch * LDI + 64 * 8);
+          uint32_t w9[5];
+#pragma unroll
+          for (int d = 0; d < 5; ++d) w9[d] = ar[d];
+          union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) af.u[d] = __builtin_amdgcn_alignbit(w9[d + 1], w9[d], shft);
+          bf.u[0] = bb.x; bf.u[1] = bb.y; bf.u[2] = bb.z; bf.u[3] = bb.w;
+          accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
       const int cl = wid * 8 + ch;
-      // A[m][u] = dY[u - m]: elements e .. e+7 of the D image, e = P + 32 ks + 8 g4 - m (m = n16): five dwords from floor(e/2)
-      // and a funnel shift by 16 bits for the odd lanes
       const int e0 = P + 8 * g4 - n16;
       const uint32_t shft = (e0 & 1) * 16;
       const uint32_t* arow = reinterpret_cast<const uint32_t*>(dimg + cl * LDI) + (e0 >> 1);
       const char* brow = ximg + cl * LDI + (16 * n16 + 8 * g4) * 2;
-#ifndef LASR_DW_NO_BFRAG_DPP
-      // B[u][n] = X[u + 16 n]: the fragment of K step ks + s is the fragment of step ks moved by 2 s COLUMNS (32 u values = two 16-frame
-      // column strides), and a column is a lane of the 16-lane DPP row.  Only NC = ceil((k + sh) / 16) <= 7 of the 16 columns carry
-      // taps, so ONE 16-byte LDS read serves up to five K steps (columns 2 s .. 2 s + 6 <= 14), the others as `v_mov_b32 dpp
-      // row_shl:2s` (lane i <- lane i + 2 s; lanes shifted in from outside the row read as zero - columns without taps): two B reads
-      // per channel and tile instead of eight.
-      // The eight K steps every tile has run WITHOUT a branch (the ninth - u in [tA + 256, tA + 288), the utterance's last tile only -
-      // follows behind the channel loop): a workgroup-uniform `if` inside this loop had cut it into one basic block per channel,
-      // i.e. every channel began with an exposed LDS round trip for its first fragments (round 5, read off the ISA).
-      const uint4 bL0 = *reinterpret_cast<const uint4*>(brow);
-      const uint4 bL4 = *reinterpret_cast<const uint4*>(brow + 64 * 4);
-#pragma unroll
-      for (int kb = 0; kb < 8; kb += 4) {
-        uint32_t wa[4][5];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-          for (int i = 0; i < 5; ++i) wa[j][i] = arow[16 * (kb + j) + i];
-        }
-        const uint4 base = kb == 0 ? bL0 : bL4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[j][i + 1], wa[j][i], shft);
-          bf.u[0] = dpp_row_shl(base.x, 2 * j); bf.u[1] = dpp_row_shl(base.y, 2 * j);
-          bf.u[2] = dpp_row_shl(base.z, 2 * j); bf.u[3] = dpp_row_shl(base.w, 2 * j);
-          accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
-        }
-      }
-#else
 #pragma unroll
       for (int kb = 0; kb < 9; kb += 3) {
         uint32_t wa[3][5];
@@ -1367,35 +1409,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
           }
         }
       }
-#endif
-    }
-#ifndef LASR_DW_NO_BFRAG_DPP
-    if (last) {                                          // workgroup-uniform: the ninth K step of the utterance's last tile
-#pragma unroll
-      for (int ch = 0; ch < 8; ++ch) {
-        const int cl = wid * 8 + ch;
-        const int e0 = P + 8 * g4 - n16;
-        const uint32_t shft = (e0 & 1) * 16;
-        const uint32_t* arow = reinterpret_cast<const uint32_t*>(dimg + cl * LDI) + (e0 >> 1) + 16 * 8;
-        const uint4 bb = *reinterpret_cast<const uint4*>(ximg + cl * LDI + (16 * n16 + 8 * g4) * 2 + 64 * 8);
-        uint32_t wa[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) wa[i] = arow[i];
-        union { uint32_t u[4]; dw_bf16x8 v; } af, bf;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af.u[i] = __builtin_amdgcn_alignbit(wa[i + 1], wa[i], shft);
-        bf.u[0] = bb.x; bf.u[1] = bb.y; bf.u[2] = bb.z; bf.u[3] = bb.w;
-        accw[ch] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf.v, accw[ch], 0, 0, 0);
-      }
     }
 #endif
     if (q == bz) DW_STAMP(3);
     // ---- phase 2b: data gradient of the tile's 256 frames, NKS K steps per channel ----------------------------------------
     dw_f32x4 accd[8];
 #pragma unroll
+    for (int ch = 0; ch < 8; ++ch) accd[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    // (round 5: the weight gradient's software pipeline applied here as well - fragments six steps ahead, MFMAs alternating over the
+    //  channels - was built and measured: this phase 1.40 -> 1.17 us per tile, but at 246 registers the allocator gave the weight
+    //  gradient's ring up: THAT phase went 3.62 -> 6.85 us and the kernel 28.4 -> 33.9 us in the step.  Left per channel.)
+#pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
       const int cl = wid * 8 + ch;
-      accd[ch] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
       const char* row = dimg + cl * LDI;
       const int s0 = 8 * g4 - n16 - sh + 24;
       const uint32_t* wrow = wsm + cl * WROW + ((s0 & 1) ? HALF + ((s0 - 1) >> 1) : (s0 >> 1));

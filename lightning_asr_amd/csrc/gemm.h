@@ -27,8 +27,13 @@ int launch_gemm_bf16_batch(const GemmArgs* g, const int* gz, int n, int dtype_c,
 int launch_gemm_bf16_dual(const GemmArgs& g, const void* A2, int64_t lda2, int64_t K1, const float* bias, int act, hipStream_t st);
 namespace lstm { struct BwdArgs; }
 // lstm_job (optional): the BiLSTM backward recurrences run in the same grid as lstm_wgs workgroups, ahead of the tiles (lstm_body.h)
+// riders (optional): reductions that are already complete when this launch is issued; the first *riders_taken of them are done by
+// extra workgroups of this launch on the CUs its one round of tiles leaves idle (reduce_body.h) - the caller reduces the rest
 int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job = nullptr,
-                           int lstm_wgs = 0);
+                           int lstm_wgs = 0, const lasr_reduce_desc* riders = nullptr, int n_riders = 0, int* riders_taken = nullptr);
+// gemm.hip: lasr_gemm_multi_split_partials with riders (above)
+int gemm_multi_split_partials_riders(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits,
+                                     const lasr_reduce_desc* riders, int n_riders, int* riders_taken, void* stream);
 // gemm.hip: lasr_gemm(split_k > 1, f32 result) without its final sum: the slabs stay at the head of `workspace`, [*splits][M*N] f32
 int gemm_split_partials_one(const void* A, const void* B, int dtype_ab, int64_t M, int64_t N, int64_t K, int transA, int transB, int split_k,
                             void* workspace, size_t workspace_bytes, int* splits, void* stream);

@@ -502,11 +502,17 @@ extern "C" int lasr_gemm_batch_split_partials(const lasr_gemm_problem* probs, in
 }
 
 static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,
-                            const lstm::BwdArgs* lstm_job, int lstm_wgs);
+                            const lstm::BwdArgs* lstm_job, int lstm_wgs, const lasr_reduce_desc* riders = nullptr, int n_riders = 0,
+                            int* riders_taken = nullptr);
 
 extern "C" int lasr_gemm_multi_split_partials(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs,
                                               int* splits, void* stream) {
   return multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, nullptr, 0);
+}
+
+int lasr::gemm_multi_split_partials_riders(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits,
+                                           const lasr_reduce_desc* riders, int n_riders, int* riders_taken, void* stream) {
+  return multi_split_impl(probs, n_probs, split_k, slabs, splits, stream, nullptr, 0, riders, n_riders, riders_taken);
 }
 
 int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* probs, int n_probs, int* n_taken, int split_k, float* const* slabs, int* splits,
@@ -547,7 +553,8 @@ int lasr::gemm_multi_split_partials_with_bilstm_bwd(const lasr_gemm_problem* pro
 }
 
 static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int split_k, float* const* slabs, int* splits, void* stream,
-                            const lstm::BwdArgs* lstm_job, int lstm_wgs) {
+                            const lstm::BwdArgs* lstm_job, int lstm_wgs, const lasr_reduce_desc* riders, int n_riders, int* riders_taken) {
+  if (riders_taken) *riders_taken = 0;
   LASR_CHECK_ARG(probs && slabs && splits && n_probs >= 1 && n_probs <= 32 && split_k >= 1 && split_k <= 1024,
                  "lasr_gemm_multi_split_partials: bad argument");
   GemmArgs g[32];
@@ -599,7 +606,7 @@ static int multi_split_impl(const lasr_gemm_problem* probs, int n_probs, int spl
   }
   const int tok = prof_begin(LASR_PROF_GEMM, st, fl, by);
   if (lstm_job && !big_tile) { prof_end(tok, st); return fail(LASR_E_SHAPE, "gemm + BiLSTM grid needs the 256-row tile form"); }
-  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st, lstm_job, lstm_wgs);
+  const int rc = launch_gemm_bf16_multi(g, gz, n_probs, big_tile, st, lstm_job, lstm_wgs, riders, n_riders, riders_taken);
   prof_end(tok, st);
   return rc;
 }

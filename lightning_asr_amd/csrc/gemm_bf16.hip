@@ -11,6 +11,7 @@
 //                  transpose), so no operand is ever transposed through HBM or VALU.
 // bf16 results leave through an LDS transpose so every global store is 16 B per lane.
 #include "gemm.h"
+#include "reduce_body.h"
 #include "lstm_body.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -464,7 +465,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Bf16Batch gb) {
 // launch is 16 K steps per workgroup between a prologue and a 32 MB partial-slab epilogue; batched, a stage needs
 // a third of the slices for the same number of workgroups, so slices are 3x longer and the slabs 3x smaller.
 static constexpr int kMaxMulti = 32;
-struct Bf16Multi { Bf16Args p[kMaxMulti]; int start[kMaxMulti + 1]; int n, total; };
+// riders (round 5): reductions of the stage that are already COMPLETE when the weight-gradient launch is issued (the depthwise
+// weight gradients' per-utterance partials, 64 MB of lasr_reduce_many's 123 MB at cfg2) run as n_rwg extra workgroups behind the tiles -
+// on the CUs the one round of tiles leaves idle (71 tiles x 3 slices = 213 of 256)
+static constexpr int kMaxRiders = 24;
+struct Bf16Multi { Bf16Args p[kMaxMulti]; int start[kMaxMulti + 1]; int n, total; lasr_reduce_desc rd[kMaxRiders]; int n_rd, n_rwg; };
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_multi_kernel(Bf16Multi gm) {
   const int lid_all = xcd_remap(blockIdx.x, gm.total);
@@ -882,6 +887,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dual_kernel(Bf16Batch gb) {
 // here for the last time, most of it cold; the slabs this launch WRITES are what the reduction right behind it reads
 template <bool NTL>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_big_multi_kernel(Bf16Multi gm) {
+  if ((int)blockIdx.x >= gm.total) {                      // workgroup-uniform: a rider workgroup (reduce_body.h)
+    const int r = blockIdx.x - gm.total;
+    for (int s = 0; s < gm.n_rd; ++s) {
+      const lasr_reduce_desc q = gm.rd[s];
+      for (int64_t i = (int64_t)r * big::NT + threadIdx.x; i < q.n; i += (int64_t)gm.n_rwg * big::NT) reduce_many_elem(q, i);
+    }
+    return;
+  }
   const int lid_all = xcd_remap(blockIdx.x, gm.total);
   int i = 0;
   while (i + 1 < gm.n && gm.start[i + 1] <= lid_all) ++i;   // workgroup-uniform scan of at most 32 entries
@@ -1029,9 +1042,12 @@ int launch_gemm_bf16_rowstat(const GemmArgs& g, float* row_stat, int32_t* row_ar
 }
 
 // n <= 32 split-K problems with f32 slab output, both operands row-contiguous ([K][M], [K][N]: weight gradients)
-int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job, int lstm_wgs) {
+int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_tile, hipStream_t st, const lstm::BwdArgs* lstm_job, int lstm_wgs,
+                           const lasr_reduce_desc* riders, int n_riders, int* riders_taken) {
   if (n < 1 || n > kMaxMulti) return fail(LASR_E_ARG, "lasr_gemm_multi_split_partials: 1..%d problems", kMaxMulti);
+  if (riders_taken) *riders_taken = 0;
   Bf16Multi m;
+  m.n_rd = 0; m.n_rwg = 0;
   bool vec = true;
   int total = 0;
   for (int i = 0; i < n; ++i) {
@@ -1060,8 +1076,26 @@ int launch_gemm_bf16_multi(const GemmArgs* g, const int* gz, int n, bool big_til
       LASR_LAUNCH_CHECK("gemm_bf16_big_multi_lstm_kernel");
       return 0;
     }
-    if (nt_loads_mask() & 8) hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<true>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
-    else hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<false>, dim3((unsigned)total), dim3(big::NT), 0, st, m);
+    // riders: as many of the offered (complete) reductions as the idle CUs can finish while the tiles run.  A rider workgroup streams
+    // at ~20 GB/s (one CU's share of what the memory system gives a streaming read), a tile slice takes ~1.7 us per K step of 64 + ~20 us
+    static const bool riders_off = getenv("LASR_WGRAD_RIDERS") && atoi(getenv("LASR_WGRAD_RIDERS")) == 0;
+    const int idle = 256 - total;
+    if (!riders_off && riders && riders_taken && n_riders > 0 && idle >= 8) {
+      int ksteps = 0;
+      for (int i = 0; i < n; ++i) ksteps = std::max(ksteps, (int)cdiv(m.p[i].k_per_split, 64));
+      double budget = (double)idle * 20e9 * ((double)ksteps * 1.7e-6 + 20e-6) * 0.8;
+      while (m.n_rd < n_riders && m.n_rd < kMaxRiders) {
+        const lasr_reduce_desc& q = riders[m.n_rd];
+        const double bytes = (double)q.n * (q.n_partials + 1) * sizeof(float);
+        if (bytes > budget) break;
+        budget -= bytes;
+        m.rd[m.n_rd++] = q;
+      }
+      if (m.n_rd > 0) { m.n_rwg = idle; *riders_taken = m.n_rd; }
+    }
+    for (int i = m.n_rd; i < kMaxRiders; ++i) m.rd[i] = lasr_reduce_desc{nullptr, nullptr, 0, 0};
+    if (nt_loads_mask() & 8) hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<true>, dim3((unsigned)(total + m.n_rwg)), dim3(big::NT), 0, st, m);
+    else hipLaunchKernelGGL(gemm_bf16_big_multi_kernel<false>, dim3((unsigned)(total + m.n_rwg)), dim3(big::NT), 0, st, m);
     LASR_LAUNCH_CHECK("gemm_bf16_big_multi_kernel");
     return 0;
   }

@@ -724,7 +724,13 @@ static int flush_wgrads(std::vector<lasr_gemm_problem>& probs, std::vector<float
                         void* stream) {
   const int split = wgrad_split();   // the cap the slabs were sized for; the library picks the slice count for its tile form
   int splits[32];
-  LASR_TRY(lasr_gemm_multi_split_partials(probs.data(), (int)probs.size(), split, slabs.data(), splits, stream));
+  // round 5: whatever `pending` holds at this point is complete (the depthwise weight gradients' per-utterance partials, the BiLSTM's) -
+  // the launch's one round of tiles leaves CUs idle (71 tiles x 3 slices = 213 of 256 at cfg2), and extra workgroups of the same launch
+  // do those reductions there; what they took leaves the list lasr_reduce_many gets (123 -> 59 MB at cfg2).  Same sums, same order.
+  int taken = 0;
+  LASR_TRY(gemm_multi_split_partials_riders(probs.data(), (int)probs.size(), split, slabs.data(), splits, pending.data(), (int)pending.size(),
+                                            &taken, stream));
+  if (taken > 0) pending.erase(pending.begin(), pending.begin() + taken);
   for (size_t i = 0; i < probs.size(); ++i)
     pending.push_back({slabs[i], reinterpret_cast<float*>(probs[i].C), probs[i].M * probs[i].N, splits[i]});
   probs.clear();

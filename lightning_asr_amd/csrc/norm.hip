@@ -3,6 +3,7 @@
 // Replaces models/QuartNet.py:33-37 (MaskCNN lengths, BatchNorm1d(eps=1e-3), ReLU) and :74-77
 // (residual add + ReLU), plus their autograd backward.  All statistics are f32.
 #include "common.h"
+#include "reduce_body.h"
 #include "se_seqsum.h"
 #include "fused.h"
 #include "dropout.h"
@@ -1452,18 +1453,7 @@ __global__ __launch_bounds__(256) void reduce_many_kernel(ReduceMany a) {
   const lasr_reduce_desc& q = a.d[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= q.n) return;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  for (int p = 0; p < q.n_partials; p += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const float x = q.partials[(int64_t)min(p + u, q.n_partials - 1) * q.n + i];
-      v[u] = p + u < q.n_partials ? x : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) { a0 += (double)v[u]; a1 += (double)v[u + 1]; a2 += (double)v[u + 2]; a3 += (double)v[u + 3]; }
-  }
-  q.out[i] = (float)((a0 + a1) + (a2 + a3));
+  reduce_many_elem(q, i);                                  // reduce_body.h
 }
 }  // namespace lasr
 

@@ -250,20 +250,29 @@ __global__ __launch_bounds__(256) void bn_se_act_fwd_kernel(const bf16_t* __rest
     if (keeper) pooled[(size_t)b * C + c] = pv;
   }
   __syncthreads();
-  // hidden[h] = relu(W1[h] . pooled): wave w takes rows h = w, w + 4, ...; lane-strided fmaf chain, then the wave sum (four rows'
-  // loads in flight)
-  for (int h0 = wid * 4; h0 < H; h0 += 16) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = lane; c < C; c += 64) {
-      const float pv = s_pool[c];
-      float w[4];
+  // hidden[h] = relu(W1[h] . pooled): wave w takes rows 8 w .. 8 w + 7 (+ 32, ...); lane-strided fmaf chain per row, then the wave sum.
+  //   ALL of a batch of 8 rows x 8 column steps = 64 loads are requested before the first is used (as a loop over c with four loads per
+  //   trip the prologue was 32 dependent L2 round trips: the fold measured 0.066 ms per cfg4 step SLOWER than the three launches)
+  for (int h0 = wid * 8; h0 < H; h0 += 32) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < C; cb += 512) {
+      float w[8][8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) w[u] = W1[(size_t)min(h0 + u, H - 1) * C + c];
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = fmaf(w[u], pv, acc[u]);
+        for (int i = 0; i < 8; ++i) w[u][i] = W1[(size_t)min(h0 + u, H - 1) * C + min(cb + lane + 64 * i, C - 1)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = cb + lane + 64 * i;
+        if (c < C) {                                            // wave-uniform (C is a multiple of 64)
+          const float pv = s_pool[c];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[u] = fmaf(w[u][i], pv, acc[u]);
+        }
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const float v = fmaxf(wave_sum(acc[u]), 0.f);
       if (lane == 0 && h0 + u < H) {
         s_hid[h0 + u] = v;
