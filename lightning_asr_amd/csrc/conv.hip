@@ -722,10 +722,48 @@ __device__ __forceinline__ void dwconv_s1_mfma_body(const bf16_t* __restrict__ x
     // ---- phase 2: one channel octet per wave, 8 channels x 2 MFMA sets x 4 frames per lane --------------------
     dw_f32x4 acc[8][NSET];
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-      const int cl = wid * 8 + ch;
+    for (int ch = 0; ch < 8; ++ch)
 #pragma unroll
       for (int ns = 0; ns < NSET; ++ns) acc[ch][ns] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    // Round 5 (the depthwise backward's lesson, same ISA pattern: `s_waitcnt lgkmcnt(0..3)` right behind the reads of the step that is
+    // about to run): the phase's 8 x NKS steps as ONE software pipeline - tap (A) and window (B) fragments kDF steps ahead through a
+    // register ring, consecutive steps on different channels (step i -> channel i % 8, K step i / 8).  The BN-fused instantiation
+    // (211-219 registers) has no room for the ring and keeps the per-channel form.
+    constexpr bool kPipe = !FUSE;
+    if constexpr (kPipe) {
+      constexpr int NSF = 8 * NKS, kDF = 4;
+      const int s0 = 8 * g4 - n16 - sh + 24;
+      const uint32_t* wbase = wsm + wid * 8 * WROW + ((s0 & 1) ? 80 + ((s0 - 1) >> 1) : (s0 >> 1));
+      const char* ibase = img + wid * 8 * LDI + (16 * n16 + 8 * g4) * 2;
+      uint32_t ta[kDF][4];
+      uint4 tb0[kDF], tb1[kDF];
+      auto issue_f = [&](int i, uint32_t (&da)[4], uint4& d0, uint4& d1) {
+        const int ch = i & 7, ks = i >> 3;
+        const uint32_t* wr = wbase + ch * WROW + 16 * ks;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) da[d] = wr[d];
+        d0 = *reinterpret_cast<const uint4*>(ibase + ch * LDI + 64 * ks);
+        if (NSET > 1) d1 = *reinterpret_cast<const uint4*>(ibase + ch * LDI + 512 + 64 * ks);
+      };
+#pragma unroll
+      for (int i = 0; i < kDF; ++i) issue_f(i, ta[i], tb0[i], tb1[i]);
+#pragma unroll
+      for (int i = 0; i < NSF; ++i) {
+        const int ch = i & 7;
+        union { uint32_t u[4]; dw_bf16x8 v; } af, bf0, bf1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) af.u[d] = ta[i % kDF][d];
+        bf0.u[0] = tb0[i % kDF].x; bf0.u[1] = tb0[i % kDF].y; bf0.u[2] = tb0[i % kDF].z; bf0.u[3] = tb0[i % kDF].w;
+        if (NSET > 1) { bf1.u[0] = tb1[i % kDF].x; bf1.u[1] = tb1[i % kDF].y; bf1.u[2] = tb1[i % kDF].z; bf1.u[3] = tb1[i % kDF].w; }
+        if (i + kDF < NSF) issue_f(i + kDF, ta[i % kDF], tb0[i % kDF], tb1[i % kDF]);
+        acc[ch][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf0.v, acc[ch][0], 0, 0, 0);
+        if (NSET > 1) acc[ch][NSET - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af.v, bf1.v, acc[ch][NSET - 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);             // (without it the scheduler sinks the ring's reads back to one step ahead)
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < (kPipe ? 0 : 8); ++ch) {
+      const int cl = wid * 8 + ch;
       const char* row = img + cl * LDI;
       // A[m][kap] = W[kap - m - sh + 24]: lane (m = n16, K group g4) needs W[s0 + 32*ks .. +7], s0 = 8*g4 - m - sh + 24:
       // 4 dwords of the channel's even- or odd-start table.  Every LDS read of the channel is issued up front.
@@ -1288,6 +1326,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void dwconv_bwd_uni_kerne
       }
       __syncthreads();
       char* img = isx ? ximg : dimg;
+      // (round 5: the four transposing reads issued together ahead of the four image writes - as written, read / write / read / write,
+      //  the compiler keeps that order (an LDS write may alias the next read) and every block pays its own LDS round trip - was built
+      //  and measured: this phase 2.94 -> 2.64 us per tile, the MFMA phases behind it 3.62 -> 3.89 and 1.40 -> 1.61 (the register
+      //  allocation moved), step 2.0118 -> 2.0160 ms.  Left as it was.)
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int blk = wid * 4 + it;                    // 8 frame groups x CG channel groups of 16 x 16 per round
