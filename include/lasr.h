@@ -76,8 +76,12 @@ int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dit
  * value; generated noise: the row's first counter) and produces no output sample of its own.  n + 1 <= L.                     */
 #define LASR_LEN_LEAD (1 << 30)
 enum { LASR_WAVE_F32 = 0, LASR_WAVE_PCM16 = 1 };
+/* pitch (round 5): elements between consecutive rows of `wave` (and of `dither`); 0 = L.  With pitch > L the batch sits in rows wider
+ * than the L that defines the frame count T = 1 + (L + 64) / 160 (every utterance still ends at its own sample_lens[b] <= L, lead-in
+ * sample included in the row: n + 1 <= pitch): a loader may keep ONE row pitch per frame-count class (static shapes for a captured
+ * hipGraph) while T stays the reference's "pad to the longest utterance" value (data_module.py:222-248).                        */
 typedef struct {
-  const void* wave; int32_t wave_dtype; const float* dither; uint64_t dither_seed; uint64_t* dither_step;
+  const void* wave; int32_t wave_dtype; const float* dither; uint64_t dither_seed; uint64_t* dither_step; int64_t pitch;
 } lasr_wave_src;
 int lasr_mel_fwd_src(const lasr_wave_src* src, const int32_t* sample_lens, const int32_t* aug, int64_t B, int64_t L,
                      int normalize, float* out_bft, void* out_btf, int dtype, int32_t* frames_out, float* pct_out,

@@ -24,7 +24,7 @@ class Dropout(C.Structure):
 class WaveSrc(C.Structure):
     """lasr_wave_src: samples (f32 or int16 PCM) + explicit dither noise or (seed, device step counter) for generated noise"""
     _fields_ = [("wave", C.c_void_p), ("wave_dtype", C.c_int32), ("dither", C.c_void_p), ("dither_seed", C.c_uint64),
-                ("dither_step", C.c_void_p)]
+                ("dither_step", C.c_void_p), ("pitch", C.c_int64)]
 
 
 WAVE_F32, WAVE_PCM16 = 0, 1

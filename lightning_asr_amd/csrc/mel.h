@@ -11,6 +11,9 @@ struct WaveSrc {
   const float* dither;                 // (B, L) N(0,1) noise, or null
   const unsigned long long* dstep;     // null: no generated noise.  Otherwise (and dither == null) noise is generated in the kernel
   unsigned long long dseed;
+  int64_t pitch = 0;                   // elements between the rows of wave / dither; 0: L.  (L then only defines T = 1 + (L + 64) / 160: a batch
+                                       // may sit in rows wider than its longest utterance - a row pitch that is the same for every
+                                       // batch of a frame-count class - without an extra frame of padding entering T)
 };
 
 // a feature transform waiting to ride in the grid of a CTC lattice launch (the prefetch of the next batch's features)

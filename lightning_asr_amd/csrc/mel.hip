@@ -167,9 +167,10 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
   const int64_t Lb = sample_lens ? (int64_t)(lw & (LASR_LEN_LEAD - 1)) : L;
   const int64_t Lp = Lb + 2 * kPad;
   const int64_t Tb = 1 + Lp / kHop;
-  const float* y = reinterpret_cast<const float*>(src.wave) + (int64_t)b * L;
-  const int16_t* y16 = reinterpret_cast<const int16_t*>(src.wave) + (int64_t)b * L;
-  const float* nz = src.dither ? src.dither + (int64_t)b * L : nullptr;
+  const int64_t pitch = src.pitch ? src.pitch : L;
+  const float* y = reinterpret_cast<const float*>(src.wave) + (int64_t)b * pitch;
+  const int16_t* y16 = reinterpret_cast<const int16_t*>(src.wave) + (int64_t)b * pitch;
+  const float* nz = src.dither ? src.dither + (int64_t)b * pitch : nullptr;
   const bool gen = !nz && src.dstep != nullptr;      // noise generated here (workgroup-uniform)
   for (int i = threadIdx.x; i < kNfft; i += 256) { s_twr[i] = g_mel.tw_re[i]; s_twi[i] = g_mel.tw_im[i]; }
   for (int i = threadIdx.x; i < kWin; i += 256) s_win[i] = g_mel.window[i];
@@ -477,6 +478,8 @@ int wave_src_from_c(const lasr_wave_src* s, WaveSrc* out, const char* who) {
   out->dither = s->dither;
   out->dstep = s->dither ? nullptr : reinterpret_cast<const unsigned long long*>(s->dither_step);
   out->dseed = s->dither_seed;
+  LASR_CHECK_ARG(s->pitch >= 0, "%s: negative row pitch", who);
+  out->pitch = s->pitch;
   return 0;
 }
 
@@ -637,7 +640,7 @@ extern "C" int lasr_spec_augment(const float* in, float* out, const int32_t* aug
 extern "C" int lasr_mel_fwd(const float* wave, const int32_t* sample_lens, const float* dither, const int32_t* aug,
                             int64_t B, int64_t L, int normalize, float* out_bft, void* out_btf, int dtype,
                             int32_t* frames_out, float* pct_out, void* workspace, size_t workspace_bytes, void* stream) {
-  const WaveSrc src = {wave, 0, dither, nullptr, 0ull};
+  const WaveSrc src = {wave, 0, dither, nullptr, 0ull, 0};
   return mel_fwd_src(src, sample_lens, aug, B, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, workspace, workspace_bytes, stream);
 }
 
@@ -664,7 +667,7 @@ extern "C" int lasr_ctc_loss_mel(const float* logp, const int64_t* targets, cons
                                  const float* dither, const int32_t* aug, int64_t Bm, int64_t L, int normalize, float* out_bft,
                                  void* out_btf, int dtype, int32_t* frames_out, float* pct_out, void* mel_workspace,
                                  size_t mel_workspace_bytes, void* stream) {
-  const WaveSrc src = {wave, 0, dither, nullptr, 0ull};
+  const WaveSrc src = {wave, 0, dither, nullptr, 0ull, 0};
   return ctc_loss_mel_src(logp, targets, in_lens, tgt_lens, B, T, C, S_max, blank, nll, grad, gscale, ctc_workspace, ctc_workspace_bytes, src,
                           sample_lens, aug, Bm, L, normalize, out_bft, out_btf, dtype, frames_out, pct_out, mel_workspace,
                           mel_workspace_bytes, stream);

@@ -382,7 +382,7 @@ static int set_prefetch(lasr_model_t* m, const WaveSrc& src, const int32_t* samp
 extern "C" int lasr_model_set_prefetch(lasr_model_t* m, const float* wave, const int32_t* sample_lens, const float* dither,
                                        const int32_t* aug, int64_t B, int64_t L, int normalize, void* out_btf, int dtype,
                                        int32_t* frames_out, float* pct_out, void* mel_workspace, size_t mel_workspace_bytes) {
-  const WaveSrc src = {wave, 0, dither, nullptr, 0ull};
+  const WaveSrc src = {wave, 0, dither, nullptr, 0ull, 0};
   return set_prefetch(m, src, sample_lens, aug, B, L, normalize, out_btf, dtype, frames_out, pct_out, mel_workspace, mel_workspace_bytes);
 }
 

@@ -131,10 +131,13 @@ class AudioParser:
         """(B, 4) int32 SpecAugment rectangles for utterances of `sample_lens` samples (host draws, as the reference)"""
         return torch.tensor([self.draw_spec_augment(1 + (int(l) + 64) // 160) for l in sample_lens], dtype=torch.int32)
 
-    def features_device(self, wave: torch.Tensor, lens: Optional[torch.Tensor], aug: Optional[torch.Tensor] = None, dither: bool = True):
+    def features_device(self, wave: torch.Tensor, lens: Optional[torch.Tensor], aug: Optional[torch.Tensor] = None, dither: bool = True,
+                        logical_len: Optional[int] = None):
         """wave (B, L) f32 or int16 PCM ALREADY in HBM -> (inputs (B,1,64,Tmax) f32 with its channels-last twin attached,
-        input_percentages (B,)); frames past each utterance are zero (collate, :222-248)."""
-        bft, btf, frames, pct = ops.mel(wave, lens, self.device_dither() if dither else None, aug, True, self._act_dtype())
+        input_percentages (B,)); frames past each utterance are zero (collate, :222-248).  logical_len: the longest utterance when
+        the rows are wider than that - Tmax is ITS frame count (the reference pads to the longest feature matrix)."""
+        bft, btf, frames, pct = ops.mel(wave, lens, self.device_dither() if dither else None, aug, True, self._act_dtype(),
+                                        logical_len=logical_len)
         inputs = bft.unsqueeze(1)
         inputs._lasr_btf = btf                                           # channels-last twin for the model
         return inputs, pct
@@ -172,7 +175,8 @@ class AudioParser:
         ev.record()
         self._stage["ev"][self._stage["k"]] = ev
         aug = self.draw_aug_batch(n_sig).to(dev) if mask else None
-        return self.features_device(wave, lens.to(dev), aug, dither)
+        # Tmax = the frames of the longest UTTERANCE (a row's lead-in sample is not part of it: it emits no frame of its own)
+        return self.features_device(wave, lens.to(dev), aug, dither, logical_len=max(int(n_sig.max()), 1))
 
     def _act_dtype(self):
         return getattr(self, "act_dtype", torch.float32)

@@ -162,11 +162,12 @@ class NativeModel:
                     bound = 1.0 / (fan_in ** 0.5)
                     self.view(t).copy_(((torch.rand(t.shape, generator=g) * 2 - 1) * bound).to(self.device))
 
-    def arm_prefetch(self, wave, sample_lens=None, dither=None, aug=None, normalize: bool = True, out=None):
+    def arm_prefetch(self, wave, sample_lens=None, dither=None, aug=None, normalize: bool = True, out=None, logical_len=None):
         """The next loss_backward / loss_backward_staged call also computes the log-mel features of `wave` (B, L) - the NEXT
         step's batch - in the grid of its CTC lattice kernel (lasr_ctc_loss_mel).  Returns (feats (B, T, 64), pct (B)), valid
         once that call has been enqueued."""
-        B, L = wave.shape
+        B, P = wave.shape
+        L = int(logical_len) if logical_len is not None else P      # (rows wider than the longest utterance: ops.mel)
         T = int(self._lib.lasr_mel_num_frames(L))
         if out is not None:                       # caller-owned (feats (B, T, 64), pct (B)): e.g. the ping-pong pair of two captured graphs
             feats, pct = out
@@ -179,7 +180,7 @@ class NativeModel:
         nb = int(self._lib.lasr_mel_workspace_bytes(B, T))
         ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.device)
         from .ops import wave_src
-        src = wave_src(wave, dither)
+        src = wave_src(wave, dither, P if P != L else 0)
         call("lasr_model_set_prefetch_src", self._h, C.byref(src), _p(sample_lens), _p(aug), B, L, int(normalize), _p(feats),
              _lib.F32 if self.act_dtype == torch.float32 else _lib.BF16, _p(frames), _p(pct), _p(ws), nb)
         self._prefetch_keep = (wave, sample_lens, dither, aug, frames, ws)       # alive until the call consumed them

@@ -62,13 +62,15 @@ class HostWaveSource:
             host = torch.zeros(B, L).pin_memory()
             lens = torch.empty(B, dtype=torch.int32)
             leads = getattr(batch, "leads", None)            # crop_raw's lead-in samples (crop after pre-emphasis, data_module.py:157-159)
-            n_real = 0
+            n_real, longest = 0, 1
             for i, w in enumerate(waves):
                 host[i, :w.numel()] = w
                 ld = int(leads[i]) if leads is not None else 0
                 lens[i] = (w.numel() - ld) | (_lib.LEN_LEAD if ld else 0)
                 n_real += w.numel() - ld
+                longest = max(longest, int(w.numel()) - ld)
             db = DevBatch()
+            db.L, db.pitch = longest, L                      # T = the frames of the longest UTTERANCE; rows may be one lead-in sample wider
             db.pcm = host.to(self.device, non_blocking=True)
             db.lens, db.sizes, db.targets = lens.to(self.device), sizes.to(self.device), targets.to(self.device)
             db.aug = None
@@ -177,7 +179,7 @@ class FusedLoop:
         pf, self._pf = self._pf, None
         if pf is not None and pf[0] == cur.index:
             return pf[1], pf[2]
-        return self.ts.features(cur.pcm, cur.lens, self.dither, cur.aug)
+        return self.ts.features(cur.pcm, cur.lens, self.dither, cur.aug, logical_len=cur.L)
 
     def _graph_for(self, cur: DevBatch, nxt: DevBatch) -> Optional[GraphedTrainStep]:
         key = cur.key
@@ -191,7 +193,7 @@ class FusedLoop:
             return None
         B, L, S, with_aug = key
         g = GraphedTrainStep(self.ts, B, L, S, ragged=True, prefetch=True, want_logp=False, wave_dtype=cur.pcm.dtype,
-                             with_aug=with_aug, dither=self.dither)
+                             with_aug=with_aug, dither=self.dither, logical_len=cur.L)
         self.graphs[key] = g
         try:
             g.targets.copy_(cur.targets)
@@ -237,7 +239,7 @@ class FusedLoop:
         else:
             nf = None
             if nxt is not None:
-                nf = native.arm_prefetch(nxt.pcm, nxt.lens, self.dither, nxt.aug)
+                nf = native.arm_prefetch(nxt.pcm, nxt.lens, self.dither, nxt.aug, logical_len=nxt.L)
             loss, nll, _, am = ts.step_features(feats, pct, cur.targets, cur.sizes, want_logp=False)
             self._pf = (nxt.index, nf[0], nf[1]) if nf is not None else None
             self.eager_steps += 1

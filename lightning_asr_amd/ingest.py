@@ -195,7 +195,8 @@ class BatchProducer(threading.Thread):
 
 class DevBatch:
     """one batch resident in HBM (views of a device ring slot), valid for the compute stream once ``ready`` has been waited on"""
-    __slots__ = ("pcm", "lens", "sizes", "aug", "targets", "paths", "B", "ld", "S", "seconds", "ready", "dslot", "index", "key", "mask", "waited")
+    __slots__ = ("pcm", "lens", "sizes", "aug", "targets", "paths", "B", "ld", "S", "seconds", "ready", "dslot", "index", "key", "mask", "waited",
+                 "L", "pitch")
 
 
 class DeviceFeeder:
@@ -240,7 +241,18 @@ class DeviceFeeder:
         k, released = self.free_dev.get()
         if k < 0:
             raise RuntimeError("device feeder closed")
-        n = hb.B * hb.ld
+        # The batch's frame count is the reference's "pad to the longest utterance" (data_module.py:222-248): T = frames(longest).
+        # The device rows get ONE pitch per frame-count class - 160 (T - 1) + 96 samples: room for the longest utterance of the class
+        # plus its lead-in sample - and the kernels are told L = 160 (T - 1) + 95, the longest length with that T (lasr_wave_src.pitch,
+        # round 5).  Until round 4 the pitch was the host reader's (longest row rounded up to 8 samples) and T followed it: one frame
+        # of padding too many whenever the rounding (or the lead-in sample) crossed a frame boundary (~5 % of cropped batches), and
+        # a different shape for nearly every batch - no hipGraph replay under the reference's random crop.
+        longest = int((hb.lens & (_lib.LEN_LEAD - 1)).max()) if hb.B else 0
+        frames = 1 + (longest + 64) // 160
+        L_log, pitch = 160 * (frames - 1) + 95, 160 * (frames - 1) + 96
+        if pitch < hb.ld:                      # (cannot happen: ld = the longest row rounded up to 8 <= 160 (T - 1) + 96)
+            L_log = pitch = hb.ld
+        n = hb.B * pitch
         cs = self.copy_stream
         if n > self.pcm[k].numel() or hb.meta_words > self.meta[k].numel():
             # A batch outgrew its slot.  The new block is allocated UNDER THE COPY STREAM: the caching allocator keeps one pool per
@@ -264,7 +276,11 @@ class DeviceFeeder:
         if released is not None:
             cs.wait_event(released)             # the step that read this device slot has finished with it
         with torch.cuda.stream(cs):
-            self.pcm[k][:n].copy_(self.ring.pcm[hb.slot][:n], non_blocking=True)
+            src = self.ring.pcm[hb.slot][:hb.B * hb.ld]
+            if pitch == hb.ld:
+                self.pcm[k][:n].copy_(src, non_blocking=True)
+            else:                               # rows at the host reader's pitch -> rows at the class pitch (the tail of a row is never read)
+                self.pcm[k][:n].view(hb.B, pitch)[:, :hb.ld].copy_(src.view(hb.B, hb.ld), non_blocking=True)
             self.meta[k][:hb.meta_words].copy_(hb.meta[:hb.meta_words], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(cs)
@@ -273,12 +289,13 @@ class DeviceFeeder:
         o_lens, o_sizes, o_aug, o_tg, _ = _meta_layout(B, S, hb.aug is not None)
         m = self.meta[k]
         db = DevBatch()
-        db.pcm = self.pcm[k][:n].view(B, hb.ld)
+        db.pcm = self.pcm[k][:n].view(B, pitch)
+        db.L, db.pitch = L_log, pitch
         db.lens, db.sizes = m[o_lens:o_lens + B], m[o_sizes:o_sizes + B]
         db.aug = m[o_aug:o_aug + 4 * B].view(B, 4) if hb.aug is not None else None
         db.targets = m[o_tg:o_tg + 2 * B * S].view(torch.int64).view(B, S)
         db.paths, db.B, db.ld, db.S, db.seconds, db.ready, db.dslot, db.index = hb.paths, B, hb.ld, S, hb.seconds, ev, k, hb.index
-        db.key = (B, hb.ld, S, hb.aug is not None)
+        db.key = (B, pitch, S, hb.aug is not None)
         db.waited = False
         return db
 

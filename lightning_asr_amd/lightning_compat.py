@@ -224,7 +224,7 @@ class Trainer:
                 for db in src:
                     if db.ready is not None and not db.ready.query():
                         torch.cuda.current_stream().wait_event(db.ready)
-                    inputs, pct = dm.audio_parser.features_device(db.pcm, db.lens, None)
+                    inputs, pct = dm.audio_parser.features_device(db.pcm, db.lens, None, logical_len=db.L)
                     yield inputs, db.targets, pct, db.sizes, db.paths
                     src.release(db)          # (after the consumer has enqueued everything that reads the slot's targets / sizes)
             finally:

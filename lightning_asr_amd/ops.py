@@ -63,8 +63,9 @@ class DeviceDither:
         return out
 
 
-def wave_src(wave: torch.Tensor, dither=None) -> "_lib.WaveSrc":
-    """lasr_wave_src for a (B, L) float32 or int16 (PCM) waveform tensor; dither: None | (B, L) f32 noise | DeviceDither"""
+def wave_src(wave: torch.Tensor, dither=None, pitch: int = 0) -> "_lib.WaveSrc":
+    """lasr_wave_src for a (B, L) float32 or int16 (PCM) waveform tensor; dither: None | (B, L) f32 noise | DeviceDither;
+    pitch: elements between rows when the rows are wider than the L the call is made with (0: L)"""
     if wave.dtype == torch.float32:
         wd = _lib.WAVE_F32
     elif wave.dtype == torch.int16:
@@ -72,18 +73,24 @@ def wave_src(wave: torch.Tensor, dither=None) -> "_lib.WaveSrc":
     else:
         raise TypeError("waveforms must be float32 or int16 PCM, got %s" % wave.dtype)
     if isinstance(dither, DeviceDither):
-        return _lib.WaveSrc(_p(wave), wd, None, dither.seed, _p(dither.step))
+        return _lib.WaveSrc(_p(wave), wd, None, dither.seed, _p(dither.step), int(pitch))
     if dither is not None and (dither.dtype != torch.float32 or tuple(dither.shape) != tuple(wave.shape)):
         raise TypeError("dither noise must be a float32 tensor of the waveform's shape")
-    return _lib.WaveSrc(_p(wave), wd, _p(dither), 0, None)
+    return _lib.WaveSrc(_p(wave), wd, _p(dither), 0, None, int(pitch))
 
 
 def mel(wave: torch.Tensor, sample_lens: Optional[torch.Tensor] = None, dither=None,
         aug: Optional[torch.Tensor] = None, normalize: bool = True, dtype=torch.float32, want_bft: bool = True,
-        want_btf: bool = True, out_btf: Optional[torch.Tensor] = None, out_pct: Optional[torch.Tensor] = None):
+        want_btf: bool = True, out_btf: Optional[torch.Tensor] = None, out_pct: Optional[torch.Tensor] = None,
+        logical_len: Optional[int] = None):
     """wave (B, L) f32 or int16 PCM -> (feats_bft (B,64,T) f32 | None, feats_btf (B,T,64) dtype | None, frames (B) i32, pct (B) f32).
-    dither: None, a (B, L) N(0,1) tensor, or a DeviceDither (noise generated inside the kernel)."""
-    B, L = wave.shape
+    dither: None, a (B, L) N(0,1) tensor, or a DeviceDither (noise generated inside the kernel).
+    logical_len: the batch's longest utterance when the rows of `wave` are wider than that (a loader's static row pitch): T = the
+    frames of `logical_len` samples - the reference's pad-to-longest (data_module.py:222-248) - not of the row width."""
+    B, P = wave.shape
+    L = int(logical_len) if logical_len is not None else P
+    if not 0 < L <= P:
+        raise ValueError("logical_len %s outside the rows' width %d" % (logical_len, P))
     T = mel_num_frames(L)
     dev = wave.device
     bft = torch.empty(B, 64, T, dtype=torch.float32, device=dev) if want_bft else None
@@ -98,7 +105,7 @@ def mel(wave: torch.Tensor, sample_lens: Optional[torch.Tensor] = None, dither=N
     pct = out_pct if out_pct is not None else torch.empty(B, dtype=torch.float32, device=dev)
     nb = _lib.load().lasr_mel_workspace_bytes(B, T)
     ws = _ws(nb, dev)
-    src = wave_src(wave, dither)
+    src = wave_src(wave, dither, P if P != L else 0)
     call("lasr_mel_fwd_src", _lib.C.byref(src), _p(sample_lens), _p(aug), B, L, int(normalize), _p(bft), _p(btf),
          F32 if dtype == torch.float32 else BF16, _p(frames), _p(pct), _p(ws), nb, _stream())
     return bft, btf, frames, pct

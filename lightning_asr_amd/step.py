@@ -120,9 +120,11 @@ class TrainStep:
             torch.distributed.broadcast(self.model.params, src, group=self.pg)
             torch.distributed.broadcast(self.model.buffers, src, group=self.pg)
 
-    def features(self, wave, sample_lens=None, dither=None, aug=None):
-        """wave (B, L) f32 on the GPU -> ([B][T][64] features in the activation dtype, pct (B))."""
-        _, btf, _, pct = ops.mel(wave, sample_lens, dither, aug, True, self.model.act_dtype, want_bft=False, want_btf=True)
+    def features(self, wave, sample_lens=None, dither=None, aug=None, logical_len=None):
+        """wave (B, L) f32 on the GPU -> ([B][T][64] features in the activation dtype, pct (B)).  logical_len: the longest utterance
+        when the rows are wider than that (ops.mel)."""
+        _, btf, _, pct = ops.mel(wave, sample_lens, dither, aug, True, self.model.act_dtype, want_bft=False, want_btf=True,
+                                 logical_len=logical_len)
         return btf, pct
 
     def optimizer_step(self) -> None:
@@ -225,7 +227,8 @@ class GraphedTrainStep:
     Shapes are fixed at construction; one instance per (B, L, S)."""
 
     def __init__(self, ts: TrainStep, B: int, L: int, S: int, ragged: bool = False, prefetch: bool = True, want_logp: bool = False,
-                 inputs=None, feats_in=None, feats_out=None, wave_dtype=torch.float32, with_aug: bool = False, dither=None):
+                 inputs=None, feats_in=None, feats_out=None, wave_dtype=torch.float32, with_aug: bool = False, dither=None,
+                 logical_len: Optional[int] = None):
         """inputs = (wave, sample_lens | None, targets, tgt_lens[, aug]): tensors already resident in HBM that the graph reads IN
         PLACE (``replay()`` then takes no data and nothing is copied); otherwise static buffers are allocated and ``step()``
         copies into them.  feats_in / feats_out = (feats, pct) pairs: the features this graph trains on and where it writes the
@@ -233,6 +236,7 @@ class GraphedTrainStep:
         wave_dtype: torch.float32 or torch.int16 (PCM); with_aug: a static (B, 4) SpecAugment block; dither: None, a static
         (B, L) noise tensor or an ``ops.DeviceDither`` (fresh noise per replay)."""
         self.ts, self.prefetch, self.want_logp = ts, prefetch, want_logp
+        self.logical_len = logical_len        # rows of L samples whose longest utterance has logical_len <= L (ops.mel): T follows it
         dev = ts.model.device
         self.bound = inputs is not None
         self.dither = dither
@@ -253,13 +257,13 @@ class GraphedTrainStep:
     def _body(self):
         ts, m = self.ts, self.ts.model
         if self.prefetch:
-            nf, npct = m.arm_prefetch(self.wave, self.lens, self.dither, self.aug, out=self.feats_out)
+            nf, npct = m.arm_prefetch(self.wave, self.lens, self.dither, self.aug, out=self.feats_out, logical_len=self.logical_len)
             out = ts.step_features(self.F_cur, self.pct_cur, self.targets, self.tgt_lens, want_logp=self.want_logp)
             if self.feats_out is None:
                 self.F_cur.copy_(nf)
                 self.pct_cur.copy_(npct)
             return out
-        feats, pct = ts.features(self.wave, self.lens, self.dither, self.aug)
+        feats, pct = ts.features(self.wave, self.lens, self.dither, self.aug, logical_len=self.logical_len)
         return ts.step_features(feats, pct, self.targets, self.tgt_lens, want_logp=self.want_logp)
 
     def capture(self, first_wave: Optional[torch.Tensor] = None, first_lens: Optional[torch.Tensor] = None, warmup: int = 2,
@@ -291,7 +295,7 @@ class GraphedTrainStep:
                 if self.aug is not None and first_aug is not None:
                     self.aug.copy_(first_aug)
             if self.prefetch and self.F_cur is None:
-                f, p_ = ts.features(first_wave, first_lens, None, first_aug)
+                f, p_ = ts.features(first_wave, first_lens, None, first_aug, logical_len=self.logical_len)
                 self.F_cur, self.pct_cur = f.clone(), p_.clone()
             elif self.prefetch and not self.bound and self.feats_out is None:
                 f, p_ = self.F_cur.clone(), self.pct_cur.clone()     # (the warm-up passes overwrite the primed features)

@@ -285,3 +285,64 @@ def test_custom_dataset_and_overridden_step_keep_working(dev, tmp_path):
 
     tr = run(MyModule, LibriDataModule, "b")
     assert tr.fused is None                                  # training_step -> loss.backward() -> Novograd.step
+
+
+def test_rows_wider_than_the_longest_utterance_keep_the_reference_frame_count(dev, tmp_path):
+    """The reference pads a batch to its longest FEATURE matrix (data_module.py:222-248): Tmax = 1 + (longest + 64) // 160.  Until
+    round 5 Tmax followed the device rows' width - the longest row rounded up to 8 samples, lead-in sample included - which is one
+    frame too many whenever the rounding crosses a frame boundary.  Now the rows' width travels as `lasr_wave_src.pitch` and the
+    call's L is the longest utterance:
+      (1) ops.mel(wave (B, P), logical_len = L): bit-identical to the tight (B, L) call, T = frames(L);
+      (2) the native ingest on files of 16 095 and 12 000 samples (16 095 + 64 = 101 * 160 - 1: rounding the row to 16 096 samples used
+          to give 102 frames): 101 frames, pct as R.collate computes it, features within MEL_TOL of the oracle, and the device rows
+          have ONE pitch per frame-count class (16 096 = 160 * 100 + 96) whatever the individual lengths are."""
+    import wave as wavmod
+    from conftest import MEL_TOL
+    from lightning_asr_amd import ops
+    from lightning_asr_amd.ingest import BatchProducer, DeviceFeeder, PinnedRing
+    from oracle import ref_cpu as R
+    g = torch.Generator().manual_seed(5)
+    # (1)
+    B, L, P = 3, 16095, 16096 + 64
+    wave = 0.1 * torch.randn(B, L, generator=g)
+    lens = torch.tensor([L, 12000, 300], dtype=torch.int32)
+    wide = torch.full((B, P), 7.0)                       # the rows' tails hold garbage: never read
+    wide[:, :L] = wave
+    noise = torch.randn(B, L, generator=g)
+    wide_n = torch.zeros(B, P); wide_n[:, :L] = noise
+    a = ops.mel(wave.to(dev), lens.to(dev), noise.to(dev), None, True)
+    b = ops.mel(wide.to(dev), lens.to(dev), wide_n.to(dev), None, True, logical_len=L)
+    assert a[0].shape == b[0].shape == (B, 64, 101) and all(torch.equal(x, y) for x, y in zip(a, b))
+    c = ops.mel(wide.to(dev), lens.to(dev), wide_n.to(dev), None, True)          # without logical_len T follows the rows: 102 frames
+    assert c[0].shape[2] == 1 + (P + 64) // 160 and torch.equal(c[0][:, :, :101], a[0]) and bool((c[0][:, :, 101:] == 0).all())
+    pcm = (wave.clamp(-1, 1) * 32767).round().to(torch.int16)
+    wide16 = torch.full((B, P), 1234, dtype=torch.int16); wide16[:, :L] = pcm
+    dd1, dd2 = ops.DeviceDither(77, dev), ops.DeviceDither(77, dev)
+    a16 = ops.mel(pcm.to(dev), lens.to(dev), dd1, None, True)
+    b16 = ops.mel(wide16.to(dev), lens.to(dev), dd2, None, True, logical_len=L)
+    assert all(torch.equal(x, y) for x, y in zip(a16, b16))
+    # (2)
+    files, lens_f = [], [16095, 12000]
+    for i, n in enumerate(lens_f):
+        x = (0.1 * torch.randn(n, generator=g)).clamp(-1, 1).mul(32767).round().to(torch.int16)
+        p = str(tmp_path / ("f%d.wav" % i))
+        with wavmod.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.numpy().tobytes())
+        files.append((p, x))
+
+    class DS:                                            # the stock dataset's attributes the producer reads
+        datasets = [{"audio_filepath": p, "text": "ab", "duration": x.numel() / 16000} for p, x in files]
+        char2index = {"a": 0, "b": 1}
+    ring = PinnedRing(2, 2 * 16200, 4096)
+    feeder = DeviceFeeder(ring, dev, n_slots=2)
+    prod = BatchProducer(DS(), [[0, 1]], ring, mask=False, audio_parser=None, n_threads=2, crop=False, feeder=feeder)
+    db = feeder.upload(prod.make([0, 1], ring.free.get(), 0))
+    assert db.pitch == 160 * 100 + 96 and db.L == 160 * 100 + 95 and tuple(db.pcm.shape) == (2, db.pitch) and db.key[1] == db.pitch
+    torch.cuda.current_stream().wait_event(db.ready)
+    bft, _, frames, pct = ops.mel(db.pcm, db.lens, None, None, True, logical_len=db.L)
+    feats = [R.parse_wave((x.float() / 32768.0).unsqueeze(0)) for _, x in files]
+    inputs, _, pct_ref, _ = R.collate(feats, [[0, 1], [0, 1]])
+    assert bft.shape[2] == inputs.shape[3] == 101                                  # (the row width alone would say 102)
+    assert frames.cpu().tolist() == [f.shape[2] for f in feats] and torch.equal(pct.cpu(), pct_ref)
+    assert float((bft.cpu() - inputs[:, 0]).abs().max() / inputs.abs().max()) < MEL_TOL + 5e-5      # (f32 oracle: + its own round-off)
+    feeder.close()
