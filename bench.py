@@ -398,7 +398,7 @@ def main():
                     help="step: TrainStep on batches resident in HBM (default); trainer: manifest -> LibriDataModule -> Trainer.fit")
     ap.add_argument("--ingest-threads", type=int, default=8, help="--path trainer: host threads decoding wav files (data.num_worker)")
     ap.add_argument("--no-trainer-record", dest="trainer_record", action="store_false",
-                    help="skip the `trainer` sub-record (25 + 30 steps through Trainer.fit) of the default one-GPU line")
+                    help="skip the `trainer` sub-record (60 + 30 steps through Trainer.fit) of the default one-GPU line")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     # N > 1 from the plain command (`python bench.py --gpus N`, no outer launcher) or under torch.distributed.run: a supervisor that
@@ -640,7 +640,7 @@ def main():
     if dist is not None:
         dist.barrier()
 
-    # ---- the drop-in path in the same record: K = 30 steps (after 25 warm-up steps) of the SAME metric through the reference's own surface (manifest ->
+    # ---- the drop-in path in the same record: K = 30 steps (after 60 warm-up steps) of the SAME metric through the reference's own surface (manifest ->
     # LibriDataModule -> LightingModule -> Trainer.fit; wav decode, int16 H2D, random crop + SpecAugment, dither, per-step decode + WER
     # inside the timed region).  One GPU only: Trainer owns its process group.  ~5 s including the synthetic corpus.
     trainer_rec = None
@@ -648,12 +648,13 @@ def main():
         del graphs
         torch.cuda.synchronize()
         try:
-            # (25 warm-up steps: while the ingest threads are still filling their ring for the first time they compete with the
-            #  enqueuing thread for the interpreter - the same run read 2.25 ms per step with 5 warm-up steps and 2.16 with 25 or 60)
-            tr_out = trainer_path(args, cfg, emit=False, steps=30, warmup=25)
+            # (60 warm-up steps: while the ingest threads are still filling their ring for the first time they compete with the
+            #  enqueuing thread for the interpreter - the same run read 2.25 ms per step with 5 warm-up steps and 2.16 with 25 or 60 -
+            #  and under the random crop the two common batch shapes are captured into hipGraphs within the first ~25 +- 13 steps)
+            tr_out = trainer_path(args, cfg, emit=False, steps=30, warmup=60)
             c_ = tr_out["config"]
-            trainer_rec = {"what": "the same metric through LibriDataModule + LightingModule + Trainer.fit (bench.py --path trainer), 25 warm-up + 30 timed steps",
-                           "value": tr_out["value"], "unit": tr_out["unit"], "ms_per_step": tr_out["ms_per_step"], "steps": 30, "warmup": 25,
+            trainer_rec = {"what": "the same metric through LibriDataModule + LightingModule + Trainer.fit (bench.py --path trainer), 60 warm-up + 30 timed steps",
+                           "value": tr_out["value"], "unit": tr_out["unit"], "ms_per_step": tr_out["ms_per_step"], "steps": 30, "warmup": 60,
                            "vs_step_line": tr_out["ms_per_step"] / ms_per_step, "host_ms_per_step": c_["host_ms_per_step"],
                            "hip_graph_steps": c_["hip_graph_steps"], "eager_steps": c_["eager_steps"], "train_crop": c_["train_crop"],
                            "ingest": c_["ingest"], "ingest_threads": c_["ingest_threads"], "padding_frac": c_["padding_frac"],

@@ -380,6 +380,15 @@ int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float*
                        float eps, float weight_decay, float grad_scale, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* roctx ranges (round 5; SURVEY 5 aux "tracing"): with LASR_ROCTX=1 in the environment the plan brackets its stages and units with
+ * named ranges - "lasr:forward", "lasr:fwd <unit>", "lasr:head", "lasr:backward", "lasr:bwd <unit>", "lasr:wgrad flush", "lasr:reduce" -
+ * through librocprofiler-sdk-roctx (dlopen'd on first use; a missing library switches the ranges off), so that
+ * `rocprofv3 --marker-trace --kernel-trace` attributes kernels to units.  The host framework adds its own with the two calls below
+ * (lightning_asr_amd/step.py: "lasr:step", "lasr:optimizer").  Host-side only: nothing is enqueued on any stream.                */
+int lasr_roctx_range_push(const char* name);
+int lasr_roctx_range_pop(void);
+int lasr_roctx_enabled(void);
+
 /* ---------------------------------------------------------------- measurement --------------
  * Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's
  * roofline leg; off by default, costs two event records per instrumented launch when on).

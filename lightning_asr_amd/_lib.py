@@ -38,6 +38,9 @@ class ModelConfig(C.Structure):
 # name -> (restype, argtypes); every symbol include/lasr.h declares
 SIGNATURES = {
     "lasr_version": (_i32, []),
+    "lasr_roctx_range_push": (_i32, [C.c_char_p]),
+    "lasr_roctx_range_pop": (_i32, []),
+    "lasr_roctx_enabled": (_i32, []),
     "lasr_last_error": (C.c_char_p, []),
     "lasr_mel_num_frames": (_i64, [_i64]),
     "lasr_mel_workspace_bytes": (_sz, [_i64, _i64]),

@@ -66,6 +66,43 @@ int nt_loads_mask() {
 }
 }  // namespace lasr
 
+// ---- roctx ranges --------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <stdlib.h>
+namespace lasr {
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("LASR_ROCTX");
+    if (!e || atoi(e) == 0) return;
+    void* h = nullptr;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+      if ((h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void roctx_push(const char* name) { Roctx& r = roctx(); if (r.push) r.push(name); }
+void roctx_pop() { Roctx& r = roctx(); if (r.pop) r.pop(); }
+}  // namespace lasr
+
+extern "C" int lasr_roctx_range_push(const char* name) {
+  LASR_CHECK_ARG(name, "lasr_roctx_range_push: null name");
+  lasr::roctx_push(name);
+  return 0;
+}
+extern "C" int lasr_roctx_range_pop(void) {
+  lasr::roctx_pop();
+  return 0;
+}
+extern "C" int lasr_roctx_enabled(void) { return lasr::roctx().push != nullptr; }
+
 extern "C" int lasr_prof_enable(int on) {
   lasr::g_prof_on = on != 0;
   if (on) {

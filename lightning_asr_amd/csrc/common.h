@@ -36,6 +36,16 @@ int hip_fail(hipError_t e, const char* what);
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// roctx ranges (capi.hip): named host-side ranges around the plan's stages and units for `rocprofv3 --marker-trace`; off unless
+// LASR_ROCTX=1 (librocprofiler-sdk-roctx.so / libroctx64.so is dlopen'd on first use - a missing library switches the ranges off)
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { roctx_push(name); }
+  ~RoctxRange() { roctx_pop(); }
+  RoctxRange(const RoctxRange&) = delete;
+};
+
 // in-library kernel timer (capi.hip); kinds are LASR_PROF_* in lasr.h
 int prof_begin(int kind, hipStream_t st, double flops, double bytes);
 void prof_end(int token, hipStream_t st);

@@ -81,6 +81,7 @@ static bool no_fuse() { static const bool v = getenv("LASR_NO_FUSE") != nullptr;
 // One "unit": [depthwise conv] -> 1x1 GEMM (+mask) -> BN  [+ residual 1x1 GEMM -> BN] -> activation
 struct Unit {
   std::string tap;
+  std::string rx_fwd, rx_bwd;     // roctx range names "lasr:fwd <tap>" / "lasr:bwd <tap>" (made once, at model creation)
   int ci = 0, co = 0, k = 0, stride = 1;
   bool has_dw = false, has_res = false, masked = false, act = true, has_se = false, ctx_before = false;
   int64_t w_dw = -1, w_pw = -1, w_res = -1, w_se1 = -1, w_se2 = -1;
@@ -204,6 +205,7 @@ static int build_model(lasr_model* m) {
     u.bn = m->add_bn("encoder.last_cnn2.1", 1024);
     m->units.push_back(u);
   }
+  for (Unit& u : m->units) { u.rx_fwd = "lasr:fwd " + u.tap; u.rx_bwd = "lasr:bwd " + u.tap; }
   if (ctx) {  // context_rnn = nn.LSTM(256, 40, bidirectional)   models/QuartNetContext.py:157
     const std::string r = "encoder.context_rnn.rnn.";
     for (int d = 0; d < 2; ++d) {
@@ -582,8 +584,10 @@ static int forward_impl(lasr_model_t* m, const float* params, float* buffers, co
                                 v.has_res ? atf(ws, v.o_coef2) : nullptr, v.has_se ? atf(ws, v.o_se_scale) : nullptr, at(ws, v.o_out), dt, B,
                                 T, v.co, v.act ? m->cfg.act : LASR_ACT_NONE, dropping ? &drop : nullptr, stream);
   };
+  RoctxRange rr_fwd(training ? "lasr:forward (training)" : "lasr:forward (eval)");
   for (size_t ui = 0; ui < m->units.size(); ++ui) {
     const Unit& u = m->units[ui];
+    RoctxRange rr_unit(u.rx_fwd.c_str());
     if (pend && !(u.has_dw && u.stride == 1 && !u.ctx_before)) {   // (not reached: the hand-over is only arranged for such a unit)
       LASR_TRY(bn_act_of(*pend));
       pend = nullptr;
@@ -820,7 +824,9 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
   std::vector<lasr_reduce_desc> pending;
   std::vector<lasr_gemm_problem> wprobs;
   std::vector<float*> wslabs;
+  RoctxRange rr_bwd("lasr:backward");
   for (int ui = unit_hi; ui >= unit_stop; --ui) {
+    RoctxRange rr_unit(m->units[ui].rx_bwd.c_str());
     const Unit& u = m->units[ui];
     const void* x_in = ui > 0 ? at(ws, m->units[ui - 1].o_out) : feats;
     if (u.ctx_before) x_in = at(ws, p.o_cat);
@@ -1002,6 +1008,7 @@ static int backward_from_glogits(lasr_model* m, const float* params, const void*
       cur ^= 1;
     }
   }
+  RoctxRange rr_tail("lasr:wgrad flush + reduce");
   if (!wprobs.empty()) LASR_TRY(flush_wgrads(wprobs, wslabs, pending, stream));
   if (!pending.empty()) {   // the stage's gradients are final
     double rb = 0;

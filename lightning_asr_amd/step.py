@@ -20,6 +20,16 @@ from .engine import NativeModel
 from .schedule import CosineAnnealingWarmupRestarts
 
 
+_ROCTX = None
+
+
+def _roctx_on() -> bool:
+    global _ROCTX
+    if _ROCTX is None:
+        _ROCTX = os.environ.get("LASR_ROCTX", "0") not in ("", "0") and bool(_lib.load().lasr_roctx_enabled())
+    return _ROCTX
+
+
 class TrainStep:
     def __init__(self, model: NativeModel, learning_rate: float = 1e-2, weight_decay: float = 1e-3,
                  betas=(0.8, 0.5), eps: float = 1e-8, schedule: Optional[CosineAnnealingWarmupRestarts] = None,
@@ -167,6 +177,15 @@ class TrainStep:
         self._lr_epoch = int(sc.last_epoch)
 
     def step_features(self, feats, pct, targets, tgt_lens, want_logp: bool = True):
+        if _roctx_on():                      # LASR_ROCTX=1: "lasr:step" around the whole step (rocprofv3 --marker-trace)
+            _lib.load().lasr_roctx_range_push(b"lasr:step")
+            try:
+                return self._step_features(feats, pct, targets, tgt_lens, want_logp)
+            finally:
+                _lib.load().lasr_roctx_range_pop()
+        return self._step_features(feats, pct, targets, tgt_lens, want_logp)
+
+    def _step_features(self, feats, pct, targets, tgt_lens, want_logp: bool = True):
         m = self.model
         if self.overlap and (self.world > 1 or self.force_staged):
             # bucketed SUM all-reduce, launched bucket by bucket in reverse layer order while the units below
@@ -197,7 +216,7 @@ class TrainStep:
                      for t in (wave, sample_lens, dither, aug))
 
     def step(self, wave, targets, tgt_lens, sample_lens=None, dither=None, aug=None, prefetch_wave=None, prefetch_lens=None,
-             prefetch_dither=None, prefetch_aug=None, want_logp: bool = True):
+             prefetch_dither=None, prefetch_aug=None, want_logp: bool = True, logical_len=None, prefetch_logical_len=None):
         """One training step on `wave`.  prefetch_wave: the NEXT step's waveforms (already in HBM): their log-mel features are
         computed during this step in the grid of the CTC lattice kernel (32 busy workgroups, 224 idle CUs for ~0.1 ms) and
         picked up by the next call if it passes the same tensors - the data-loader prefetch of the reference's workers;
@@ -206,10 +225,10 @@ class TrainStep:
         if pf is not None and pf[0] == self._prefetch_key(wave, sample_lens, dither, aug):
             feats, pct = pf[1], pf[2]
         else:
-            feats, pct = self.features(wave, sample_lens, dither, aug)
+            feats, pct = self.features(wave, sample_lens, dither, aug, logical_len=logical_len)
         nxt = None
         if prefetch_wave is not None:
-            nf, npct = self.model.arm_prefetch(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug)
+            nf, npct = self.model.arm_prefetch(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug, logical_len=prefetch_logical_len)
             nxt = (self._prefetch_key(prefetch_wave, prefetch_lens, prefetch_dither, prefetch_aug), nf, npct)
         out = self.step_features(feats, pct, targets, tgt_lens, want_logp=want_logp)
         self._prefetched = nxt

@@ -87,7 +87,7 @@ def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph, drop_
 
     def hook(db):
         seen.append({"pcm": db.pcm.clone(), "lens": db.lens.clone(), "targets": db.targets.clone(), "sizes": db.sizes.clone(),
-                     "aug": None if db.aug is None else db.aug.clone()})
+                     "aug": None if db.aug is None else db.aug.clone(), "L": db.L})      # L: the longest utterance (rows may be wider)
     tr = Trainer(max_epochs=1, default_root_dir=str(tmp_path / "run"), device=str(dev), check_val_every_n_epoch=1, log_every_n_steps=2)
     tr._fused_on_batch = hook
     hist = tr.fit(model, dm)
@@ -110,7 +110,8 @@ def _fit_and_replay(dev, tmp_path, dtype, steps, crop, monkeypatch, graph, drop_
         nxt = seen[i + 1] if i + 1 < len(seen) else None
         ts.step(b["pcm"], b["targets"], b["sizes"], sample_lens=b["lens"], dither=dd, aug=b["aug"],
                 prefetch_wave=None if nxt is None else nxt["pcm"], prefetch_lens=None if nxt is None else nxt["lens"],
-                prefetch_dither=None if nxt is None else dd, prefetch_aug=None if nxt is None else nxt["aug"], want_logp=False)
+                prefetch_dither=None if nxt is None else dd, prefetch_aug=None if nxt is None else nxt["aug"], want_logp=False,
+                logical_len=b["L"], prefetch_logical_len=None if nxt is None else nxt["L"])
     torch.cuda.synchronize()
     # (validation ran at the end of the epoch and does not touch the parameters; BN running statistics are training-only)
     assert torch.equal(model.encoder.native.params, m2.params), float((model.encoder.native.params - m2.params).abs().max())
