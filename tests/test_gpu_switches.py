@@ -130,3 +130,19 @@ def test_context_se_switches(dev):
     allp = _run({"LASR_LSTM_WGRAD_BUDGET": "0"}, variant="context_se")
     _close(allp, base, "LASR_LSTM_WGRAD_BUDGET=0")
     assert allp["loss"] == base["loss"]
+
+
+def test_roctx_ranges_change_nothing_but_are_live(dev):
+    """LASR_ROCTX=1: the plan's roctx ranges (host-side markers for `rocprofv3 --marker-trace`) are live - the roctx library was found
+    and bound - and the step's numbers are the numbers without them."""
+    import ctypes
+    base = _run({})
+    traced = _run({"LASR_ROCTX": "1"})
+    assert traced == base
+    code = ("import os, sys; sys.path.insert(0, %r); from lightning_asr_amd import _lib; lib = _lib.load(); "
+            "print(int(lib.lasr_roctx_enabled()), lib.lasr_roctx_range_push(b'lasr:test'), lib.lasr_roctx_range_pop())" % ROOT)
+    on = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LASR_ROCTX="1"), capture_output=True, text=True, timeout=120)
+    off = subprocess.run([sys.executable, "-c", code], env={k: v for k, v in os.environ.items() if k != "LASR_ROCTX"}, capture_output=True,
+                         text=True, timeout=120)
+    assert on.returncode == 0 and on.stdout.split() == ["1", "0", "0"], (on.stdout, on.stderr[-500:])
+    assert off.returncode == 0 and off.stdout.split() == ["0", "0", "0"], (off.stdout, off.stderr[-500:])
