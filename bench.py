@@ -405,6 +405,11 @@ def main():
     # never touches the GPU starts FRESH worker processes, one per GPU, relays rank 0's JSON line (plus a `launcher` record: which
     # rung of graph + lasr_comm -> eager + lasr_comm -> eager + torch.distributed ran) and exits with their code - launch.py
     from lightning_asr_amd import launch
+    if launch.role(args.gpus) == "parent" and os.environ.get("LASR_BENCH_BACKEND", "nccl") == "nccl" and \
+            os.environ.get("LASR_DIST_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+        # (device_count() does not initialise the GPU; the rehearsal backends share devices round-robin and are exempt)
+        raise SystemExit("bench.py --gpus %d: this host shows %d GPU(s) - one process per GPU over RCCL needs %d"
+                         % (args.gpus, torch.cuda.device_count(), args.gpus))
     rc = launch.maybe_launch(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
     if rc is not None:
         sys.exit(rc)
