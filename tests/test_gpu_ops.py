@@ -628,7 +628,8 @@ def test_dwconv_wgrad_bf16_mfma(dev, C, k, T, B):
 def test_reduce_many_segments(dev):
     from lightning_asr_amd import ops
     g = torch.Generator().manual_seed(3)
-    shapes = [(16, 512 * 512), (1, 7), (32, 512 * 75), (5, 1000), (64, 33), (3, 2048), (7, 4096), (6, 100), (2, 1028), (4, 12)]
+    shapes = [(16, 512 * 512), (1, 7), (32, 512 * 75), (5, 1000), (64, 33), (3, 2048), (7, 4096), (6, 100), (2, 1028), (4, 12),
+              (3, 512 * 512), (3, 1024 * 5 + 17), (4, 1023), (2, 1024), (1, 4097)]
     segs, refs = [], []
     for (P, n) in shapes:
         pt = torch.randn(P, n, generator=g)
@@ -637,6 +638,10 @@ def test_reduce_many_segments(dev):
     ops.reduce_many(segs)
     for (pt, out), ref in zip(segs, refs):
         assert max_rel(out, ref) < 1e-6
+        P = pt.shape[0]
+        if P <= 4:     # split-K slabs (round 5: four elements per thread): the fixed-order f64 sum, bit for bit
+            v = [pt[u].cpu().double() if u < P else torch.zeros(pt.shape[1], dtype=torch.float64) for u in range(4)]
+            assert torch.equal(out.cpu(), ((v[0] + v[1]) + (v[2] + v[3])).float())
 
 
 def test_wgrad_multi_exact_integers(dev):
