@@ -379,6 +379,12 @@ int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float*
                        const int64_t* offsets, int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2,
                        float eps, float weight_decay, float grad_scale, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same step for a caller that KEEPS its workspace: zero it once before the first call (the per-tensor norm accumulators live
+ * there); every call leaves it zeroed, so the memset launch of lasr_novograd_step is not issued (round 5).                  */
+int lasr_novograd_step_keep(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                            const int64_t* offsets, int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2,
+                            float eps, float weight_decay, float grad_scale, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* roctx ranges (round 5; SURVEY 5 aux "tracing"): with LASR_ROCTX=1 in the environment the plan brackets its stages and units with
  * named ranges - "lasr:forward", "lasr:fwd <unit>", "lasr:head", "lasr:backward", "lasr:bwd <unit>", "lasr:wgrad flush", "lasr:reduce" -

@@ -90,6 +90,7 @@ SIGNATURES = {
     "lasr_greedy_decode": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p]),
     "lasr_novograd_workspace_bytes": (_sz, [_i64, _i64]),
     "lasr_novograd_step": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p, _sz, _p]),
+    "lasr_novograd_step_keep": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _p, _f32, _f32, _f32, _f32, _f32, _p, _sz, _p]),
     "lasr_cast_f32_to_bf16": (_i32, [_p, _p, _i64, _p]),
     "lasr_cast_pad_f32_to_bf16": (_i32, [_p, _p, _i64, _i64, _i64, _p]),
     "lasr_gemm_ld": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _p, _i32, _p, _sz, _p]),

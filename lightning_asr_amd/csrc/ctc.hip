@@ -132,12 +132,31 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     const float* be = beta + (b * T + t) * SP;
     const int64_t* tg = targets + b * S_max;
     float blank_occ = 0.f;
+    // the lane's NS lattice values of either direction as 16-byte loads, its labels and their log-probs requested with them (clamped
+    // indices, no branch around a load): as eight scalar loads + a label load + a gather per state inside `if (s < SS)` the row was a
+    // chain of dependent round trips (round 5)
+    float av[NS], bv[NS], lpc[NS];
+    int cls[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i += 4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(al + lane * NS + i);
+      const float4 b4 = *reinterpret_cast<const float4*>(be + lane * NS + i);
+      av[i] = a4.x; av[i + 1] = a4.y; av[i + 2] = a4.z; av[i + 3] = a4.w;
+      bv[i] = b4.x; bv[i + 1] = b4.y; bv[i + 2] = b4.z; bv[i + 3] = b4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int s = lane * NS + i;
+      const int64_t lab = S_max > 0 ? tg[min((int64_t)(s >> 1), S_max - 1)] : 0;   // (S_max = 0: an empty targets tensor)
+      cls[i] = (s & 1) ? (int)min(max(lab, (int64_t)0), C - 1) : blank;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) lpc[i] = lp[cls[i]];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int s = lane * NS + i;
       if (s < SS) {
-        const int c = (s & 1) ? (int)min(max(tg[s >> 1], (int64_t)0), C - 1) : blank;
-        const float v = expf(al[s] + be[s] + nl - lp[c]);
+        const float v = expf(av[i] + bv[i] + nl - lpc[i]);
         if (s & 1) s_v[s >> 1] = v;
         else blank_occ += v;
       }

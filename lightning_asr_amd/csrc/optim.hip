@@ -27,12 +27,15 @@ __global__ __launch_bounds__(256) void novograd_norm_kernel(const float* __restr
     if ((seg & 3) == 0) {   // 16-byte groups of the segment (every tensor of the model starts on one), scalar tail
       const int64_t nv = (tend - seg) >> 2;
       // four 16-byte loads in flight per thread (clamped address, masked value): a 64 KB slice is 4 rounds instead of 16 dependent trips
-      for (int64_t q0 = threadIdx.x; q0 < nv; q0 += 4 * 256) {
-        float4 g4[4];
+      // (round 3: 13.6 -> 10.1 us.  Round 5 tried sixteen in flight - one round per slice: 10.8 -> 18.2 us, the short tensors' slices
+      // then issue sixteen clamped duplicate loads each)
+      constexpr int kInFlight = 4;
+      for (int64_t q0 = threadIdx.x; q0 < nv; q0 += kInFlight * 256) {
+        float4 g4[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) g4[u] = *reinterpret_cast<const float4*>(grads + seg + 4 * min(q0 + 256 * u, nv - 1));
+        for (int u = 0; u < kInFlight; ++u) g4[u] = *reinterpret_cast<const float4*>(grads + seg + 4 * min(q0 + 256 * u, nv - 1));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kInFlight; ++u) {
           const float mk = q0 + 256 * u < nv ? grad_scale : 0.f;
           const float a = g4[u].x * mk, b = g4[u].y * mk, c = g4[u].z * mk, d = g4[u].w * mk;
           acc += ((double)a * (double)a + (double)b * (double)b) + ((double)c * (double)c + (double)d * (double)d);
@@ -142,9 +145,28 @@ extern "C" size_t lasr_novograd_workspace_bytes(int64_t n_tensors, int64_t n_ele
   return align_up((size_t)n_tensors * sizeof(float), 256) + align_up((size_t)n_tensors * sizeof(double), 256);
 }
 
+static int novograd_step_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* offsets,
+                              int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, void* workspace, size_t workspace_bytes, void* stream, bool zeroed);
+
 extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* offsets,
                                   int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2, float eps,
                                   float weight_decay, float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  return novograd_step_impl(params, grads, exp_avg, exp_avg_sq, offsets, n_tensors, n_elems, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                            workspace, workspace_bytes, stream, false);
+}
+// the same step on a workspace the caller keeps: zero before its FIRST use, left zero by every call (the moment kernel re-zeroes the
+// norm accumulators it has consumed) - the per-step memset launch (4.6 us in the cfg2 trace) is the caller's one-time torch.zeros
+extern "C" int lasr_novograd_step_keep(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* offsets,
+                                       int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2, float eps,
+                                       float weight_decay, float grad_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  return novograd_step_impl(params, grads, exp_avg, exp_avg_sq, offsets, n_tensors, n_elems, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                            workspace, workspace_bytes, stream, true);
+}
+
+static int novograd_step_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const int64_t* offsets,
+                              int64_t n_tensors, int64_t n_elems, const float* lr, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, void* workspace, size_t workspace_bytes, void* stream, bool zeroed) {
   LASR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && offsets && lr && workspace, "lasr_novograd_step: null pointer");
   LASR_CHECK_SHAPE(n_tensors > 0 && n_tensors < (1 << 20) && n_elems > 0, "lasr_novograd_step: n_tensors=%lld", (long long)n_tensors);
   if (workspace_bytes < lasr_novograd_workspace_bytes(n_tensors, n_elems)) return fail(LASR_E_WORKSPACE, "lasr_novograd_step: workspace");
@@ -154,8 +176,10 @@ extern "C" int lasr_novograd_step(float* params, const float* grads, float* exp_
   // (bench.py's class table) gradients read twice, parameters and momentum read and written
   const int tok = prof_begin(LASR_PROF_OTHER, st, 0.0, 6.0 * (double)n_elems * sizeof(float));
   struct End { int t; hipStream_t s; ~End() { prof_end(t, s); } } end_{tok, st};
-  hipError_t me = hipMemsetAsync(norm2, 0, (size_t)n_tensors * sizeof(double), st);
-  if (me != hipSuccess) return hip_fail(me, "lasr_novograd_step memset");
+  if (!zeroed) {
+    hipError_t me = hipMemsetAsync(norm2, 0, (size_t)n_tensors * sizeof(double), st);
+    if (me != hipSuccess) return hip_fail(me, "lasr_novograd_step memset");
+  }
   hipLaunchKernelGGL(novograd_norm_kernel, dim3((unsigned)cdiv(n_elems, kNormChunk)), dim3(256), 0, st, grads, offsets, (int)n_tensors,
                      n_elems, norm2, grad_scale);
   LASR_LAUNCH_CHECK("novograd_norm_kernel");

@@ -410,11 +410,21 @@ def greedy_decode(ids: torch.Tensor, lens: Optional[torch.Tensor], blank: int):
 
 
 # ---------------------------------------------------------------------------------- optimiser
+def novograd_workspace(n_tensors: int, n_elems: int, device) -> torch.Tensor:
+    """a ZEROED workspace a caller keeps across novograd_step(ws=...) calls (every call leaves it zeroed)"""
+    return torch.zeros(max(int(_lib.load().lasr_novograd_workspace_bytes(n_tensors, n_elems)), 256), dtype=torch.uint8, device=device)
+
+
 def novograd_step(params, grads, exp_avg, exp_avg_sq, offsets, lr_dev, beta1=0.8, beta2=0.5, eps=1e-8, weight_decay=0.0,
-                  grad_scale=1.0):
+                  grad_scale=1.0, ws: Optional[torch.Tensor] = None):
+    """ws: a workspace from novograd_workspace() kept by the caller - the step then issues no memset of its own"""
     n_t = exp_avg_sq.numel()
     n = params.numel()
     nb = _lib.load().lasr_novograd_workspace_bytes(n_t, n)
+    if ws is not None:
+        call("lasr_novograd_step_keep", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(offsets), n_t, n, _p(lr_dev), beta1,
+             beta2, eps, weight_decay, grad_scale, _p(ws), ws.numel(), _stream())
+        return
     ws = _ws(nb, params.device)
     call("lasr_novograd_step", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), _p(offsets), n_t, n, _p(lr_dev), beta1,
          beta2, eps, weight_decay, grad_scale, _p(ws), nb, _stream())

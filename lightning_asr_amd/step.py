@@ -147,8 +147,10 @@ class TrainStep:
             else:
                 torch.distributed.all_reduce(m.grads, group=self.pg)
         self._reduced = False
+        if getattr(self, "_opt_ws", None) is None:       # kept across steps: zeroed once, left zeroed by every step (no memset launch)
+            self._opt_ws = ops.novograd_workspace(self.exp_avg_sq.numel(), m.params.numel(), m.device)
         ops.novograd_step(m.params, m.grads, self.exp_avg, self.exp_avg_sq, self.offsets, self.lr_dev, self.betas[0],
-                          self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world)
+                          self.betas[1], self.eps, self.wd, grad_scale=1.0 / self.world, ws=self._opt_ws)
         if self.schedule is not None:
             if self._lr_state is not None and self.schedule.last_epoch != self._lr_epoch:
                 self.sync_device_schedule()                # the host schedule was loaded / reset since the last step

@@ -458,6 +458,19 @@ def test_novograd_matches_oracle(dev):
     ref_flat = torch.cat([p.flatten() for p in ref_p])
     assert max_rel(flat, ref_flat) < 2e-6
     assert max_rel(v, torch.stack([x for x in st.exp_avg_sq])) < 5e-5     # oracle sums ||g||^2 in f32
+    # the kept-workspace form (lasr_novograd_step_keep: zeroed once by the caller, left zeroed by every step, no memset launch):
+    # the same three steps land on the same bits as the form that zeroes per call
+    g2 = torch.Generator().manual_seed(9)
+    ps2 = [torch.randn(s, generator=g2) for s in shapes]
+    flat2 = torch.cat([p.flatten() for p in ps2]).to(dev)
+    m2, v2 = torch.zeros_like(flat2), torch.zeros(len(ps2), device=dev)
+    ws = ops.novograd_workspace(len(ps2), flat2.numel(), dev)
+    for step in range(3):
+        gr = [torch.randn(s, generator=g2) * (step + 1) for s in shapes]
+        gflat = torch.cat([x.flatten() for x in gr]).to(dev) * 4.0
+        ops.novograd_step(flat2, gflat, m2, v2, offsets, lr, 0.8, 0.5, 1e-8, 1e-3, grad_scale=0.25, ws=ws)
+    assert torch.equal(flat2, flat) and torch.equal(v2, v) and torch.equal(m2, m)
+    assert int(ws.view(torch.int32).abs().sum().item()) == 0 or bool((ws[256 * ((4 * len(ps2) + 255) // 256):] == 0).all())   # norm accumulators left zeroed
 
 
 # ----------------------------------------------------------------------------------------- bf16 MFMA GEMM
