@@ -82,7 +82,10 @@ class _Worker:
     def __init__(self, cmd: Sequence[str], env: Dict[str, str], capture: bool, stream: bool):
         self.lines: List[str] = []
         self.stream = stream
-        self.p = subprocess.Popen(list(cmd), env=env, stdout=subprocess.PIPE if capture else None, text=capture, bufsize=1 if capture else -1)
+        # rank 0: stdout is read here; every other rank's stdout goes to OUR stderr - stdout of the whole run carries what rank 0
+        # printed and nothing else (gloo, for one, announces its peers on stdout from every rank)
+        self.p = subprocess.Popen(list(cmd), env=env, stdout=subprocess.PIPE if capture else sys.stderr, text=capture,
+                                  bufsize=1 if capture else -1)
         self.t = None
         if capture:
             self.t = threading.Thread(target=self._pump, daemon=True)
@@ -151,15 +154,16 @@ def _last_json(lines: List[str]) -> Optional[dict]:
 
 
 def _emit(lines: List[str], record: dict, hold_json: bool) -> None:
-    """print what rank 0 printed; in hold_json mode the last JSON line gets the `launcher` record merged in"""
+    """hold_json mode: rank 0's last JSON line, with the `launcher` record merged in, is the ONLY thing written to stdout"""
     if not hold_json:
         return                               # (streamed live)
     js = _last_json(lines)
-    for line in lines:
+    for line in lines:                       # whatever else rank 0 said goes to stderr: stdout is the ONE JSON line
         s = line.strip()
         if js is not None and s.startswith("{") and s.endswith("}"):
             continue
-        sys.stdout.write(line)
+        sys.stderr.write(line)
+    sys.stderr.flush()
     if js is not None:
         js["launcher"] = record
         sys.stdout.write(json.dumps(js) + "\n")

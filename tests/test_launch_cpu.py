@@ -34,8 +34,8 @@ def test_plain_command_starts_its_own_ranks():
     assert js["world"] == 2 and js["sum"] == 3.0
     assert js["launcher"]["rung_index"] == 0 and js["launcher"]["rung"] == "graph + lasr_comm"
     assert js["launcher"]["attempts"][0]["exit_codes"] == [0, 0]
-    assert "some chatter" in r.stdout                       # everything else rank 0 printed is relayed too
-    assert r.stdout.count('"metric"') == 1                  # ONE JSON line
+    assert "some chatter" in r.stderr and "some chatter" not in r.stdout      # everything else rank 0 printed goes to stderr
+    assert r.stdout.count('"metric"') == 1 and len(r.stdout.strip().splitlines()) == 1      # stdout is the ONE JSON line
 
 
 def test_failed_rung_is_retried_in_fresh_processes_one_rung_down():
