@@ -134,9 +134,17 @@ __device__ __forceinline__ void wave_sync() {
 
 // grid: (ceil(T/16), B), block 256.  dB values -> db_out [B][T][64] f32 (workspace); per-block
 // (sum, sumsq) in double -> partials[b][blk][2].
+// Exchange rows of the FFT passes: element n of a wave's row sits at n + (n / 64) * kExPad doubles (mx()).  Pass 1 writes lane (g, k) =
+// (lane / 8, lane % 8) at n = 64 g + k + 8 r: with a 512-byte block per g the eight g's of a wave hit the same banks (8-way conflicts
+// on 16 of the 32 LDS instructions of a frame pair; 46 % of the kernel's LDS cycles were conflicts); 8 doubles of padding per block
+// rotate consecutive g's by 16 banks - two accesses per bank per half-wave, which 64-bit accesses cannot beat.  The unit-stride
+// accesses of the other passes keep their pattern (round 5).
+static constexpr int kExPad = 8;
+static constexpr int kExRow = kNfft + (kNfft / 64 - 1) * kExPad + 8;       // 576 doubles
+__device__ __forceinline__ int mx(int n) { return n + (n >> 6) * kExPad; }
 struct MelSmem {
-  double re[kWaves][kNfft];
-  double im[kWaves][kNfft];
+  double re[kWaves][kExRow];
+  double im[kWaves][kExRow];
   double twr[kNfft];
   double twi[kNfft];
   double red[kWaves][2];
@@ -149,8 +157,8 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
                                             int64_t L, int64_t T, float* __restrict__ db_out,
                                             double* __restrict__ partials, int32_t* __restrict__ frames_out,
                                             float* __restrict__ pct_out, int bx, int by, int nbx, MelSmem& sm) {
-  double (&s_re)[kWaves][kNfft] = sm.re;
-  double (&s_im)[kWaves][kNfft] = sm.im;
+  double (&s_re)[kWaves][kExRow] = sm.re;
+  double (&s_im)[kWaves][kExRow] = sm.im;
   double (&s_twr)[kNfft] = sm.twr;
   double (&s_twi)[kNfft] = sm.twi;
   double (&s_red)[kWaves][2] = sm.red;
@@ -287,20 +295,20 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
     fft8(v);
     wave_sync();  // previous iteration's readers are done with sre/sim
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { sre[lane * 8 + r] = v[kPerm[r]].re; sim[lane * 8 + r] = v[kPerm[r]].im; }
+    for (int r = 0; r < 8; ++r) { sre[mx(lane * 8) + r] = v[kPerm[r]].re; sim[mx(lane * 8) + r] = v[kPerm[r]].im; }
     wave_sync();
     // ---- pass 1 (Ns = 8)
     {
       const int k = lane & 7;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        cplx x = {sre[lane + 64 * r], sim[lane + 64 * r]};
+        cplx x = {sre[mx(lane + 64 * r)], sim[mx(lane + 64 * r)]};
         const int tw = r * k * 8;
         v[r] = cmul(x, cplx{s_twr[tw], s_twi[tw]});
       }
       fft8(v);
       wave_sync();
-      const int base = (lane >> 3) * 64 + k;
+      const int base = mx((lane >> 3) * 64) + k;             // (k + 8 r < 64: inside the block)
 #pragma unroll
       for (int r = 0; r < 8; ++r) { sre[base + r * 8] = v[kPerm[r]].re; sim[base + r * 8] = v[kPerm[r]].im; }
       wave_sync();
@@ -309,14 +317,14 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
     {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        cplx x = {sre[lane + 64 * r], sim[lane + 64 * r]};
+        cplx x = {sre[mx(lane + 64 * r)], sim[mx(lane + 64 * r)]};
         const int tw = r * lane;
         v[r] = cmul(x, cplx{s_twr[tw], s_twi[tw]});
       }
       fft8(v);
       wave_sync();
 #pragma unroll
-      for (int r = 0; r < 8; ++r) { sre[lane + 64 * r] = v[kPerm[r]].re; sim[lane + 64 * r] = v[kPerm[r]].im; }
+      for (int r = 0; r < 8; ++r) { sre[mx(lane + 64 * r)] = v[kPerm[r]].re; sim[mx(lane + 64 * r)] = v[kPerm[r]].im; }
       wave_sync();
     }
     // ---- split the two spectra: powers of bins 0..256 of A and B (bin k pairs with N - k)
@@ -325,7 +333,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
     for (int r = 0; r < 5; ++r) {
       const int k = (r < 4) ? lane + 64 * r : 256;
       const int km = (kNfft - k) & (kNfft - 1);
-      const double zr = sre[k], zi = sim[k], mr = sre[km], mi = sim[km];
+      const double zr = sre[mx(k)], zi = sim[mx(k)], mr = sre[mx(km)], mi = sim[mx(km)];
       const double ar = zr + mr, ai = zi - mi, br = zi + mi, bi = mr - zr;
       pa[r] = 0.25 * (ar * ar + ai * ai);
       pb[r] = 0.25 * (br * br + bi * bi);
