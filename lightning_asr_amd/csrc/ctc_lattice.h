@@ -244,13 +244,20 @@ __device__ __forceinline__ void ctc_alpha_beta_body(const float* __restrict__ lo
     }
   }
   __syncthreads();
-  // chain of equal labels (for the deterministic per-class sum in the gradient kernel)
-  for (int i = threadIdx.x; i < S; i += NT) {
+  // chain of equal labels (for the deterministic per-class sum in the gradient kernel).  By the helper waves where the workgroup has
+  // any (the fused feature + lattice grid): as two O(S) loops of dependent-latency LDS reads per label on the lattice waves they
+  // stood 6.5 us (S = 100) in front of the recursion (phase stamps, round 5).  One pass over the labels finds both answers: the
+  // smallest j > i with the same label, and whether any j < i has it.
+  constexpr int kChainT0 = NT > 128 ? 128 : 0, kChainN = NT > 128 ? NT - 128 : NT;
+  for (int i = (int)threadIdx.x - kChainT0; i >= 0 && i < S; i += kChainN) {
     const int me = s_tg[i];
-    int nx = -1;
-    for (int j = S - 1; j > i; --j) nx = (s_tg[j] == me) ? j : nx;
-    int first = 1;
-    for (int j = 0; j < i; ++j) first = (s_tg[j] == me) ? 0 : first;
+    int nx = -1, first = 1;
+#pragma unroll 8
+    for (int j = S - 1; j >= 0; --j) {
+      const bool same = s_tg[j] == me;
+      nx = (same && j > i) ? j : nx;
+      first = (same && j < i) ? 0 : first;
+    }
     next_same[(int64_t)b * S_max * 2 + i] = nx;
     next_same[(int64_t)b * S_max * 2 + S_max + i] = first;
   }

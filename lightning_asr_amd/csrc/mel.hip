@@ -142,6 +142,12 @@ __device__ __forceinline__ void wave_sync() {
 static constexpr int kExPad = 8;
 static constexpr int kExRow = kNfft + (kNfft / 64 - 1) * kExPad + 8;       // 576 doubles
 __device__ __forceinline__ int mx(int n) { return n + (n >> 6) * kExPad; }
+#ifdef LASR_MEL_STAMPS
+__device__ unsigned long long* g_mel_stamps = nullptr;   // debug builds only (tools/mel_stamps.py): phase times of every workgroup's wave 0
+#define MEL_STAMP(i_) do { if (g_mel_stamps && threadIdx.x == 0) g_mel_stamps[((int64_t)by * nbx + bx) * 8 + (i_)] = wall_clock64(); } while (0)
+#else
+#define MEL_STAMP(i_) do {} while (0)
+#endif
 struct MelSmem {
   double re[kWaves][kExRow];
   double im[kWaves][kExRow];
@@ -167,6 +173,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
 
   const int b = by;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  MEL_STAMP(0);
   // sample_lens[b]: valid samples; bit LASR_LEN_LEAD set = the row starts with ONE lead-in sample x[-1] in front of them (a crop
   // that does not begin at the file's first sample: the reference pre-emphasises BEFORE it crops, data_module.py:157-159, so the
   // crop's first sample is y[loc] - 0.97 y[loc-1], dither of both included)
@@ -269,6 +276,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
     }
   }
   __syncthreads();
+  MEL_STAMP(1);
 
   double acc_s = 0.0, acc_q = 0.0;
   double* sre = s_re[wid];
@@ -297,6 +305,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
 #pragma unroll
     for (int r = 0; r < 8; ++r) { sre[mx(lane * 8) + r] = v[kPerm[r]].re; sim[mx(lane * 8) + r] = v[kPerm[r]].im; }
     wave_sync();
+    if (it == 0) MEL_STAMP(2);
     // ---- pass 1 (Ns = 8)
     {
       const int k = lane & 7;
@@ -313,6 +322,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
       for (int r = 0; r < 8; ++r) { sre[base + r * 8] = v[kPerm[r]].re; sim[base + r * 8] = v[kPerm[r]].im; }
       wave_sync();
     }
+    if (it == 0) MEL_STAMP(3);
     // ---- pass 2 (Ns = 64): Z[lane + 64 r] = v[perm r]
     {
 #pragma unroll
@@ -327,6 +337,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
       for (int r = 0; r < 8; ++r) { sre[mx(lane + 64 * r)] = v[kPerm[r]].re; sim[mx(lane + 64 * r)] = v[kPerm[r]].im; }
       wave_sync();
     }
+    if (it == 0) MEL_STAMP(4);
     // ---- split the two spectra: powers of bins 0..256 of A and B (bin k pairs with N - k)
     double pa[5], pb[5];
 #pragma unroll
@@ -343,6 +354,7 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
     for (int r = 0; r < 4; ++r) { sre[lane + 64 * r] = pa[r]; sim[lane + 64 * r] = pb[r]; }
     if (lane == 0) { sre[256] = pa[4]; sim[256] = pb[4]; }
     wave_sync();
+    if (it == 0) MEL_STAMP(5);
     // ---- mel + dB: lane = mel channel, both frames
     double mA = 0.0, mB = 0.0;
 #pragma unroll
@@ -364,7 +376,9 @@ __device__ __forceinline__ void mel_db_body(const WaveSrc src, const int32_t* __
       }
       if (f < T) db_out[((int64_t)b * T + f) * kMel + lane] = db;
     }
+    if (it == 0) MEL_STAMP(6);
   }
+  MEL_STAMP(7);
   acc_s = wave_sum_d(acc_s);
   acc_q = wave_sum_d(acc_q);
   if (lane == 0) { s_red[wid][0] = acc_s; s_red[wid][1] = acc_q; }
@@ -469,6 +483,12 @@ __global__ __launch_bounds__(256) void mel_norm_kernel(const float* __restrict__
 
 using namespace lasr;
 
+#ifdef LASR_MEL_STAMPS
+extern "C" int lasr_debug_set_mel_stamps(void* buf) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lasr::g_mel_stamps), &p, sizeof(p));
+}
+#endif
 extern "C" int64_t lasr_mel_num_frames(int64_t n_samples) { return 1 + (n_samples + 2 * kPad) / kHop; }
 
 extern "C" size_t lasr_mel_workspace_bytes(int64_t B, int64_t T) {

@@ -1490,6 +1490,12 @@ extern "C" int lasr_reduce_many(const lasr_reduce_desc* descs, int n_descs, void
   LASR_CHECK_ARG(descs && n_descs >= 1 && n_descs <= 64, "lasr_reduce_many: 1..64 segments");
   lasr::ReduceMany a;
   int64_t nmax = 0;
+  static const bool dump = getenv("LASR_REDUCE_DUMP") != nullptr;      // dev aid: the segments of every launch on stderr
+  if (dump) {
+    fprintf(stderr, "lasr_reduce_many: %d segments:", n_descs);
+    for (int i = 0; i < n_descs; ++i) fprintf(stderr, " %lldx%d", (long long)descs[i].n, descs[i].n_partials);
+    fprintf(stderr, "\n");
+  }
   for (int i = 0; i < n_descs; ++i) {
     LASR_CHECK_ARG(descs[i].partials && descs[i].out && descs[i].n > 0 && descs[i].n_partials > 0, "lasr_reduce_many: bad segment");
     a.d[i] = descs[i];
