@@ -123,13 +123,20 @@ __device__ __forceinline__ uint4 load_chunk(const bf16_t* __restrict__ X, int ld
   else off = (uint32_t)min(k0 + c / RCH, kend - 1) * (uint32_t)ld + (uint32_t)min(r0 + ((c % RCH) << 3), ((R + 7) & ~7) - 8);
   return Vec<bf16_t>::raw_if_nt<NTL>(X + off);
 }
-template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_>
+// FULL: the K step that is staged lies wholly inside the K range (every step but a slice's last): no element to zero - the per-chunk
+// masks (compare, selects, four ANDs, a divergent branch for the partial chunk) cost ~60 VALU instructions and three exec-mask branches
+// per K step and wave in the steady-state loop, where they can never apply (round 5)
+template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_, bool FULL = false>
 __device__ __forceinline__ void store_chunk(char* __restrict__ s, const uint4& v, int k0, int kend, int p) {
   constexpr int RCH = ROWS / 8;
   const int c = threadIdx.x + NT * p;
-  const int nvalid = !TRANS ? kend - (k0 + ((c & 7) << 3)) : (k0 + c / RCH < kend ? 8 : 0);
   const int off = !TRANS ? (c >> 3) * LDK_ + ((c & 7) << 4) : (c / RCH) * LDR_ + ((c % RCH) << 4);
-  *reinterpret_cast<uint4*>(s + off) = mask_chunk(v, nvalid);
+  if constexpr (FULL) {
+    *reinterpret_cast<uint4*>(s + off) = v;
+  } else {
+    const int nvalid = !TRANS ? kend - (k0 + ((c & 7) << 3)) : (k0 + c / RCH < kend ? 8 : 0);
+    *reinterpret_cast<uint4*>(s + off) = mask_chunk(v, nvalid);
+  }
 }
 
 // generic path: any pitch/alignment, element-granular edges
@@ -526,7 +533,8 @@ __device__ __forceinline__ uint4 dual_row_mask(const Bf16Args& g, uint4 v, int k
   return make_uint4(v.x & mk, v.y & mk, v.z & mk, v.w & mk);
 }
 
-template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false, bool NTL = false>
+// FULLST: the step being staged (k_store) is not the slice's last one (store_chunk<FULL>)
+template <bool TRANS_A, bool TRANS_B, bool NARROW, bool STORE, bool LOAD, bool DUAL = false, bool NTL = false, bool FULLST = false>
 __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char* __restrict__ sB, char* __restrict__ dA,
                                          char* __restrict__ dB, f32x16 (&acc)[big::Cfg<NARROW>::MI][2], uint4 (&ra)[4],
                                          uint4 (&rb)[big::Cfg<NARROW>::NCB], const Bf16Args& g, int m0, int n0, int k_store,
@@ -558,10 +566,10 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
       // 8-byte row-major LDS writes (the natural order left 2-byte writes: 128 ds_write_b16 per lane, 9 us per launch)
       for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[cur][ni], a[cur][mi], acc[mi][ni], 0, 0, 0);
     if constexpr (STORE) {
-      if constexpr (DUAL) store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, dual_row_mask(g, ra[ks], k_store, ks, kma), k_store, kend, ks);
-      else store_chunk<TRANS_A, BTM, NT, LD_KC, LDR>(dA, ra[ks], k_store, kend, ks);
-      if constexpr (CF::NCB == 4) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks], k_store, kend, ks);
-      else if (ks < CF::NCB) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB>(dB, rb[ks < CF::NCB ? ks : 0], k_store, kend, ks);
+      if constexpr (DUAL) store_chunk<TRANS_A, BTM, NT, LD_KC, LDR, FULLST>(dA, dual_row_mask(g, ra[ks], k_store, ks, kma), k_store, kend, ks);
+      else store_chunk<TRANS_A, BTM, NT, LD_KC, LDR, FULLST>(dA, ra[ks], k_store, kend, ks);
+      if constexpr (CF::NCB == 4) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB, FULLST>(dB, rb[ks], k_store, kend, ks);
+      else if (ks < CF::NCB) store_chunk<TRANS_B, CF::BN, NT, LD_KC, CF::LDRB, FULLST>(dB, rb[ks < CF::NCB ? ks : 0], k_store, kend, ks);
     }
     if constexpr (LOAD) {
       if constexpr (DUAL) ra[ks] = load_chunk_dual(g, m0, k_load, ks, kma);
@@ -665,7 +673,8 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     for (; it + 2 < nk; ++it) {
       const char* sA = smem + (it & 1) * BUF;
       char* dA = smem + ((it + 1) & 1) * BUF;
-      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL, NTL>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
+      // (it + 2 < nk: the step staged here, it + 1, is never the last one)
+      big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL, NTL, true>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
                                              kbeg + (it + 2) * TK, kend, wm, wn, lane, kma);
       __syncthreads();
     }
