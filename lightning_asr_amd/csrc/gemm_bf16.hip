@@ -585,6 +585,7 @@ __device__ __forceinline__ void big_step(const char* __restrict__ sA, const char
 // first 4096 workgroups of a launch.  The buffer is set by lasr_debug_set_gemm_stamps (tools/gemm_stamps.py).
 __device__ unsigned long long* g_stamps = nullptr;
 #define LASR_STAMP(i_) do { if (stamps && threadIdx.x == 0 && blockIdx.x < 4096) stamps[blockIdx.x * 8 + (i_)] = wall_clock64(); } while (0)
+// slots 6, 7: shader cycles (s_memtime) of the K loop, and of them the cycles wave 0 stood at the loop's barriers
 #else
 #define LASR_STAMP(i_) do {} while (0)
 #endif
@@ -667,6 +668,10 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
   }
   __syncthreads();
   LASR_STAMP(1);
+#ifdef LASR_GEMM_STAMPS
+  unsigned long long kstamp_barrier = 0;                   // shader cycles this wave stood at the loop's barriers
+  const unsigned long long kstamp_c0 = __builtin_readcyclecounter();
+#endif
   {
     // steady state: compute step it, stage step it+1 (registers -> other image), fetch step it+2
     int it = 0;
@@ -676,7 +681,14 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
       // (it + 2 < nk: the step staged here, it + 1, is never the last one)
       big_step<TRANS_A, TRANS_B, NARROW, true, true, DUAL, NTL, true>(sA, sA + OPER, dA, dA + OPER, acc, ra, rb, g, m0, n0, kbeg + (it + 1) * TK,
                                              kbeg + (it + 2) * TK, kend, wm, wn, lane, kma);
+#ifdef LASR_GEMM_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long tb0 = __builtin_readcyclecounter();
       __syncthreads();
+      kstamp_barrier += __builtin_readcyclecounter() - tb0;
+#else
+      __syncthreads();
+#endif
     }
     if (it + 1 < nk) {
       const char* sA = smem + (it & 1) * BUF;
@@ -691,6 +703,12 @@ __device__ __forceinline__ void gemm_bf16_big_tile(const Bf16Args& g, const int 
     __syncthreads();
   }
   LASR_STAMP(2);
+#ifdef LASR_GEMM_STAMPS
+  if (stamps && threadIdx.x == 0 && blockIdx.x < 4096) {
+    stamps[blockIdx.x * 8 + 6] = __builtin_readcyclecounter() - kstamp_c0;
+    stamps[blockIdx.x * 8 + 7] = kstamp_barrier;
+  }
+#endif
   // ---- epilogue: bias, row mask, bf16 rounding, BN column sums.  The whole tile is laid out row-major in LDS as
   //      bf16 (528 / 272-byte rows over the operand images, free after the last barrier): a lane owns output row l31
   //      of each of its MFMA tiles and 4 consecutive columns per register quad -> one packed conversion per pair and

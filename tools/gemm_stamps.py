@@ -29,6 +29,7 @@ for (N, K, tB) in [(512, 512, 0), (512, 64, 0), (256, 256, 0), (512, 512, 1), (1
         _lib.check(lib.lasr_gemm_batch(ps, 2, 1, 1, 0, tB, 1, ws.data_ptr(), ws.numel(), st), "gemm")
         torch.cuda.synchronize()
     t = stamps.view(4096, 8).cpu()
+    cyc, bar = t[:, 6].double(), t[:, 7].double()   # shader cycles (s_memtime) across the K loop; of them, wave 0 at the loop's barriers
     e = t[:, [2, 5, 3]].double() * 0.01
     nb = int((t[:, 0] != 0).sum())
     t = t[:nb, :5].double() * 0.01          # 100 MHz ticks -> us
@@ -36,6 +37,10 @@ for (N, K, tB) in [(512, 512, 0), (512, 64, 0), (256, 256, 0), (512, 512, 1), (1
     ph = (t[:, 1:] - t[:, :-1])
     print("N=%d K=%d tB=%d: %d workgroups; launch span %.1f us; start skew mean %.1f max %.1f us" % (
         N, K, tB, nb, float(t[:, 4].max() - t0), float((t[:, 0] - t0).mean()), float((t[:, 0] - t0).max())))
+    kl = ph[:, 1]
+    print("   K loop: %.0f shader cycles mean (%.0f per 64-deep K step) in %.2f us -> shader clock %.0f MHz while it runs; wave 0 at the steady-state barriers: %.0f cycles per step"
+          % (float(cyc[:nb].mean()), float(cyc[:nb].mean()) / max(K // 64, 1), float(kl.mean()), float((cyc[:nb] / kl).mean()),
+             float(bar[:nb].mean()) / max(K // 64 - 2, 1)))
     ee = (e[:nb, 1:] - e[:nb, :-1])
     print("   epilogue of wave 0: convert + LDS image + barrier %.2f | 16 row-pair stores %.2f us (means); max %s" % (
         *[float(ee[:, i].mean()) for i in range(2)], [round(float(ee[:, i].max()), 1) for i in range(2)]))
