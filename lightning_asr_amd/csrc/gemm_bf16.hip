@@ -98,18 +98,23 @@ __device__ __forceinline__ void load_vec(const bf16_t* __restrict__ X, int ld, i
   }
 }
 
-template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_, int NCH = 4>
+// FULL: the step lies wholly inside the K range - nothing to zero (see store_chunk)
+template <bool TRANS, int ROWS, int NT, int LDK_, int LDR_, int NCH = 4, bool FULL = false>
 __device__ __forceinline__ void store_vec(char* __restrict__ s, const uint4 (&reg)[NCH], int k0, int kend) {
   constexpr int RCH = ROWS / 8;
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < NCH; ++p) {
     const int c = tid + NT * p;
-    // elements past the K range become zero: whole k-rows of a row-contiguous operand, the tail elements of a
-    // K-contiguous chunk (K need not be a multiple of 8; the pitch is, so the chunk itself is in bounds)
-    const int nvalid = !TRANS ? kend - (k0 + ((c & 7) << 3)) : (k0 + c / RCH < kend ? 8 : 0);
     const int off = !TRANS ? (c >> 3) * LDK_ + ((c & 7) << 4) : (c / RCH) * LDR_ + ((c % RCH) << 4);
-    *reinterpret_cast<uint4*>(s + off) = mask_chunk(reg[p], nvalid);
+    if constexpr (FULL) {
+      *reinterpret_cast<uint4*>(s + off) = reg[p];
+    } else {
+      // elements past the K range become zero: whole k-rows of a row-contiguous operand, the tail elements of a
+      // K-contiguous chunk (K need not be a multiple of 8; the pitch is, so the chunk itself is in bounds)
+      const int nvalid = !TRANS ? kend - (k0 + ((c & 7) << 3)) : (k0 + c / RCH < kend ? 8 : 0);
+      *reinterpret_cast<uint4*>(s + off) = mask_chunk(reg[p], nvalid);
+    }
   }
 }
 
@@ -272,8 +277,13 @@ __device__ __forceinline__ void gemm_bf16_tile(const Bf16Args& g, const int lid)
   }
 #define LASR_STORE(RA_, RB_, K0_)                                                         \
   if constexpr (VEC) {                                                                   \
-    store_vec<TRANS_A, TM, 256, LD_KC, LD_RC>(sA, RA_, (K0_), kend);                     \
-    store_vec<TRANS_B, TN, 256, LD_KC, LD_RC>(sB, RB_, (K0_), kend);                     \
+    if ((K0_) + TK <= kend) {             /* workgroup-uniform: an interior step, no K-tail masks */ \
+      store_vec<TRANS_A, TM, 256, LD_KC, LD_RC, 4, true>(sA, RA_, (K0_), kend);          \
+      store_vec<TRANS_B, TN, 256, LD_KC, LD_RC, 4, true>(sB, RB_, (K0_), kend);          \
+    } else {                                                                             \
+      store_vec<TRANS_A, TM, 256, LD_KC, LD_RC>(sA, RA_, (K0_), kend);                   \
+      store_vec<TRANS_B, TN, 256, LD_KC, LD_RC>(sB, RB_, (K0_), kend);                   \
+    }                                                                                    \
   } else {                                                                               \
     store_oper<TRANS_A>(sA, RA_);                                                        \
     store_oper<TRANS_B>(sB, RB_);                                                        \
